@@ -1,0 +1,122 @@
+"""ctypes binding of libmrl.so (C ABI declared in include/mrl.h).
+
+The product path has NO CPU fallback: if the library is missing or no HIP device is visible,
+every op raises.  (The oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmrl.so')
+
+c_void_p, c_int, c_long, c_float, c_double, c_size_t, c_char_p = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_char_p)
+
+
+class ModelDesc(ctypes.Structure):
+    """mirror of mrl_model_desc (include/mrl.h)"""
+    _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
+                ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('value_copy', c_int),
+                ('pd_kind', c_int), ('nact', c_int)]
+
+
+NET_MLP, NET_NATURE_CNN = 0, 1
+PD_CATEGORICAL, PD_DIAG_GAUSSIAN = 0, 1
+OB_F32, OB_U8 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+# name -> (restype, argtypes); the single source of truth for tests/test_abi.py as well
+SIGNATURES = {
+    'mrl_version': (c_int, []),
+    'mrl_strerror': (c_char_p, [c_int]),
+    'mrl_device_count': (c_int, []),
+    'mrl_gae': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p,
+                        c_int, c_int, c_void_p]),
+    'mrl_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'mrl_sf01': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'mrl_model_create': (c_int, [ctypes.POINTER(ModelDesc), ctypes.POINTER(c_void_p)]),
+    'mrl_model_destroy': (None, [c_void_p]),
+    'mrl_model_num_params': (c_long, [c_void_p]),
+    'mrl_model_num_tensors': (c_int, [c_void_p]),
+    'mrl_model_tensor_info': (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int),
+                                      ctypes.POINTER(c_int * 4), ctypes.POINTER(c_long), ctypes.POINTER(c_float)]),
+    'mrl_model_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'mrl_model_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_model_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                               c_size_t, c_int, c_void_p]),
+    'mrl_adam_scratch_bytes': (c_size_t, [c_long]),
+    'mrl_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
+                                   c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class MrlError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmrl.so; raises if it has not been built (python -m baselines_amd.csrc.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrlError('libmrl.so not found at %s -- build it with `python -m baselines_amd.csrc.build` '
+                       '(there is no CPU fallback)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name):
+            continue   # optional groups (envs / replay) are bound by their own modules
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def bind(name, restype, argtypes):
+    """Bind an additional symbol (used by optional modules)."""
+    lib = load()
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    SIGNATURES.setdefault(name, (restype, argtypes))
+    return fn
+
+
+def check(rc, what='mrl call'):
+    if rc != 0:
+        msg = load().mrl_strerror(int(rc))
+        raise MrlError('%s failed: rc=%d (%s)' % (what, rc, msg.decode() if msg else '?'))
+
+
+_gpu_ok = None
+
+
+def require_gpu():
+    """Raise unless a HIP device is usable.  Called by every device object constructor."""
+    global _gpu_ok
+    if _gpu_ok:
+        return
+    import torch
+    lib = load()
+    if not torch.cuda.is_available() or lib.mrl_device_count() <= 0:
+        raise MrlError('baselines_amd needs an AMD GPU (gfx950): no HIP device visible and there is no CPU path')
+    _gpu_ok = True
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (so our launches order with torch's allocator/copies)."""
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), 'expected a contiguous device tensor'
+    return c_void_p(t.data_ptr())

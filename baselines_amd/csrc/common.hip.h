@@ -1,0 +1,39 @@
+// shared host/device helpers for libmrl
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mrl.h"
+
+#define MRL_HIP_CHECK(expr)                           \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) return (int)_e;         \
+    } while (0)
+
+#define MRL_LAUNCH_CHECK()                            \
+    do {                                              \
+        hipError_t _e = hipGetLastError();            \
+        if (_e != hipSuccess) return (int)_e;         \
+    } while (0)
+
+namespace mrl {
+
+// deterministic block-wide sum of doubles (256 threads), result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double* sh /* >= 4 doubles */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    return r;
+}
+
+// env-major flat index (runner.py:69-74) -> time-major storage row
+__device__ __forceinline__ long envmajor_to_row(long i, int T, int N) { return (i % T) * (long)N + i / T; }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace mrl

@@ -1,0 +1,905 @@
+// PPO2 policy/value model on gfx950: layout object, forward/backward orchestration over the
+// MFMA implicit-GEMM template (gemm.hip.h), fused heads + loss + closed-form gradients,
+// act-side sampling, deterministic reductions.
+//
+// Reference map (paths relative to baselines/):
+//   networks   common/models.py:15-26 (nature_cnn), :74-103 (mlp); a2c/utils.py:37-63 (conv, fc)
+//   heads      common/policies.py:43-64; common/distributions.py:59-113 (+ _matching_fc :351-355)
+//   pd maths   common/distributions.py:153-204, 227-251
+//   loss       ppo2/model.py:57-91;  adv normalisation ppo2/model.py:136-139
+//   gather     ppo2/ppo2.py:157-165 (fused into the first-layer loaders; sf01 runner.py:69-74 eliminated)
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "common.hip.h"
+#include "gemm.hip.h"
+
+using namespace mrl;
+
+// ============================================================================================
+// host-side layout
+// ============================================================================================
+struct Layer {
+    int kind;   // 0 conv, 1 fc
+    int H, W, C, rf, stride, OH, OW, NF;   // conv
+    int K, N;                              // fc (and conv: K = rf*rf*C, N = NF)
+    int act;
+    long w_off, b_off;
+    long out_elems;                        // per sample
+};
+
+struct Net {
+    std::vector<Layer> L;
+    int nlat;
+    int lat_act;
+};
+
+struct TensorInfo {
+    std::string name;
+    int ndim;
+    int shape[4];
+    long off;
+    float scale;   // <0: zeros
+};
+
+struct mrl_model {
+    mrl_model_desc d;
+    Net pi, vf;
+    bool vf_copy;
+    bool has_pi_head;
+    long pi_w, pi_b, logstd, vf_w, vf_b;   // flat offsets (-1: absent)
+    long head_off;                         // first head parameter (heads are contiguous at the tail)
+    int HP;                                // number of head parameters
+    long P;
+    long ob_elems;
+    std::vector<TensorInfo> tensors;
+};
+
+static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> shape, float scale) {
+    TensorInfo t;
+    t.name = name;
+    t.ndim = (int)shape.size();
+    long n = 1;
+    for (int i = 0; i < 4; ++i) {
+        t.shape[i] = i < t.ndim ? shape[i] : 1;
+        n *= t.shape[i];
+    }
+    t.off = m->P;
+    t.scale = scale;
+    m->tensors.push_back(t);
+    m->P += n;
+    return t.off;
+}
+
+static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
+    const mrl_model_desc& d = m->d;
+    const float s2 = sqrtf(2.f);
+    if (d.network == MRL_NET_NATURE_CNN) {
+        if (d.ob_ndim != 3 || d.ob_dtype != MRL_OB_U8 || d.ob_shape[2] % 4 != 0) return MRL_EUNSUP;
+        int H = d.ob_shape[0], W = d.ob_shape[1], C = d.ob_shape[2];
+        const int nf[3] = {32, 64, 64}, rf[3] = {8, 4, 3}, st[3] = {4, 2, 1};
+        const char* nm[3] = {"c1", "c2", "c3"};
+        for (int i = 0; i < 3; ++i) {
+            Layer l{};
+            l.kind = 0; l.H = H; l.W = W; l.C = C; l.rf = rf[i]; l.stride = st[i]; l.NF = nf[i];
+            if (H < rf[i] || W < rf[i]) return MRL_EUNSUP;
+            l.OH = (H - rf[i]) / st[i] + 1;
+            l.OW = (W - rf[i]) / st[i] + 1;
+            l.K = rf[i] * rf[i] * C; l.N = nf[i]; l.act = ACT_RELU;
+            l.w_off = add_tensor(m, prefix + "/" + nm[i] + "/w", {rf[i], rf[i], C, nf[i]}, s2);
+            l.b_off = add_tensor(m, prefix + "/" + nm[i] + "/b", {1, nf[i], 1, 1}, -1.f);
+            l.out_elems = (long)l.OH * l.OW * l.NF;
+            net.L.push_back(l);
+            H = l.OH; W = l.OW; C = l.NF;
+        }
+        Layer f{};
+        f.kind = 1; f.K = H * W * C; f.N = 512; f.act = ACT_RELU;
+        f.w_off = add_tensor(m, prefix + "/fc1/w", {f.K, f.N}, s2);
+        f.b_off = add_tensor(m, prefix + "/fc1/b", {f.N}, -1.f);
+        f.out_elems = f.N;
+        net.L.push_back(f);
+        net.nlat = 512; net.lat_act = ACT_RELU;
+        return 0;
+    } else if (d.network == MRL_NET_MLP) {
+        if (d.ob_dtype != MRL_OB_F32 || d.num_layers < 1 || d.num_layers > 8 || d.num_hidden < 1) return MRL_EUNSUP;
+        int nin = (int)m->ob_elems;
+        for (int i = 0; i < d.num_layers; ++i) {
+            Layer f{};
+            f.kind = 1; f.K = nin; f.N = d.num_hidden; f.act = d.activation;
+            char nm[32];
+            snprintf(nm, sizeof nm, "/mlp_fc%d", i);
+            f.w_off = add_tensor(m, prefix + nm + "/w", {f.K, f.N}, s2);
+            f.b_off = add_tensor(m, prefix + nm + "/b", {f.N}, -1.f);
+            f.out_elems = f.N;
+            net.L.push_back(f);
+            nin = f.N;
+        }
+        net.nlat = nin; net.lat_act = d.activation;
+        return 0;
+    }
+    return MRL_EUNSUP;
+}
+
+extern "C" int mrl_model_create(const mrl_model_desc* desc, mrl_model** out) {
+    if (!desc || !out) return MRL_EINVAL;
+    if (desc->nact < 1 || desc->ob_ndim < 1 || desc->ob_ndim > 3) return MRL_EINVAL;
+    if (desc->pd_kind != MRL_PD_CATEGORICAL && desc->pd_kind != MRL_PD_DIAG_GAUSSIAN) return MRL_EUNSUP;
+    mrl_model* m = new mrl_model();
+    m->d = *desc;
+    m->P = 0;
+    m->ob_elems = 1;
+    for (int i = 0; i < desc->ob_ndim; ++i) m->ob_elems *= desc->ob_shape[i];
+    m->vf_copy = desc->value_copy != 0;
+    int rc = build_net(m, m->pi, "ppo2_model/pi");
+    if (rc == 0 && m->vf_copy) rc = build_net(m, m->vf, "ppo2_model/vf");
+    if (rc) { delete m; return rc; }
+    const int nlat = m->pi.nlat, nlatv = m->vf_copy ? m->vf.nlat : nlat;
+    m->head_off = m->P;
+    m->has_pi_head = (nlat != desc->nact);   // distributions.py:351-355
+    m->pi_w = m->pi_b = m->logstd = -1;
+    if (m->has_pi_head) {
+        m->pi_w = add_tensor(m, "ppo2_model/pi/w", {nlat, desc->nact}, 0.01f);
+        m->pi_b = add_tensor(m, "ppo2_model/pi/b", {desc->nact}, -1.f);
+    }
+    if (desc->pd_kind == MRL_PD_DIAG_GAUSSIAN) m->logstd = add_tensor(m, "ppo2_model/pi/logstd", {1, desc->nact}, -1.f);
+    m->vf_w = add_tensor(m, "ppo2_model/vf/w", {nlatv, 1}, 1.0f);
+    m->vf_b = add_tensor(m, "ppo2_model/vf/b", {1}, -1.f);
+    m->HP = (int)(m->P - m->head_off);
+    *out = m;
+    return 0;
+}
+
+extern "C" void mrl_model_destroy(mrl_model* m) { delete m; }
+extern "C" long mrl_model_num_params(const mrl_model* m) { return m ? m->P : 0; }
+extern "C" int mrl_model_num_tensors(const mrl_model* m) { return m ? (int)m->tensors.size() : 0; }
+
+extern "C" int mrl_model_tensor_info(const mrl_model* m, int i, char* name, int name_cap, int* ndim, int shape[4],
+                                     long* offset, float* init_scale) {
+    if (!m || i < 0 || i >= (int)m->tensors.size()) return MRL_EINVAL;
+    const TensorInfo& t = m->tensors[i];
+    if (name && name_cap > 0) {
+        strncpy(name, t.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (ndim) *ndim = t.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
+    if (offset) *offset = t.off;
+    if (init_scale) *init_scale = t.scale;
+    return 0;
+}
+
+// ---- workspace carving ------------------------------------------------------------------
+struct NetWs {
+    std::vector<float*> h, dz;
+};
+struct Ws {
+    NetWs pi, vf;
+    float* pdparam;      // [chunk][nact]  (act side)
+    float* part;         // split-K / bias / head partial slabs
+    size_t part_floats;
+    double* dscratch;    // adv partials [ADV_G][2] | head stat partials [HEAD_MAXBLK][5] | stats acc [5]
+    float* advstat;      // [2]
+    size_t total;
+};
+
+constexpr int ADV_G = 256;
+constexpr int HEAD_MAXBLK = 512;
+constexpr int BIAS_MAXBLK = 512;
+constexpr int WGRAD_TARGET_WGS = 1536;
+
+struct Split { int nsplit, ksplit; };
+static Split pick_split(int Mp, int Np, long Kp) {
+    int bn = Np <= 32 ? 32 : (Np <= 64 ? 64 : 128);
+    long tiles = (long)((Mp + 127) / 128) * ((Np + bn - 1) / bn);
+    long ns = std::max<long>(1, WGRAD_TARGET_WGS / std::max<long>(1, tiles));
+    long maxns = std::max<long>(1, Kp / 128);
+    ns = std::min(ns, maxns);
+    long ks = (Kp + ns - 1) / ns;
+    ks = (ks + 31) / 32 * 32;
+    Split s;
+    s.ksplit = (int)ks;
+    s.nsplit = (int)((Kp + ks - 1) / ks);
+    return s;
+}
+
+static long layer_rows(const Layer& l, int B) { return l.kind == 0 ? (long)B * l.OH * l.OW : (long)B; }
+
+static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    size_t part_floats = (size_t)HEAD_MAXBLK * m->HP;
+    auto do_net = [&](const Net& net, NetWs& nw) {
+        nw.h.clear(); nw.dz.clear();
+        for (const Layer& l : net.L) {
+            nw.h.push_back((float*)take((size_t)chunk * l.out_elems * 4));
+            nw.dz.push_back((float*)take((size_t)chunk * l.out_elems * 4));
+            Split s = pick_split(l.K, l.N, layer_rows(l, chunk));
+            part_floats = std::max(part_floats, (size_t)s.nsplit * l.K * l.N);
+            part_floats = std::max(part_floats, (size_t)BIAS_MAXBLK * l.N);
+        }
+    };
+    do_net(m->pi, ws.pi);
+    if (m->vf_copy) do_net(m->vf, ws.vf);
+    ws.pdparam = (float*)take((size_t)chunk * m->d.nact * 4);
+    ws.part = (float*)take(part_floats * 4);
+    ws.part_floats = part_floats;
+    ws.dscratch = (double*)take((size_t)(ADV_G * 2 + HEAD_MAXBLK * 5 + 8) * 8);
+    ws.advstat = (float*)take(64);
+    ws.total = off;
+}
+
+extern "C" size_t mrl_model_workspace_bytes(const mrl_model* m, int chunk) {
+    if (!m || chunk <= 0) return 0;
+    Ws ws;
+    carve(m, chunk, nullptr, ws);
+    return ws.total;
+}
+
+// ============================================================================================
+// small kernels
+// ============================================================================================
+
+// out[i] = (accumulate ? out[i] : 0) + sum_z part[z*slab + i]   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, long slab, int nz,
+                                                           float* __restrict__ out, long n, int accumulate) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int z = 0; z < nz; ++z) s += part[(long)z * slab + i];
+        out[i] = s;
+    }
+}
+static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st) {
+    int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// column sums of dz [rows][N] -> part[blk][N]   (bias gradient, tf.gradients of `+ b`)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, long rows, int N,
+                                                     float* __restrict__ part) {
+    extern __shared__ float sh[];   // [256]
+    const int tid = threadIdx.x;
+    long rpb = (rows + gridDim.x - 1) / gridDim.x;
+    long r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+    if (N <= 256 && 256 % N == 0) {
+        int RL = 256 / N, c = tid % N, rl = tid / N;
+        float s = 0.f;
+        for (long r = r0 + rl; r < r1; r += RL) s += dz[r * N + c];
+        sh[tid] = s;
+        __syncthreads();
+        if (rl == 0) {
+            float t = 0.f;
+            for (int q = 0; q < RL; ++q) t += sh[q * N + c];
+            part[(long)blockIdx.x * N + c] = t;
+        }
+    } else {
+        for (int c = tid; c < N; c += 256) {
+            float s = 0.f;
+            for (long r = r0; r < r1; ++r) s += dz[r * N + c];
+            part[(long)blockIdx.x * N + c] = s;
+        }
+    }
+}
+
+// advantage statistics over the minibatch (model.py:136-139), f64 accumulation
+__global__ __launch_bounds__(256) void advstat_part_kernel(const float* __restrict__ ret, const float* __restrict__ val,
+                                                           const int64_t* __restrict__ idx, int B, int T, int N,
+                                                           double* __restrict__ part) {
+    __shared__ double sh[4];
+    double s = 0.0, s2 = 0.0;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        long r = idx ? envmajor_to_row(idx[b], T, N) : b;
+        float a = __fsub_rn(ret[r], val[r]);
+        s += (double)a;
+        s2 += (double)a * (double)a;
+    }
+    double t = block_sum_256(s, sh);
+    double t2 = block_sum_256(s2, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = t; part[blockIdx.x * 2 + 1] = t2; }
+}
+__global__ __launch_bounds__(256) void advstat_final_kernel(const double* __restrict__ part, int G, int B,
+                                                            float* __restrict__ advstat, double* __restrict__ stats_acc) {
+    __shared__ double sh[4];
+    double s = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < G; i += 256) { s += part[i * 2]; s2 += part[i * 2 + 1]; }
+    double t = block_sum_256(s, sh);
+    double t2 = block_sum_256(s2, sh);
+    if (threadIdx.x == 0) {
+        double mean = t / B;
+        double var = t2 / B - mean * mean;
+        if (var < 0) var = 0;
+        advstat[0] = (float)mean;
+        advstat[1] = (float)sqrt(var);
+    }
+    if (threadIdx.x < 5) stats_acc[threadIdx.x] = 0.0;
+}
+
+// ---- heads ---------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* lat; const float* vlat; int nlat, nlatv; int shared; int lat_act, vlat_act;
+    const float* Wpi; const float* bpi; const float* logstd; const float* Wvf; const float* bvf;
+    int has_pi_head, pd_kind, nact, HP, TS;
+    // training inputs
+    const void* actions; const float* returns; const float* values; const float* neglogp;
+    const int64_t* idx; long row0; int T, N; int Bc;
+    const float* advstat; float cliprange, ent_coef, vf_coef, invB;
+    float* dz_pi; float* dz_vf; float* hpart; double* spart;
+    // act inputs / outputs
+    const float* noise; void* actions_out; float* values_out; float* neglogp_out; float* pdparam_out;
+};
+
+struct HeadLds {
+    float *lat, *vlat, *Wpi, *Wvf, *bpi, *logstd, *hacc, *pi, *dpi, *dls, *v, *dv;
+};
+__host__ __device__ static inline size_t head_lds_carve(const HeadArgs& a, bool train, float* base, HeadLds& L) {
+    size_t o = 0;
+    auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += (n + 3) / 4 * 4; return p; };
+    L.lat = take((size_t)a.TS * (a.nlat + 1));
+    L.vlat = a.shared ? L.lat : take((size_t)a.TS * (a.nlatv + 1));
+    L.Wpi = a.has_pi_head ? take((size_t)a.nlat * a.nact) : nullptr;
+    L.Wvf = take(a.nlatv);
+    L.bpi = take(a.nact);
+    L.logstd = take(a.nact);
+    L.pi = take((size_t)a.TS * a.nact);
+    L.v = take(a.TS);
+    if (train) {
+        L.hacc = take(a.HP);
+        L.dpi = take((size_t)a.TS * a.nact);
+        L.dls = take((size_t)a.TS * a.nact);
+        L.dv = take(a.TS);
+    } else {
+        L.hacc = L.dpi = L.dls = L.dv = nullptr;
+    }
+    return o * sizeof(float);
+}
+
+__device__ __forceinline__ void head_load_weights(const HeadArgs& a, const HeadLds& L) {
+    const int tid = threadIdx.x;
+    if (a.has_pi_head) {
+        for (int q = tid; q < a.nlat * a.nact; q += 256) L.Wpi[q] = a.Wpi[q];
+        for (int q = tid; q < a.nact; q += 256) L.bpi[q] = a.bpi[q];
+    }
+    for (int q = tid; q < a.nlatv; q += 256) L.Wvf[q] = a.Wvf[q];
+    if (a.pd_kind == MRL_PD_DIAG_GAUSSIAN)
+        for (int q = tid; q < a.nact; q += 256) L.logstd[q] = a.logstd[q];
+}
+
+// stage the latent rows of a tile and compute pdparam (logits / mean) and the value
+__device__ __forceinline__ void head_tile_forward(const HeadArgs& a, const HeadLds& L, int s0, int ns) {
+    const int tid = threadIdx.x;
+    for (int q = tid; q < ns * a.nlat; q += 256) {
+        int s = q / a.nlat, k = q - s * a.nlat;
+        L.lat[s * (a.nlat + 1) + k] = a.lat[(long)(s0 + s) * a.nlat + k];
+    }
+    if (!a.shared)
+        for (int q = tid; q < ns * a.nlatv; q += 256) {
+            int s = q / a.nlatv, k = q - s * a.nlatv;
+            L.vlat[s * (a.nlatv + 1) + k] = a.vlat[(long)(s0 + s) * a.nlatv + k];
+        }
+    __syncthreads();
+    const int nout = a.nact + 1;
+    for (int q = tid; q < ns * nout; q += 256) {
+        int s = q / nout, j = q - s * nout;
+        if (j < a.nact) {
+            float acc;
+            if (a.has_pi_head) {
+                acc = 0.f;
+                const float* x = L.lat + s * (a.nlat + 1);
+                for (int k = 0; k < a.nlat; ++k) acc = fmaf(x[k], L.Wpi[k * a.nact + j], acc);
+                acc += L.bpi[j];
+            } else {
+                acc = L.lat[s * (a.nlat + 1) + j];
+            }
+            L.pi[s * a.nact + j] = acc;
+        } else {
+            float acc = 0.f;
+            const float* x = L.vlat + s * (a.nlatv + 1);
+            for (int k = 0; k < a.nlatv; ++k) acc = fmaf(x[k], L.Wvf[k], acc);
+            L.v[s] = acc + a.bvf[0];
+        }
+    }
+    __syncthreads();
+}
+
+#define MRL_HALF_LOG_2PI 0.9189385332046727f      /* f32(0.5*log(2*pi)) */
+#define MRL_HALF_LOG_2PIE 1.4189385332046727f     /* f32(0.5*log(2*pi*e)) */
+
+__global__ __launch_bounds__(256) void heads_train_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sred[4];
+    HeadLds L;
+    head_lds_carve(a, true, smem, L);
+    const int tid = threadIdx.x;
+    head_load_weights(a, L);
+    for (int q = tid; q < a.HP; q += 256) L.hacc[q] = 0.f;
+    double st[5] = {0, 0, 0, 0, 0};
+    const int ntiles = (a.Bc + a.TS - 1) / a.TS;
+    const float mean = a.advstat[0], sd = a.advstat[1] + 1e-8f;
+    const float eps = a.cliprange;
+    const float ce = a.ent_coef * a.invB;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int s0 = tile * a.TS, ns = min(a.TS, a.Bc - s0);
+        head_tile_forward(a, L, s0, ns);
+        if (tid < ns) {
+            const int s = tid;
+            const int b = s0 + s;
+            const long r = a.idx ? envmajor_to_row(a.idx[b], a.T, a.N) : a.row0 + b;
+            const float R = a.returns[r], oldv = a.values[r], oldnlp = a.neglogp[r];
+            const float adv = ((R - oldv) - mean) / sd;
+            float* pi = L.pi + s * a.nact;
+            float* dpi = L.dpi + s * a.nact;
+            float nlp, H;
+            if (a.pd_kind == MRL_PD_CATEGORICAL) {
+                const int act = static_cast<const int32_t*>(a.actions)[r];
+                float mx = pi[0];
+                for (int j = 1; j < a.nact; ++j) mx = fmaxf(mx, pi[j]);
+                float z0 = 0.f;
+                for (int j = 0; j < a.nact; ++j) z0 += expf(pi[j] - mx);
+                const float logz = logf(z0);
+                nlp = logz - (pi[act] - mx);
+                H = 0.f;
+                for (int j = 0; j < a.nact; ++j) {
+                    float a0 = pi[j] - mx;
+                    H += (expf(a0) / z0) * (logz - a0);
+                }
+                const float ratio = expf(oldnlp - nlp);
+                const float pg1 = -adv * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+                const float pg2 = -adv * rc;
+                float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+                const float dnlp = dr * (-ratio) * a.invB;
+                for (int j = 0; j < a.nact; ++j) {
+                    float a0 = pi[j] - mx;
+                    float p = expf(a0) / z0;
+                    float logp = a0 - logz;
+                    dpi[j] = dnlp * (p - (j == act ? 1.f : 0.f)) + ce * p * (logp + H);
+                }
+                st[0] += (double)fmaxf(pg1, pg2);
+                st[3] += (double)((nlp - oldnlp) * (nlp - oldnlp));
+                st[4] += (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
+            } else {
+                const float* x = static_cast<const float*>(a.actions) + r * a.nact;
+                float* dls = L.dls + s * a.nact;
+                float ssum = 0.f, lsum = 0.f;
+                H = 0.f;
+                for (int k = 0; k < a.nact; ++k) {
+                    float ls = L.logstd[k];
+                    float u = (x[k] - pi[k]) / expf(ls);
+                    ssum += u * u;
+                    lsum += ls;
+                    H += ls + MRL_HALF_LOG_2PIE;
+                }
+                nlp = 0.5f * ssum + MRL_HALF_LOG_2PI * (float)a.nact + lsum;
+                const float ratio = expf(oldnlp - nlp);
+                const float pg1 = -adv * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+                const float pg2 = -adv * rc;
+                float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+                const float dnlp = dr * (-ratio) * a.invB;
+                for (int k = 0; k < a.nact; ++k) {
+                    float sdk = expf(L.logstd[k]);
+                    float u = (x[k] - pi[k]) / sdk;
+                    dpi[k] = dnlp * (-(u / sdk));
+                    dls[k] = dnlp * (1.f - u * u) - ce;
+                }
+                st[0] += (double)fmaxf(pg1, pg2);
+                st[3] += (double)((nlp - oldnlp) * (nlp - oldnlp));
+                st[4] += (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
+            }
+            // value loss (model.py:68-75)
+            const float v = L.v[s];
+            const float dvc = fminf(fmaxf(v - oldv, -eps), eps);
+            const float vclip = oldv + dvc;
+            const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+            float dl = (l1 >= l2) ? (v - R) : ((v - oldv >= -eps && v - oldv <= eps) ? (vclip - R) : 0.f);
+            L.dv[s] = a.vf_coef * a.invB * dl;
+            st[1] += 0.5 * (double)fmaxf(l1, l2);
+            st[2] += (double)H;
+        }
+        __syncthreads();
+        // dz of the latent layers: (dpi . Wpi^T [+ dv * Wvf]) * act'(lat)
+        for (int q = tid; q < ns * a.nlat; q += 256) {
+            int s = q / a.nlat, k = q - s * a.nlat;
+            float g;
+            if (a.has_pi_head) {
+                g = 0.f;
+                const float* w = L.Wpi + k * a.nact;
+                const float* d = L.dpi + s * a.nact;
+                for (int j = 0; j < a.nact; ++j) g = fmaf(d[j], w[j], g);
+            } else {
+                g = L.dpi[s * a.nact + k];
+            }
+            if (a.shared) g = fmaf(L.dv[s], L.Wvf[k], g);
+            float hv = L.lat[s * (a.nlat + 1) + k];
+            a.dz_pi[(long)(s0 + s) * a.nlat + k] = g * act_bwd_from_out(hv, a.lat_act);
+        }
+        if (!a.shared)
+            for (int q = tid; q < ns * a.nlatv; q += 256) {
+                int s = q / a.nlatv, k = q - s * a.nlatv;
+                float hv = L.vlat[s * (a.nlatv + 1) + k];
+                a.dz_vf[(long)(s0 + s) * a.nlatv + k] = L.dv[s] * L.Wvf[k] * act_bwd_from_out(hv, a.vlat_act);
+            }
+        // head parameter gradients accumulated in LDS (each element owned by one thread)
+        for (int e = tid; e < a.HP; e += 256) {
+            int q = e;
+            float g = 0.f;
+            bool done = false;
+            if (a.has_pi_head) {
+                if (q < a.nlat * a.nact) {
+                    int k = q / a.nact, j = q - k * a.nact;
+                    for (int s = 0; s < ns; ++s) g = fmaf(L.lat[s * (a.nlat + 1) + k], L.dpi[s * a.nact + j], g);
+                    done = true;
+                } else {
+                    q -= a.nlat * a.nact;
+                    if (q < a.nact) {
+                        for (int s = 0; s < ns; ++s) g += L.dpi[s * a.nact + q];
+                        done = true;
+                    } else q -= a.nact;
+                }
+            }
+            if (!done && a.pd_kind == MRL_PD_DIAG_GAUSSIAN) {
+                if (q < a.nact) {
+                    for (int s = 0; s < ns; ++s) g += L.dls[s * a.nact + q];
+                    done = true;
+                } else q -= a.nact;
+            }
+            if (!done) {
+                if (q < a.nlatv) {
+                    for (int s = 0; s < ns; ++s) g = fmaf(L.vlat[s * (a.nlatv + 1) + q], L.dv[s], g);
+                } else {
+                    for (int s = 0; s < ns; ++s) g += L.dv[s];
+                }
+            }
+            L.hacc[e] += g;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < a.HP; e += 256) a.hpart[(long)blockIdx.x * a.HP + e] = L.hacc[e];
+    for (int j = 0; j < 5; ++j) {
+        double t = block_sum_256(st[j], sred);
+        if (tid == 0) a.spart[blockIdx.x * 5 + j] = t;
+    }
+}
+
+// stats_acc[j] += sum_blk spart[blk][j]
+__global__ void heads_stats_reduce_kernel(const double* __restrict__ spart, int nblk, double* __restrict__ acc) {
+    int j = threadIdx.x;
+    if (j < 5) {
+        double s = acc[j];
+        for (int b = 0; b < nblk; ++b) s += spart[b * 5 + j];
+        acc[j] = s;
+    }
+}
+__global__ void stats_finalize_kernel(const double* __restrict__ acc, float invB, float* __restrict__ out) {
+    int j = threadIdx.x;
+    if (j < 5) out[j] = (float)(acc[j] * (double)invB);
+}
+
+// act side: sample + neglogp (policies.py:52-55)
+__global__ __launch_bounds__(256) void heads_act_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    HeadLds L;
+    head_lds_carve(a, false, smem, L);
+    const int tid = threadIdx.x;
+    head_load_weights(a, L);
+    __syncthreads();
+    const int ntiles = (a.Bc + a.TS - 1) / a.TS;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int s0 = tile * a.TS, ns = min(a.TS, a.Bc - s0);
+        head_tile_forward(a, L, s0, ns);
+        if (tid < ns) {
+            const int s = tid;
+            const long b = a.row0 + s0 + s;
+            const float* pi = L.pi + s * a.nact;
+            if (a.values_out) a.values_out[b] = L.v[s];
+            if (a.pdparam_out)
+                for (int j = 0; j < a.nact; ++j) a.pdparam_out[b * a.nact + j] = pi[j];
+            if (a.actions_out) {
+                const float* nz = a.noise + b * a.nact;
+                if (a.pd_kind == MRL_PD_CATEGORICAL) {
+                    // argmax(logits - log(-log(u))), first max wins (tf.argmax)
+                    int best = 0;
+                    float bv = pi[0] - logf(-logf(nz[0]));
+                    for (int j = 1; j < a.nact; ++j) {
+                        float c = pi[j] - logf(-logf(nz[j]));
+                        if (c > bv) { bv = c; best = j; }
+                    }
+                    float mx = pi[0];
+                    for (int j = 1; j < a.nact; ++j) mx = fmaxf(mx, pi[j]);
+                    float z0 = 0.f;
+                    for (int j = 0; j < a.nact; ++j) z0 += expf(pi[j] - mx);
+                    static_cast<int32_t*>(a.actions_out)[b] = best;
+                    a.neglogp_out[b] = logf(z0) - (pi[best] - mx);
+                } else {
+                    float* ao = static_cast<float*>(a.actions_out) + b * a.nact;
+                    float ssum = 0.f, lsum = 0.f;
+                    for (int k = 0; k < a.nact; ++k) {
+                        float ls = L.logstd[k], sdk = expf(ls);
+                        float x = pi[k] + sdk * nz[k];
+                        ao[k] = x;
+                        float u = (x - pi[k]) / sdk;
+                        ssum += u * u;
+                        lsum += ls;
+                    }
+                    a.neglogp_out[b] = 0.5f * ssum + MRL_HALF_LOG_2PI * (float)a.nact + lsum;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ============================================================================================
+// layer launches
+// ============================================================================================
+struct In {               // layer-0 input description
+    const void* obs; const int64_t* idx; int T, N;
+};
+
+template <class AF, class BF, class EF>
+static int gemm_dispatch(const AF& af, const BF& bf, const EF& ef, int M, int N, int K, int zdim, int ksplit,
+                         hipStream_t st) {
+    hipError_t e;
+    if (N <= 32) e = launch_gemm<AF, BF, EF, 4, 1, 1, 1>(af, bf, ef, M, N, K, zdim, ksplit, st);
+    else if (N <= 64) e = launch_gemm<AF, BF, EF, 4, 1, 1, 2>(af, bf, ef, M, N, K, zdim, ksplit, st);
+    else e = launch_gemm<AF, BF, EF, 2, 2, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st);
+    return (int)e;
+}
+
+static inline int is_vec(const void* p, long ld) { return (ld % 4 == 0) && ((uintptr_t)p % 16 == 0); }
+
+static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
+                         const float* params, float* hout, int B, hipStream_t st) {
+    const float* W = params + l.w_off;
+    const float* bias = params + l.b_off;
+    RowMC bf{W, l.N, l.N, l.K, is_vec(W, l.N)};
+    if (l.kind == 0) {
+        int npix = B * l.OH * l.OW;
+        EpiBiasAct ef{hout, l.NF, bias, l.act};
+        if (first) {
+            ConvPatchKC<true> af;
+            af.p = in.obs; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
+            af.OW = l.OW; af.npix = npix; af.kconv = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N;
+            return gemm_dispatch(af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+        } else {
+            ConvPatchKC<false> af;
+            af.p = hprev; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
+            af.OW = l.OW; af.npix = npix; af.kconv = l.K; af.idx = nullptr; af.T = 1; af.N = 1;
+            return gemm_dispatch(af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+        }
+    } else {
+        EpiBiasAct ef{hout, l.N, bias, l.act};
+        if (first) {
+            GatherKC af;
+            af.p = (const float*)in.obs; af.ld = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N; af.rows = B;
+            af.kmax = l.K; af.vec = is_vec(in.obs, l.K);
+            return gemm_dispatch(af, bf, ef, B, l.N, l.K, 1, l.K, st);
+        } else {
+            RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K)};
+            return gemm_dispatch(af, bf, ef, B, l.N, l.K, 1, l.K, st);
+        }
+    }
+}
+
+static int net_forward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, int B,
+                       hipStream_t st) {
+    for (size_t i = 0; i < net.L.size(); ++i) {
+        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], B, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// backward through one net; nw.dz[last] already holds dloss/d(pre-activation of the last layer)
+static int net_backward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws,
+                        float* grads, int B, int accumulate, hipStream_t st) {
+    for (int i = (int)net.L.size() - 1; i >= 0; --i) {
+        const Layer& l = net.L[i];
+        const float* dz = nw.dz[i];
+        const float* hprev = i ? nw.h[i - 1] : nullptr;
+        const long rows = layer_rows(l, B);
+        const bool first = (i == 0);
+        // ---- weight gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n]  (split-K over rows)
+        Split sp = pick_split(l.K, l.N, rows);
+        if ((size_t)sp.nsplit * l.K * l.N > ws.part_floats) return MRL_ENOSPC;
+        EpiPartial ep{ws.part, (long)l.K * l.N, l.N};
+        RowMC bfm{dz, l.N, l.N, (int)rows, is_vec(dz, l.N)};
+        int rc;
+        if (l.kind == 0) {
+            if (first) {
+                ConvPatchMC<true> af;
+                af.p = in.obs; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
+                af.OW = l.OW; af.npix = (int)rows; af.kconv = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N;
+                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+            } else {
+                ConvPatchMC<false> af;
+                af.p = hprev; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
+                af.OW = l.OW; af.npix = (int)rows; af.kconv = l.K; af.idx = nullptr; af.T = 1; af.N = 1;
+                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+            }
+        } else {
+            if (first) {
+                GatherMC af;
+                af.p = (const float*)in.obs; af.ld = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N; af.rows = B;
+                af.kmax = l.K; af.vec = is_vec(in.obs, l.K);
+                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+            } else {
+                RowMC af{hprev, l.K, l.K, B, is_vec(hprev, l.K)};
+                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+            }
+        }
+        if (rc) return rc;
+        rc = reduce_slabs(ws.part, (long)l.K * l.N, sp.nsplit, grads + l.w_off, (long)l.K * l.N, accumulate, st);
+        if (rc) return rc;
+        // ---- bias gradient
+        int nblk = (int)std::min<long>(BIAS_MAXBLK, std::max<long>(1, rows / 64));
+        hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), st, dz, rows, l.N, ws.part);
+        MRL_LAUNCH_CHECK();
+        rc = reduce_slabs(ws.part, l.N, nblk, grads + l.b_off, l.N, accumulate, st);
+        if (rc) return rc;
+        // ---- data gradient into dz[i-1] (masked by act' of layer i-1)
+        if (!first) {
+            const Layer& lp = net.L[i - 1];
+            if (l.kind == 0) {
+                DgradGeom g;
+                g.H = l.H; g.W = l.W; g.C = l.C; g.rf = l.rf; g.stride = l.stride; g.OH = l.OH; g.OW = l.OW;
+                g.NF = l.NF; g.taps = (l.rf + l.stride - 1) / l.stride;
+                g.HY = (l.H + l.stride - 1) / l.stride; g.WX = (l.W + l.stride - 1) / l.stride; g.B = B;
+                DgradA af; static_cast<DgradGeom&>(af) = g; af.dz = dz;
+                DgradB bf; static_cast<DgradGeom&>(bf) = g; bf.w = params + l.w_off;
+                EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hprev; ef.act = lp.act;
+                int Kd = g.taps * g.taps * l.NF;
+                rc = gemm_dispatch(af, bf, ef, B * g.HY * g.WX, l.C, Kd, l.stride * l.stride, Kd, st);
+            } else {
+                RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N)};
+                const float* W = params + l.w_off;
+                RowKC bf{W, l.N, l.K, l.N, is_vec(W, l.N)};
+                EpiMaskAct ef{nw.dz[i - 1], l.K, hprev, lp.act};
+                rc = gemm_dispatch(af, bf, ef, B, l.K, l.N, 1, l.N, st);
+            }
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+static void fill_head_args(const mrl_model* m, const float* params, const Ws& ws, HeadArgs& a) {
+    memset(&a, 0, sizeof a);
+    const Net& pn = m->pi;
+    a.nlat = pn.nlat; a.lat_act = pn.lat_act;
+    a.lat = ws.pi.h.back();
+    if (m->vf_copy) {
+        a.shared = 0; a.nlatv = m->vf.nlat; a.vlat_act = m->vf.lat_act; a.vlat = ws.vf.h.back();
+    } else {
+        a.shared = 1; a.nlatv = pn.nlat; a.vlat_act = pn.lat_act; a.vlat = a.lat;
+    }
+    a.has_pi_head = m->has_pi_head;
+    a.Wpi = m->has_pi_head ? params + m->pi_w : nullptr;
+    a.bpi = m->has_pi_head ? params + m->pi_b : nullptr;
+    a.logstd = m->logstd >= 0 ? params + m->logstd : nullptr;
+    a.Wvf = params + m->vf_w; a.bvf = params + m->vf_b;
+    a.pd_kind = m->d.pd_kind; a.nact = m->d.nact; a.HP = m->HP;
+}
+
+static int pick_ts(HeadArgs& a, bool train) {
+    HeadLds L;
+    for (int ts : {32, 16, 8, 4}) {
+        a.TS = ts;
+        if (head_lds_carve(a, train, nullptr, L) <= 150 * 1024) return 0;
+    }
+    return MRL_EUNSUP;
+}
+
+// ============================================================================================
+// public entry points
+// ============================================================================================
+extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void* obs, const float* noise, int n,
+                             void* actions_out, float* values_out, float* neglogp_out, float* pdparam_out,
+                             void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+    if (!m || !params || !obs || n <= 0 || chunk <= 0 || !workspace) return MRL_EINVAL;
+    if ((actions_out != nullptr) != (neglogp_out != nullptr)) return MRL_EINVAL;
+    if (actions_out && !noise) return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Ws ws;
+    carve(m, chunk, (char*)workspace, ws);
+    if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int Bc = std::min(chunk, n - c0);
+        In in{(const char*)obs + (size_t)c0 * ob_bytes, nullptr, 1, 1};
+        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
+        if (rc) return rc;
+        if (m->vf_copy) {
+            rc = net_forward(m, m->vf, in, params, ws.vf, Bc, st);
+            if (rc) return rc;
+        }
+        HeadArgs a;
+        fill_head_args(m, params, ws, a);
+        if ((rc = pick_ts(a, false))) return rc;
+        a.Bc = Bc; a.row0 = c0;
+        a.noise = noise; a.actions_out = actions_out; a.values_out = values_out; a.neglogp_out = neglogp_out;
+        a.pdparam_out = pdparam_out;
+        HeadLds L;
+        size_t lds = head_lds_carve(a, false, nullptr, L);
+        int ntiles = (Bc + a.TS - 1) / a.TS;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)heads_act_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(heads_act_kernel, dim3(std::min(ntiles, HEAD_MAXBLK)), dim3(256), lds, st, a);
+        MRL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                              const float* returns, const float* values, const float* neglogpacs,
+                              const int64_t* idx, int B, int T, int N, float cliprange, float ent_coef,
+                              float vf_coef, float* grads_out, float* stats_out, void* workspace,
+                              size_t workspace_bytes, int chunk, void* stream) {
+    if (!m || !params || !obs || !actions || !returns || !values || !neglogpacs || !grads_out || !stats_out ||
+        !workspace || B <= 0 || chunk <= 0)
+        return MRL_EINVAL;
+    if (idx && (T <= 0 || N <= 0)) return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Ws ws;
+    carve(m, chunk, (char*)workspace, ws);
+    if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    double* advpart = ws.dscratch;
+    double* spart = ws.dscratch + ADV_G * 2;
+    double* stats_acc = spart + HEAD_MAXBLK * 5;
+    // minibatch advantage statistics (model.py:136-139)
+    int G = std::min(ADV_G, (B + 255) / 256);
+    hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, B, T, N, advpart);
+    MRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, B, ws.advstat, stats_acc);
+    MRL_LAUNCH_CHECK();
+    const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
+    const float invB = 1.f / (float)B;
+    for (int c0 = 0; c0 < B; c0 += chunk) {
+        const int Bc = std::min(chunk, B - c0);
+        const int accumulate = c0 > 0;
+        In in;
+        if (idx) { in.obs = obs; in.idx = idx + c0; in.T = T; in.N = N; }
+        else { in.obs = (const char*)obs + (size_t)c0 * ob_bytes; in.idx = nullptr; in.T = 1; in.N = 1; }
+        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
+        if (rc) return rc;
+        if (m->vf_copy && (rc = net_forward(m, m->vf, in, params, ws.vf, Bc, st))) return rc;
+        HeadArgs a;
+        fill_head_args(m, params, ws, a);
+        if ((rc = pick_ts(a, true))) return rc;
+        a.Bc = Bc; a.row0 = c0;
+        a.actions = actions; a.returns = returns; a.values = values; a.neglogp = neglogpacs;
+        a.idx = idx ? idx + c0 : nullptr; a.T = T; a.N = N;
+        a.advstat = ws.advstat; a.cliprange = cliprange; a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.invB = invB;
+        a.dz_pi = ws.pi.dz.back();
+        a.dz_vf = m->vf_copy ? ws.vf.dz.back() : nullptr;
+        a.hpart = ws.part; a.spart = spart;
+        HeadLds L;
+        size_t lds = head_lds_carve(a, true, nullptr, L);
+        int ntiles = (Bc + a.TS - 1) / a.TS;
+        int nblk = std::min(ntiles, HEAD_MAXBLK);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)heads_train_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(heads_train_kernel, dim3(nblk), dim3(256), lds, st, a);
+        MRL_LAUNCH_CHECK();
+        if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st))) return rc;
+        hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, nblk, stats_acc);
+        MRL_LAUNCH_CHECK();
+        if ((rc = net_backward(m, m->pi, in, params, ws.pi, ws, grads_out, Bc, accumulate, st))) return rc;
+        if (m->vf_copy && (rc = net_backward(m, m->vf, in, params, ws.vf, ws, grads_out, Bc, accumulate, st)))
+            return rc;
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, st, stats_acc, invB, stats_out);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,229 @@
+// Rollout-side kernels: GAE scan (K2), gather / sf01 (K4/K3), clip+Adam (K8/K9).
+#include "common.hip.h"
+
+using namespace mrl;
+
+extern "C" int mrl_version(void) { return MRL_VERSION; }
+
+extern "C" const char* mrl_strerror(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case MRL_EINVAL: return "mrl: invalid argument";
+        case MRL_ENOSPC: return "mrl: workspace too small";
+        case MRL_EUNSUP: return "mrl: unsupported configuration";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "mrl: unknown error";
+    }
+}
+
+extern "C" int mrl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// GAE.  One workgroup = 64 environments (one wavefront runs the recurrence, all four waves do
+// the coalesced HBM<->LDS staging).  Time is processed in chunks of TC steps from the back so
+// any nsteps fits; the f64 carry lives in a register of wave 0.
+//
+// Reference arithmetic (ppo2/runner.py:58-64 under NumPy promotion rules):
+//   gv    = f32(gamma) * V[t+1]                      (f32 product, rounded)
+//   delta = ((f64 r[t] + f64(gv) * nnt) - f64 V[t])  (f64)
+//   last  = delta + ((gamma*lam) * nnt) * last       (f64; gamma*lam is a host double)
+//   adv[t] = f32(last);  ret[t] = adv[t] + V[t]      (f32 add)
+// Explicit *_rn intrinsics keep the compiler from contracting any of it into FMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int GAE_TC = 128;
+constexpr int GAE_E = 64;
+
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                  const uint8_t* __restrict__ done,
+                                                  const float* __restrict__ last_val,
+                                                  const uint8_t* __restrict__ last_done, float gamma_f,
+                                                  double gamma_lam, float* __restrict__ adv_out,
+                                                  float* __restrict__ ret_out, int T, int N) {
+    __shared__ float s_r[GAE_TC][GAE_E];        // rewards in, advantages out
+    __shared__ float s_v[GAE_TC + 1][GAE_E];    // values t_lo..t_hi (slot n = V[t_hi])
+    __shared__ float s_ret[GAE_TC][GAE_E];
+    __shared__ uint8_t s_d[GAE_TC + 1][GAE_E];  // dones t_lo+1..t_hi stored at slot (t - t_lo)
+
+    const int e0 = blockIdx.x * GAE_E;
+    const int tid = threadIdx.x;
+    double carry = 0.0;
+    for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {
+        const int t_lo = max(0, t_hi - GAE_TC);
+        const int n = t_hi - t_lo;
+        for (int q = tid; q < (n + 1) * GAE_E; q += 256) {
+            int tt = q / GAE_E, le = q % GAE_E, e = e0 + le, t = t_lo + tt;
+            if (e < N) {
+                if (tt < n) s_r[tt][le] = rew[(long)t * N + e];
+                s_v[tt][le] = (t < T) ? val[(long)t * N + e] : last_val[e];
+                if (tt > 0) s_d[tt][le] = (t < T) ? done[(long)t * N + e] : last_done[e];
+            }
+        }
+        __syncthreads();
+        if (tid < GAE_E && e0 + tid < N) {
+            for (int tt = n - 1; tt >= 0; --tt) {
+                double nnt = s_d[tt + 1][tid] ? 0.0 : 1.0;
+                float v = s_v[tt][tid];
+                float gv = __fmul_rn(gamma_f, s_v[tt + 1][tid]);
+                double delta = __dsub_rn(__dadd_rn((double)s_r[tt][tid], __dmul_rn((double)gv, nnt)), (double)v);
+                carry = __dadd_rn(delta, __dmul_rn(__dmul_rn(gamma_lam, nnt), carry));
+                float a = (float)carry;
+                s_r[tt][tid] = a;
+                s_ret[tt][tid] = __fadd_rn(a, v);
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < n * GAE_E; q += 256) {
+            int tt = q / GAE_E, le = q % GAE_E, e = e0 + le;
+            if (e < N) {
+                long o = (long)(t_lo + tt) * N + e;
+                if (adv_out) adv_out[o] = s_r[tt][le];
+                ret_out[o] = s_ret[tt][le];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int mrl_gae(const float* rew, const float* val, const uint8_t* done, const float* last_val,
+                       const uint8_t* last_done, double gamma, double lam, float* adv_out, float* ret_out,
+                       int T, int N, void* stream) {
+    if (T <= 0 || N <= 0 || !rew || !val || !done || !last_val || !last_done || !ret_out) return MRL_EINVAL;
+    dim3 grid((N + GAE_E - 1) / GAE_E);
+    hipLaunchKernelGGL(gae_kernel, grid, dim3(256), 0, (hipStream_t)stream, rew, val, done, last_val, last_done,
+                       (float)gamma, gamma * lam, adv_out, ret_out, T, N);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Row gather / sf01.  Rows are moved 16 B per lane when row_bytes % 16 == 0, else 4 B / 1 B.
+// ------------------------------------------------------------------------------------------
+template <typename V>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const V* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          V* __restrict__ dst, long B, int T, int N, int rowv,
+                                                          int mode /*0 gather idx, 1 sf01*/) {
+    long total = B * (long)rowv;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += (long)gridDim.x * 256L) {
+        long b = q / rowv;
+        int c = (int)(q - b * rowv);
+        long i = (mode == 0) ? idx[b] : b;
+        long srow = envmajor_to_row(i, T, N);
+        dst[q] = src[srow * rowv + c];
+    }
+}
+
+static int launch_gather(const void* src, const int64_t* idx, void* dst, long B, int T, int N, int row_bytes,
+                         int mode, hipStream_t st) {
+    if (B <= 0) return 0;
+    if (row_bytes <= 0 || T <= 0 || N <= 0) return MRL_EINVAL;
+    bool a16 = (row_bytes % 16 == 0) && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    bool a4 = (row_bytes % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
+    int unit = a16 ? 16 : (a4 ? 4 : 1);
+    int rowv = row_bytes / unit;
+    long total = B * (long)rowv;
+    int blocks = (int)min((total + 255) / 256, (long)8192);
+    if (unit == 16)
+        hipLaunchKernelGGL(gather_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, idx,
+                           (uint4*)dst, B, T, N, rowv, mode);
+    else if (unit == 4)
+        hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, idx,
+                           (uint32_t*)dst, B, T, N, rowv, mode);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)src, idx,
+                           (uint8_t*)dst, B, T, N, rowv, mode);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrl_gather_rows(const void* src, const int64_t* idx, void* dst, int B, int T, int N, int row_bytes,
+                               void* stream) {
+    if (!src || !idx || !dst) return MRL_EINVAL;
+    return launch_gather(src, idx, dst, B, T, N, row_bytes, 0, (hipStream_t)stream);
+}
+
+extern "C" int mrl_sf01(const void* src, void* dst, int T, int N, int row_bytes, void* stream) {
+    if (!src || !dst) return MRL_EINVAL;
+    return launch_gather(src, nullptr, dst, (long)T * N, T, N, row_bytes, 1, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// clip_by_global_norm + Adam (TF-1 ApplyAdam form).  Two launches:
+//   1) sumsq partials (f64, fixed order) of g/total_weight;
+//   2) every block re-reduces the partials in the same order -> identical norm everywhere,
+//      then updates its slice:  m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps).
+// Algorithmic traffic 28 B/param (read p,g,m,v; write p,m,v) + 4 B/param for the norm pass.
+// ------------------------------------------------------------------------------------------
+constexpr int ADAM_MAX_PART = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long P, float total_weight,
+                                                    double* __restrict__ part) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < P; i += (long)gridDim.x * 256L) {
+        float x = g[i];
+        if (total_weight != 1.f) x = x / total_weight;
+        s += (double)x * (double)x;
+    }
+    double r = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long P, float alpha, float beta1,
+                                                   float beta2, float eps, float max_grad_norm, float total_weight,
+                                                   const double* __restrict__ part, int npart,
+                                                   float* __restrict__ gnorm_out) {
+    __shared__ double sh[4];
+    __shared__ float s_scale;
+    float scale = 1.f;
+    if (max_grad_norm >= 0.f) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < npart; i += 256) s += part[i];
+        double tot = block_sum_256(s, sh);
+        if (threadIdx.x == 0) {
+            float gn = (float)sqrt(tot);
+            // tf.clip_by_global_norm: scale = clip_norm * min(1/global_norm, 1/clip_norm)
+            s_scale = max_grad_norm * fminf(1.f / gn, 1.f / max_grad_norm);
+            if (gnorm_out && blockIdx.x == 0) gnorm_out[0] = gn;
+        }
+        __syncthreads();
+        scale = s_scale;
+    }
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < P; i += (long)gridDim.x * 256L) {
+        float x = g[i];
+        if (total_weight != 1.f) x = x / total_weight;
+        x = x * scale;
+        g[i] = x;   // the clipped, averaged gradient (model.py:112 self.grads)
+        float mi = m[i], vi = v[i];
+        mi = mi + (x - mi) * omb1;
+        vi = vi + (x * x - vi) * omb2;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    }
+}
+
+extern "C" size_t mrl_adam_scratch_bytes(long P) {
+    (void)P;
+    return ADAM_MAX_PART * sizeof(double);
+}
+
+extern "C" int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, float alpha, float beta1,
+                                  float beta2, float eps, float max_grad_norm, float total_weight, float* gnorm_out,
+                                  void* scratch, void* stream) {
+    if (!params || !grads || !m || !v || P <= 0 || !scratch || total_weight <= 0.f) return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (int)min((P + 1023) / 1024, (long)ADAM_MAX_PART);
+    if (max_grad_norm >= 0.f) {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grads, P, total_weight, (double*)scratch);
+        MRL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, P, alpha, beta1, beta2, eps,
+                       max_grad_norm, total_weight, (const double*)scratch, blocks, gnorm_out);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,122 @@
+/*
+ * mrl.h -- C ABI of libmrl.so, the MI355X (gfx950) PPO2 / DQN-replay hot path.
+ *
+ * The reference (openai/baselines) has no FFI: its extension points are Python call
+ * signatures.  This header is the boundary a non-Python host (or the Python
+ * mirror in baselines_amd/) binds instead of `sess.run(...)` / the NumPy loops.  Each entry
+ * point cites the reference code it replaces (paths relative to baselines/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous on it;
+ *   - return value: 0 ok, >0 hipError_t, <0 argument error (MRL_E*);
+ *   - no global state, no hidden allocation on the data path: scratch comes from a
+ *     caller-provided workspace whose size is queried first;
+ *   - rollout storage is time-major SoA [T][N]; the reference's env-major flat index
+ *     i = e*T + t (ppo2/runner.py:69-74 `sf01`) is translated inside the kernels, so sf01's
+ *     full copy never happens.
+ */
+#ifndef MRL_H_
+#define MRL_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRL_VERSION 1
+
+#define MRL_EINVAL   (-1)   /* bad argument / unsupported shape */
+#define MRL_ENOSPC   (-2)   /* workspace too small */
+#define MRL_EUNSUP   (-3)   /* configuration outside the supported hot path */
+
+int mrl_version(void);
+const char* mrl_strerror(int code);
+/* number of visible HIP devices (<=0: none).  Used by the Python loader to fail loudly. */
+int mrl_device_count(void);
+
+/* ---- K2: GAE(lambda) backward recurrence --- ppo2/runner.py:52-65 -----------------------
+ * rew,val f32 [T][N]; done u8 [T][N] (flag ENTERING step t); last_val f32 [N]; last_done u8 [N].
+ * Reproduces NumPy's dtype mix exactly: f32 product gamma*V_{t+1}, f64 carry, RN store to f32;
+ * ret = f32(adv_f32 + val).  adv_out may be NULL.  Bit-exact vs the reference. */
+int mrl_gae(const float* rew, const float* val, const uint8_t* done, const float* last_val,
+            const uint8_t* last_done, double gamma, double lam, float* adv_out, float* ret_out,
+            int T, int N, void* stream);
+
+/* ---- K4: standalone minibatch gather --- ppo2/ppo2.py:162-164 `arr[mbinds]` ---------------
+ * src time-major rows [T*N][row_bytes]; idx env-major flat indices int64 [B]; dst [B][row_bytes]. */
+int mrl_gather_rows(const void* src, const int64_t* idx, void* dst, int B, int T, int N,
+                    int row_bytes, void* stream);
+/* sf01 as a device op (only for callers that insist on env-major copies): dst[e*T+t] = src[t*N+e] */
+int mrl_sf01(const void* src, void* dst, int T, int N, int row_bytes, void* stream);
+
+/* ---- model description --- common/policies.py:121-179, common/models.py:15-26,74-103 ------ */
+enum { MRL_NET_MLP = 0, MRL_NET_NATURE_CNN = 1 };
+enum { MRL_PD_CATEGORICAL = 0, MRL_PD_DIAG_GAUSSIAN = 1 };
+enum { MRL_OB_F32 = 0, MRL_OB_U8 = 1 };
+enum { MRL_ACT_NONE = 0, MRL_ACT_RELU = 1, MRL_ACT_TANH = 2 };
+
+typedef struct mrl_model_desc {
+    int network;          /* MRL_NET_* */
+    int ob_ndim;          /* 1 (vector) or 3 (H,W,C image) */
+    int ob_shape[3];
+    int ob_dtype;         /* MRL_OB_* */
+    int num_layers;       /* mlp: models.py:75 (default 2) */
+    int num_hidden;       /* mlp: (default 64) */
+    int activation;       /* mlp: MRL_ACT_TANH (default) | MRL_ACT_RELU */
+    int value_copy;       /* policies.py:154-166: 0 = shared latent, 1 = value_network='copy' */
+    int pd_kind;          /* MRL_PD_*  (distributions.py:278-290) */
+    int nact;             /* Discrete.n or Box.shape[0] */
+} mrl_model_desc;
+
+typedef struct mrl_model mrl_model;   /* host-side layout object; owns no device memory */
+
+int  mrl_model_create(const mrl_model_desc* desc, mrl_model** out);
+void mrl_model_destroy(mrl_model* m);
+long mrl_model_num_params(const mrl_model* m);          /* P (floats) */
+int  mrl_model_num_tensors(const mrl_model* m);
+/* tensor i in TF variable-creation order: name (e.g. "ppo2_model/pi/c1/w"),
+ * shape (<=4 dims, TF shapes incl. conv bias [1,nf,1,1]), flat offset, init scale (<0: zeros). */
+int  mrl_model_tensor_info(const mrl_model* m, int i, char* name, int name_cap, int* ndim,
+                           int shape[4], long* offset, float* init_scale);
+/* workspace bytes needed to process `chunk` samples at a time (forward+backward). */
+size_t mrl_model_workspace_bytes(const mrl_model* m, int chunk);
+
+/* ---- K6+K10: act side --- common/policies.py:77-113, distributions.py:199-201,247-248 -----
+ * obs [n][ob...] in the model's ob dtype.  noise: uniform(0,1) f32 [n][nact] (Categorical,
+ * Gumbel-max) or N(0,1) f32 [n][nact] (DiagGaussian).  actions_out: int32 [n] or f32 [n][nact].
+ * Any of actions_out/neglogp_out may be NULL together (value-only call == PolicyWithValue.value). */
+int mrl_model_act(const mrl_model* m, const float* params, const void* obs, const float* noise,
+                  int n, void* actions_out, float* values_out, float* neglogp_out,
+                  float* pdparam_out /* [n][nact] logits or mean, may be NULL */,
+                  void* workspace, size_t workspace_bytes, int chunk, void* stream);
+
+/* ---- K4+K5+K6+K7: gradient of the PPO2 loss on one minibatch --- ppo2/model.py:57-91,133-158
+ * Rollout fields are time-major [T*N] (obs [T*N][ob...]); idx int64 [B] are the reference's
+ * env-major flat indices (idx == NULL: rows 0..B-1 of the given arrays, T and N ignored).
+ * actions: int32 [T*N] (Categorical) or f32 [T*N][nact].
+ * Computes advs = returns - values normalised over the MINIBATCH (model.py:136-139), the loss,
+ * closed-form gradients and back-propagates through heads and networks.
+ * grads_out f32 [P] is overwritten with dloss/dparams (NOT yet clipped).
+ * stats_out f32 [5] = [pg_loss, vf_loss, entropy, approxkl, clipfrac] (model.py:115-116). */
+int mrl_model_grad(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                   const float* returns, const float* values, const float* neglogpacs,
+                   const int64_t* idx, int B, int T, int N, float cliprange, float ent_coef,
+                   float vf_coef, float* grads_out, float* stats_out, void* workspace,
+                   size_t workspace_bytes, int chunk, void* stream);
+
+/* ---- K8+K9: [rank average] -> clip_by_global_norm -> Adam --- ppo2/model.py:97-114,
+ * common/mpi_adam_optimizer.py:39-40.  grads := grads / total_weight (if != 1) BEFORE the norm,
+ * scale = c*min(1/gn, 1/c) (max_grad_norm < 0: no clipping), TF-1 ApplyAdam update with
+ * alpha = lr*sqrt(1-beta2_power)/(1-beta1_power) supplied by the caller (host f32).
+ * scratch: >= mrl_adam_scratch_bytes(P).  gnorm_out f32 [1] may be NULL. */
+size_t mrl_adam_scratch_bytes(long P);
+int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, float alpha,
+                       float beta1, float beta2, float eps, float max_grad_norm,
+                       float total_weight, float* gnorm_out, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRL_H_ */

@@ -1,0 +1,278 @@
+"""
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+PyTorch-CPU restatement of the TensorFlow-1 graph the reference PPO2 builds
+(tensorflow<2 is a third-party dependency that is absent from /root/reference
+and from this image -> "parity unpinned" at the TF boundary).
+Paths below are relative to /root/reference/baselines/.
+
+  networks        common/models.py:15-26 (nature_cnn), :74-103 (mlp);
+                  layers a2c/utils.py:37-63 (conv: NHWC/HWIO/VALID, fc), :142-145
+  policy heads    common/policies.py:43-64, common/distributions.py:59-113, 351-355
+  pd maths        common/distributions.py:153-204 (Categorical), :227-251 (DiagGaussian)
+  loss            ppo2/model.py:57-91
+  clip + Adam     ppo2/model.py:97-114 (tf.clip_by_global_norm, tf.train.AdamOptimizer eps=1e-5);
+                  Adam update restated from the published TF-1 ApplyAdam kernel form
+                  (m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= m*alpha/(sqrt(v)+eps),
+                  alpha = lr*sqrt(1-b2^t)/(1-b1^t)), cross-pinned by common/mpi_adam.py:38-41.
+  MPI averaging   common/mpi_adam_optimizer.py:21,39-40 (flat grad * w, sum, / sum w; THEN clip)
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .ppo2_numpy import ortho_init
+
+
+def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
+                      num_layers=2, num_hidden=64):
+    """Ordered (name, shape, init_scale|None) list in TF variable-creation order
+    (SURVEY.md App. A.6): policy net -> value net copy -> pi head -> [logstd] -> vf head."""
+    specs = []
+
+    def net(prefix):
+        if network == 'cnn':
+            assert tuple(ob_shape) == (84, 84, 4) or len(ob_shape) == 3
+            h, w, c = ob_shape
+            specs.append((prefix + '/c1/w', (8, 8, c, 32), math.sqrt(2)))
+            specs.append((prefix + '/c1/b', (1, 32, 1, 1), None))
+            specs.append((prefix + '/c2/w', (4, 4, 32, 64), math.sqrt(2)))
+            specs.append((prefix + '/c2/b', (1, 64, 1, 1), None))
+            specs.append((prefix + '/c3/w', (3, 3, 64, 64), math.sqrt(2)))
+            specs.append((prefix + '/c3/b', (1, 64, 1, 1), None))
+            h1, w1 = (h - 8) // 4 + 1, (w - 8) // 4 + 1
+            h2, w2 = (h1 - 4) // 2 + 1, (w1 - 4) // 2 + 1
+            h3, w3 = h2 - 2, w2 - 2
+            specs.append((prefix + '/fc1/w', (h3 * w3 * 64, 512), math.sqrt(2)))
+            specs.append((prefix + '/fc1/b', (512,), None))
+            return 512
+        elif network == 'mlp':
+            nin = int(np.prod(ob_shape))
+            for i in range(num_layers):
+                specs.append((prefix + '/mlp_fc%d/w' % i, (nin, num_hidden), math.sqrt(2)))
+                specs.append((prefix + '/mlp_fc%d/b' % i, (num_hidden,), None))
+                nin = num_hidden
+            return nin
+        raise ValueError('Unknown network type: {}'.format(network))
+
+    nlat = net('ppo2_model/pi')
+    nlat_v = nlat
+    if value_network == 'copy':
+        nlat_v = net('ppo2_model/vf')
+    # distributions.py:351-355 _matching_fc: no head when latent width == size
+    has_pi_head = (nlat != nact)
+    if has_pi_head:
+        specs.append(('ppo2_model/pi/w', (nlat, nact), 0.01))
+        specs.append(('ppo2_model/pi/b', (nact,), None))
+    if pd_kind == 'gaussian':
+        specs.append(('ppo2_model/pi/logstd', (1, nact), None))
+    specs.append(('ppo2_model/vf/w', (nlat_v, 1), 1.0))
+    specs.append(('ppo2_model/vf/b', (1,), None))
+    return specs, has_pi_head
+
+
+def init_params(specs):
+    """Draw order == spec order; only `w` tensors consume np.random (a2c/utils.py:20-35)."""
+    out = {}
+    for name, shape, scale in specs:
+        if scale is None:
+            out[name] = np.zeros(shape, np.float32)
+        else:
+            out[name] = ortho_init(shape, scale)
+    return out
+
+
+class OracleModel(object):
+    """Reference-shaped model object (ppo2/model.py:27-158) on torch-CPU.
+
+    step/value take explicit noise (teacher forcing: TF's Philox stream cannot be
+    reproduced) -- uniform [N,nA] for Categorical Gumbel-max
+    (distributions.py:199-201), standard normal [N,nA] for DiagGaussian (:247-248).
+    """
+    loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+
+    def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_network=None,
+                 ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float32,
+                 params=None, num_layers=2, num_hidden=64, total_weight=1.0, rank_weight=1.0,
+                 allreduce=None):
+        self.network, self.ob_shape, self.ob_dtype = network, tuple(ob_shape), np.dtype(ob_dtype)
+        self.pd_kind, self.nact, self.value_network = pd_kind, nact, value_network
+        self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+        self.dtype = dtype
+        self.num_layers, self.num_hidden = num_layers, num_hidden
+        self.specs, self.has_pi_head = build_param_specs(network, ob_shape, pd_kind, nact, value_network,
+                                                         num_layers, num_hidden)
+        if params is None:
+            params = init_params(self.specs)
+        self.names = [s[0] for s in self.specs]
+        self.p = {k: torch.tensor(np.asarray(params[k]), dtype=dtype, requires_grad=True) for k in self.names}
+        self.m = {k: torch.zeros_like(self.p[k]) for k in self.names}
+        self.v = {k: torch.zeros_like(self.p[k]) for k in self.names}
+        # TF keeps beta powers as f32 variables multiplied after each apply
+        npdt = np.float32 if dtype == torch.float32 else np.float64
+        self.beta1, self.beta2, self.eps = npdt(0.9), npdt(0.999), npdt(1e-5)
+        self.beta1_power, self.beta2_power = npdt(0.9), npdt(0.999)
+        self.npdt = npdt
+        self.rank_weight, self.total_weight, self.allreduce = rank_weight, total_weight, allreduce
+        self.initial_state = None
+        self.last_grads = None
+
+    # ---- networks ---------------------------------------------------------
+    def _net(self, x, prefix):
+        p = self.p
+        if self.network == 'cnn':
+            # models.py:19: tf.cast(float32) / 255.
+            h = x.to(self.dtype) / 255.
+            h = h.permute(0, 3, 1, 2)
+            for name, stride in (('c1', 4), ('c2', 2), ('c3', 1)):
+                w = p[prefix + '/%s/w' % name].permute(3, 2, 0, 1)  # HWIO -> OIHW
+                b = p[prefix + '/%s/b' % name].reshape(-1)
+                h = F.relu(F.conv2d(h, w, b, stride=stride))
+            h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)  # conv_to_fc on NHWC
+            return F.relu(h @ p[prefix + '/fc1/w'] + p[prefix + '/fc1/b'])
+        else:
+            h = x.to(self.dtype).reshape(x.shape[0], -1)
+            for i in range(self.num_layers):
+                h = torch.tanh(h @ p[prefix + '/mlp_fc%d/w' % i] + p[prefix + '/mlp_fc%d/b' % i])
+            return h
+
+    def forward(self, obs):
+        x = torch.as_tensor(np.asarray(obs))
+        lat = self._net(x, 'ppo2_model/pi')
+        vlat = self._net(x, 'ppo2_model/vf') if self.value_network == 'copy' else lat
+        if self.has_pi_head:
+            pi = lat @ self.p['ppo2_model/pi/w'] + self.p['ppo2_model/pi/b']
+        else:
+            pi = lat
+        vf = (vlat @ self.p['ppo2_model/vf/w'] + self.p['ppo2_model/vf/b'])[:, 0]
+        return pi, vf
+
+    # ---- pd maths -----------------------------------------------------------
+    def _neglogp(self, pi, a):
+        if self.pd_kind == 'categorical':
+            # softmax_cross_entropy_with_logits_v2(logits, onehot)
+            a0 = pi - pi.max(dim=-1, keepdim=True)[0]
+            lse = torch.log(torch.exp(a0).sum(-1))
+            return lse - a0.gather(1, a.long().reshape(-1, 1))[:, 0]
+        logstd = self.p['ppo2_model/pi/logstd']
+        logstd_b = pi * 0.0 + logstd
+        std = torch.exp(logstd_b)
+        return 0.5 * (((a - pi) / std) ** 2).sum(-1) + 0.5 * math.log(2.0 * math.pi) * float(self.nact) \
+            + logstd_b.sum(-1)
+
+    def _entropy(self, pi):
+        if self.pd_kind == 'categorical':
+            a0 = pi - pi.max(dim=-1, keepdim=True)[0]
+            ea0 = torch.exp(a0)
+            z0 = ea0.sum(-1, keepdim=True)
+            p0 = ea0 / z0
+            return (p0 * (torch.log(z0) - a0)).sum(-1)
+        logstd_b = pi * 0.0 + self.p['ppo2_model/pi/logstd']
+        return (logstd_b + .5 * math.log(2.0 * math.pi * math.e)).sum(-1)
+
+    # ---- act side ---------------------------------------------------------
+    def step(self, obs, noise, **_):
+        with torch.no_grad():
+            pi, vf = self.forward(obs)
+            nz = torch.as_tensor(np.asarray(noise)).to(self.dtype)
+            if self.pd_kind == 'categorical':
+                a = torch.argmax(pi - torch.log(-torch.log(nz)), dim=-1)
+            else:
+                a = pi + torch.exp(pi * 0.0 + self.p['ppo2_model/pi/logstd']) * nz
+            nlp = self._neglogp(pi, a)
+        a_np = a.numpy().astype(np.int64) if self.pd_kind == 'categorical' else a.numpy().astype(np.float32)
+        return a_np, vf.numpy().astype(np.float32), None, nlp.numpy().astype(np.float32)
+
+    def value(self, obs, **_):
+        with torch.no_grad():
+            return self.forward(obs)[1].numpy().astype(np.float32)
+
+    # ---- learner ------------------------------------------------------------
+    def loss_and_stats(self, obs, returns, actions, values, neglogpacs, cliprange, advs):
+        dt = self.dtype
+        R = torch.as_tensor(np.asarray(returns)).to(dt)
+        OLDV = torch.as_tensor(np.asarray(values)).to(dt)
+        OLDNLP = torch.as_tensor(np.asarray(neglogpacs)).to(dt)
+        ADV = torch.as_tensor(np.asarray(advs)).to(dt)
+        A = torch.as_tensor(np.asarray(actions))
+        if self.pd_kind != 'categorical':
+            A = A.to(dt)
+        pi, vpred = self.forward(obs)
+        neglogpac = self._neglogp(pi, A)
+        entropy = self._entropy(pi).mean()
+        vpredclipped = OLDV + torch.clamp(vpred - OLDV, -cliprange, cliprange)
+        vf_losses1 = (vpred - R) ** 2
+        vf_losses2 = (vpredclipped - R) ** 2
+        vf_loss = .5 * torch.maximum(vf_losses1, vf_losses2).mean()
+        ratio = torch.exp(OLDNLP - neglogpac)
+        pg_losses = -ADV * ratio
+        pg_losses2 = -ADV * torch.clamp(ratio, 1.0 - cliprange, 1.0 + cliprange)
+        pg_loss = torch.maximum(pg_losses, pg_losses2).mean()
+        approxkl = .5 * ((neglogpac - OLDNLP) ** 2).mean()
+        clipfrac = (torch.abs(ratio - 1.0) > cliprange).to(dt).mean()
+        loss = pg_loss - entropy * self.ent_coef + vf_loss * self.vf_coef
+        return loss, [pg_loss, vf_loss, entropy, approxkl, clipfrac]
+
+    def compute_grads(self, cliprange, obs, returns, actions, values, neglogpacs):
+        """model.py:136-139 + graph gradients.  Returns (stats, flat unclipped grad ndarray)."""
+        returns = np.asarray(returns)
+        values = np.asarray(values)
+        if self.dtype == torch.float64:
+            returns64, values64 = returns.astype(np.float64), values.astype(np.float64)
+            advs = returns64 - values64
+            advs = (advs - advs.mean()) / (advs.std() + 1e-8)
+        else:
+            advs = returns - values
+            advs = (advs - advs.mean()) / (advs.std() + 1e-8)
+        for t in self.p.values():
+            t.grad = None
+        loss, stats = self.loss_and_stats(obs, returns, actions, values, neglogpacs, cliprange, advs)
+        loss.backward()
+        grads = []
+        for k in self.names:
+            g = self.p[k].grad
+            grads.append(torch.zeros_like(self.p[k]) if g is None else g.detach().clone())
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        return [float(s.detach()) for s in stats], flat
+
+    def apply_flat_grad(self, lr, flat):
+        """[MPI average] -> clip_by_global_norm -> TF-1 Adam.  flat: torch 1-D."""
+        if self.allreduce is not None:
+            # mpi_adam_optimizer.py:21,39-40
+            flat = self.allreduce(flat * self.rank_weight) / self.total_weight
+        if self.max_grad_norm is not None:
+            # tf.clip_by_global_norm: scale = c * min(1/gn, 1/c)
+            gn = torch.sqrt((flat * flat).sum())
+            c = torch.tensor(self.max_grad_norm, dtype=self.dtype)
+            scale = c * torch.minimum(1.0 / gn, 1.0 / c)
+            flat = flat * scale
+            self.last_gnorm = float(gn)
+        self.last_grads = flat.clone()
+        lr = self.npdt(lr)
+        one = self.npdt(1)
+        alpha = lr * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
+        off = 0
+        with torch.no_grad():
+            for k in self.names:
+                n = self.p[k].numel()
+                g = flat[off:off + n].reshape(self.p[k].shape)
+                off += n
+                self.m[k] += (g - self.m[k]) * float(one - self.beta1)
+                self.v[k] += (g * g - self.v[k]) * float(one - self.beta2)
+                self.p[k] -= (self.m[k] * float(alpha)) / (torch.sqrt(self.v[k]) + float(self.eps))
+        self.beta1_power = self.npdt(self.beta1_power * self.beta1)
+        self.beta2_power = self.npdt(self.beta2_power * self.beta2)
+
+    def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
+        stats, flat = self.compute_grads(cliprange, obs, returns, actions, values, neglogpacs)
+        self.apply_flat_grad(lr, flat)
+        return stats
+
+    # ---- helpers --------------------------------------------------------------
+    def flat_params(self):
+        return np.concatenate([self.p[k].detach().numpy().reshape(-1) for k in self.names])
+
+    def params_numpy(self):
+        return {k: self.p[k].detach().numpy().copy() for k in self.names}

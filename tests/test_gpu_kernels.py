@@ -1,0 +1,251 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP entry point of libmrl.so, called
+through the C ABI, against the oracle (NumPy restatement pinned by the reference's golden
+vectors; torch-CPU restatement of the TF graph)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo2_numpy as O
+from oracle.ppo2_torch import OracleModel, build_param_specs, init_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from baselines_amd import ops
+    return ops
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['t128_n8', 't5_n3', 't37_n70', 't1_n4', 't64_n129_alldone', 't64_n65_nodone',
+                                  't300_n33_g1', 't16_n64_lam0'])
+def test_gae_bit_exact_vs_reference_golden(golden_dir, name):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, 'runner_%s.npz' % name))
+    ret, adv = ops.gae(dev(g['in_rewards']), dev(g['in_values']), dev(g['in_dones']), dev(g['in_last_values']),
+                       dev(g['in_last_dones']), float(g['gamma']), float(g['lam']), want_advs=True)
+    got = ops.sf01(ret).cpu().numpy()
+    np.testing.assert_array_equal(got, g['out_returns'])      # bit-exact vs the reference's Runner.run
+    ret_o, adv_o = O.gae(g['in_rewards'], g['in_values'], g['in_dones'], g['in_last_values'], g['in_last_dones'],
+                         float(g['gamma']), float(g['lam']))
+    np.testing.assert_array_equal(adv.cpu().numpy(), adv_o)
+
+
+def test_gae_full_size_properties():
+    """BASELINE size (T=128, N=4096): bit-exact vs the oracle + all-done rows reduce to r - v."""
+    ops = _ops()
+    ro = O.synthetic_rollout('cartpole', 128, 4096, 3)
+    rew = (np.random.RandomState(0).randn(128, 4096) * 2).astype(np.float32)
+    ret = ops.gae(dev(rew), dev(ro['values']), dev(ro['dones']), dev(ro['last_values']), dev(ro['last_dones']),
+                  0.99, 0.95).cpu().numpy()
+    ret_o, _ = O.gae(rew, ro['values'], ro['dones'], ro['last_values'], ro['last_dones'], 0.99, 0.95)
+    np.testing.assert_array_equal(ret, ret_o)
+    # terminal transitions: adv = r - v exactly (f64 then f32) -> ret = f32(f32(r - v) + v)
+    nxt = np.concatenate([ro['dones'][1:], ro['last_dones'][None]], 0)
+    expect = ((rew.astype(np.float64) - ro['values']).astype(np.float32) + ro['values'])
+    np.testing.assert_array_equal(ret[nxt], expect[nxt])
+
+
+@pytest.mark.parametrize('shape,dtype', [((84, 84, 4), np.uint8), ((376,), np.float32), ((), np.float32),
+                                         ((3,), np.uint8), ((17,), np.float32)])
+def test_gather_and_sf01(shape, dtype):
+    ops = _ops()
+    T, N = 7, 13
+    rng = np.random.RandomState(1)
+    arr = (rng.randint(0, 255, (T, N) + shape)).astype(dtype)
+    flat = O.sf01(arr)
+    idx = rng.permutation(T * N)[:40].astype(np.int64)
+    got = ops.gather_rows(dev(arr), dev(idx), T, N).cpu().numpy()
+    np.testing.assert_array_equal(got, flat[idx])
+    np.testing.assert_array_equal(ops.sf01(dev(arr)).cpu().numpy(), flat)
+
+
+# ------------------------------------------------------------------------------------------------
+def _make_pair(network, ob_shape, ob_dtype, pd_kind, nact, value_network, seed, chunk, **kw):
+    ops = _ops()
+    np.random.seed(seed)
+    om = OracleModel(network=network, ob_shape=ob_shape, ob_dtype=ob_dtype, pd_kind=pd_kind, nact=nact,
+                     value_network=value_network, ent_coef=kw.pop('ent_coef', 0.01), vf_coef=0.5,
+                     max_grad_norm=kw.pop('max_grad_norm', 0.5), **kw)
+    dm = ops.DeviceModel(network=network, ob_shape=ob_shape, ob_dtype=ob_dtype, pd_kind=pd_kind, nact=nact,
+                         value_copy=(value_network == 'copy'), chunk=chunk,
+                         num_layers=kw.get('num_layers', 2), num_hidden=kw.get('num_hidden', 64))
+    # layout must equal the reference's variable order / shapes
+    assert [t['name'] for t in dm.tensors] == om.names
+    for t, (nm, shp, sc) in zip(dm.tensors, om.specs):
+        assert tuple(t['shape']) == tuple(shp), (nm, t['shape'], shp)
+        assert (t['init_scale'] is None) == (sc is None)
+    flat = om.flat_params()
+    assert flat.size == dm.P
+    return om, dm, dev(flat.astype(np.float32))
+
+
+def _perturb(om, seed, scale=0.05):
+    """biases/logstd are zero at init; perturb everything so every gradient path is exercised"""
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for k in om.names:
+            om.p[k] += torch.tensor(scale * rng.randn(*om.p[k].shape), dtype=om.p[k].dtype)
+
+
+CONFIGS = {
+    'cartpole_mlp_shared': dict(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind='categorical', nact=2,
+                                value_network=None, kind='cartpole', T=16, N=8, B=64, chunk=64),
+    'mujoco_mlp_copy': dict(network='mlp', ob_shape=(376,), ob_dtype=np.float32, pd_kind='gaussian', nact=17,
+                            value_network='copy', kind='mujoco', T=16, N=24, B=192, chunk=80),
+    'atari_cnn': dict(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6,
+                      value_network=None, kind='atari', T=4, N=8, B=24, chunk=16),
+    'mlp_matching_fc': dict(network='mlp', ob_shape=(11,), ob_dtype=np.float32, pd_kind='gaussian', nact=64,
+                            value_network=None, kind=None, T=8, N=8, B=32, chunk=32),
+}
+
+
+def _rollout(cfg, om, seed):
+    """Seeded synthetic rollout whose actions / values / neglogpacs come from the (oracle) policy
+    itself with teacher-forced noise, like a real Runner.run -> ratios near 1, realistic loss scale."""
+    rng = np.random.RandomState(seed)
+    T, N = cfg['T'], cfg['N']
+    if cfg['kind']:
+        ro = O.synthetic_rollout(cfg['kind'], T, N, seed)
+    else:
+        ro = O.synthetic_rollout('cartpole', T, N, seed)
+        ro['obs'] = rng.randn(*((T, N) + cfg['ob_shape'])).astype(np.float32)
+    acts, vals, nlps = [], [], []
+    for t in range(T):
+        nz = (rng.rand(N, cfg['nact']) if cfg['pd_kind'] == 'categorical' else rng.randn(N, cfg['nact']))
+        a, v, _, nlp = om.step(ro['obs'][t], nz.astype(np.float32))
+        acts.append(a); vals.append(v); nlps.append(nlp)
+    ro['actions'], ro['values'], ro['neglogpacs'] = np.stack(acts), np.stack(vals), np.stack(nlps)
+    ro['last_values'] = om.value(ro['obs'][0])
+    ro['rewards'] = (ro['rewards'] * 0.3).astype(np.float32)
+    return ro
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_model_act_grad_train_vs_oracle(name):
+    cfg = dict(CONFIGS[name])
+    ops = _ops()
+    kind, T, N, B, chunk = cfg.pop('kind'), cfg.pop('T'), cfg.pop('N'), cfg.pop('B'), cfg.pop('chunk')
+    full = dict(CONFIGS[name])
+    om, dm, _ = _make_pair(seed=0, chunk=chunk, **cfg)
+    _perturb(om, 1)
+    ro = _rollout(full, om, 2)
+    _perturb(om, 3, 0.01)          # "a few optimizer steps later": ratios != 1, some samples clipped
+    params = dev(om.flat_params().astype(np.float32))
+    om64 = OracleModel(network=cfg['network'], ob_shape=cfg['ob_shape'], ob_dtype=cfg['ob_dtype'],
+                       pd_kind=cfg['pd_kind'], nact=cfg['nact'], value_network=cfg['value_network'],
+                       ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float64,
+                       params=om.params_numpy())
+    returns, _ = O.gae(ro['rewards'], ro['values'], ro['dones'], ro['last_values'], ro['last_dones'], 0.99, 0.95)
+
+    # ---- act side (teacher-forced noise) ----
+    rng = np.random.RandomState(5)
+    obs0 = ro['obs'][0]
+    noise = (rng.rand(N, cfg['nact']) if cfg['pd_kind'] == 'categorical' else rng.randn(N, cfg['nact'])).astype(np.float32)
+    a_o, v_o, _, nlp_o = om.step(obs0, noise)
+    a_d, v_d, nlp_d, pd_d = dm.act(params, dev(obs0), dev(noise), want_pdparam=True)
+    with torch.no_grad():
+        pd_o, _ = om.forward(obs0)
+    np.testing.assert_allclose(pd_d.cpu().numpy(), pd_o.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(v_d.cpu().numpy(), v_o, rtol=1e-4, atol=2e-5)
+    if cfg['pd_kind'] == 'categorical':
+        np.testing.assert_array_equal(a_d.cpu().numpy().astype(np.int64), a_o)
+    else:
+        np.testing.assert_allclose(a_d.cpu().numpy(), a_o, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(nlp_d.cpu().numpy(), nlp_o, rtol=1e-4, atol=2e-5)
+    v_only = dm.act(params, dev(obs0), None, want_actions=False)[1]
+    np.testing.assert_array_equal(v_only.cpu().numpy(), v_d.cpu().numpy())
+
+    # ---- learner: gradient of the loss on a gathered minibatch ----
+    np.random.seed(7)
+    idx = next(iter(O.minibatch_indices(T * N, B, 1)))
+    f = {k: O.sf01(ro[k]) for k in ('obs', 'actions', 'values', 'neglogpacs')}
+    fret = O.sf01(returns)
+    mb = dict(obs=f['obs'][idx], returns=fret[idx], actions=f['actions'][idx], values=f['values'][idx],
+              neglogpacs=f['neglogpacs'][idx])
+    cliprange = 0.2
+    stats_o, g_o = om.compute_grads(cliprange, mb['obs'], mb['returns'], mb['actions'], mb['values'], mb['neglogpacs'])
+    stats_64, g_64 = om64.compute_grads(cliprange, mb['obs'], mb['returns'], mb['actions'], mb['values'],
+                                        mb['neglogpacs'])
+    acts = ro['actions'].astype(np.int32) if cfg['pd_kind'] == 'categorical' else ro['actions']
+    d_obs, d_act, d_ret = dev(ro['obs']), dev(acts), dev(returns)
+    d_val, d_nlp, d_idx = dev(ro['values']), dev(ro['neglogpacs']), dev(idx)
+    grads = torch.empty(dm.P, dtype=torch.float32, device='cuda')
+    stats = torch.empty(5, dtype=torch.float32, device='cuda')
+    dm.grad(params, d_obs, d_act, d_ret, d_val, d_nlp, d_idx, B, T, N, cliprange, 0.01, 0.5, grads, stats)
+    s_d = stats.cpu().numpy()
+    g_d = grads.cpu().numpy().astype(np.float64)
+    # north-star bar: fp32 losses within 1e-5 of the reference CPU path
+    np.testing.assert_allclose(s_d, np.array(stats_o), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s_d, np.array(stats_64), rtol=1e-5, atol=1e-5)
+    g64 = g_64.numpy()
+    scale = np.abs(g64).max()
+    err_d = np.abs(g_d - g64).max() / scale
+    err_o = np.abs(g_o.numpy().astype(np.float64) - g64).max() / scale
+    assert err_d < 5e-5, (err_d, err_o)          # as close to fp64 as the fp32 CPU restatement is (same class)
+    # per-tensor check so a wrong small tensor cannot hide behind a big one
+    for t in dm.tensors:
+        sl = slice(t['offset'], t['offset'] + t['size'])
+        ref = g64[sl]
+        tol = 5e-5 * max(np.abs(ref).max(), 1e-3 * scale)
+        assert np.abs(g_d[sl] - ref).max() <= tol, (t['name'], np.abs(g_d[sl] - ref).max(), tol)
+
+    # same minibatch passed directly (idx == NULL path)
+    grads2 = torch.empty_like(grads)
+    stats2 = torch.empty_like(stats)
+    mb_act = mb['actions'].astype(np.int32) if cfg['pd_kind'] == 'categorical' else mb['actions']
+    dm.grad(params, dev(mb['obs']), dev(mb_act), dev(mb['returns']), dev(mb['values']), dev(mb['neglogpacs']), None,
+            B, 1, 1, cliprange, 0.01, 0.5, grads2, stats2)
+    np.testing.assert_array_equal(grads2.cpu().numpy(), grads.cpu().numpy())
+    np.testing.assert_array_equal(stats2.cpu().numpy(), s_d)
+
+    # ---- optimizer: 3 full train steps (clip + TF-Adam) ----
+    m = torch.zeros_like(params)
+    v = torch.zeros_like(params)
+    scratch = torch.empty(8192, dtype=torch.uint8, device='cuda')
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    lr = np.float32(3e-4)
+    for it in range(3):
+        om.train(float(lr), cliprange, mb['obs'], mb['returns'], None, mb['actions'], mb['values'], mb['neglogpacs'])
+        dm.grad(params, d_obs, d_act, d_ret, d_val, d_nlp, d_idx, B, T, N, cliprange, 0.01, 0.5, grads, stats)
+        alpha = lr * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p)
+        gn = torch.empty(1, dtype=torch.float32, device='cuda')
+        ops.adam_clip_step(params, grads, m, v, alpha, 0.9, 0.999, 1e-5, 0.5, 1.0, scratch, gn)
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+        assert abs(float(gn.cpu()) - om.last_gnorm) <= 1e-4 * om.last_gnorm
+    np.testing.assert_allclose(params.cpu().numpy(), om.flat_params(), rtol=0, atol=3e-6)
+
+
+def test_adam_clip_matches_oracle_many_steps():
+    ops = _ops()
+    rng = np.random.RandomState(0)
+    P = 100003
+    om = OracleModel(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind='categorical', nact=2)
+    # hijack the oracle's optimizer on a single fake tensor
+    om.names = ['x']
+    om.p = {'x': torch.tensor(rng.randn(P).astype(np.float32))}
+    om.m = {'x': torch.zeros(P)}
+    om.v = {'x': torch.zeros(P)}
+    params = dev(om.p['x'].numpy().copy())
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    scratch = torch.empty(8192, dtype=torch.uint8, device='cuda')
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for it in range(20):
+        g = (rng.randn(P) * (10.0 if it % 2 else 0.001)).astype(np.float32)   # clipped and unclipped steps
+        om.total_weight, om.rank_weight = 1.0, 1.0
+        om.apply_flat_grad(2.5e-4, torch.tensor(g))
+        gd = dev(g)
+        alpha = np.float32(2.5e-4) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p)
+        ops.adam_clip_step(params, gd, m, v, alpha, 0.9, 0.999, 1e-5, 0.5, 1.0, scratch)
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+        np.testing.assert_allclose(gd.cpu().numpy(), om.last_grads.numpy(), rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(params.cpu().numpy(), om.p['x'].numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.cpu().numpy(), om.m['x'].numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(v.cpu().numpy(), om.v['x'].numpy(), rtol=1e-5, atol=1e-12)
