@@ -49,6 +49,14 @@ SIGNATURES = {
     'mrl_adam_scratch_bytes': (c_size_t, [c_long]),
     'mrl_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'mrl_synth_env_obs': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    'mrl_prof_enable': (c_int, [c_int]),
+    'mrl_prof_num_labels': (c_int, []),
+    'mrl_prof_get': (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_double),
+                             ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
 }
 
 _lib = None
@@ -120,3 +128,20 @@ def ptr(t):
         return c_void_p(0)
     assert t.is_cuda and t.is_contiguous(), 'expected a contiguous device tensor'
     return c_void_p(t.data_ptr())
+
+
+def prof_enable(on=True):
+    load().mrl_prof_enable(1 if on else 0)
+
+
+def prof_report():
+    """{label: dict(count, ms, flops, bytes)} accumulated since prof_enable(True)."""
+    lib = load()
+    out = {}
+    name = ctypes.create_string_buffer(128)
+    for i in range(lib.mrl_prof_num_labels()):
+        cnt, ms, fl, by = c_long(), c_double(), c_double(), c_double()
+        check(lib.mrl_prof_get(i, name, 128, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        if cnt.value:
+            out[name.value.decode()] = dict(count=cnt.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    return out

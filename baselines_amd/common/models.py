@@ -1,0 +1,62 @@
+"""Network registry with the reference's surface (common/models.py:7-13, 257-275): builders are
+looked up by name and called with the user's **network_kwargs.  A builder here returns a
+*description* that the HIP model layout (csrc/model.hip) understands, instead of a TF graph
+function.  Supported on the hot path: 'mlp' (models.py:74-103) and 'cnn' = NatureCNN
+(models.py:15-26); every other name raises like get_network_builder does (models.py:275)."""
+
+mapping = {}
+
+
+def register(name):
+    def _thunk(func):
+        mapping[name] = func
+        return func
+    return _thunk
+
+
+class NetworkDesc(object):
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.kw = kw
+
+    def __repr__(self):
+        return 'NetworkDesc(%s, %s)' % (self.kind, self.kw)
+
+
+def _activation_name(activation):
+    if activation is None:
+        return 'tanh'
+    if isinstance(activation, str):
+        name = activation
+    else:
+        name = getattr(activation, '__name__', str(activation))
+    name = name.lower()
+    if 'tanh' in name:
+        return 'tanh'
+    if 'relu' in name:
+        return 'relu'
+    raise ValueError('unsupported mlp activation for the HIP path: {}'.format(activation))
+
+
+@register('mlp')
+def mlp(num_layers=2, num_hidden=64, activation=None, layer_norm=False):
+    if layer_norm:
+        raise NotImplementedError('layer_norm is outside the supported hot path (SURVEY.md 2.1 row 2)')
+    return NetworkDesc('mlp', num_layers=int(num_layers), num_hidden=int(num_hidden),
+                       activation=_activation_name(activation))
+
+
+@register('cnn')
+def cnn(**conv_kwargs):
+    if conv_kwargs:
+        raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(conv_kwargs)))
+    return NetworkDesc('cnn')
+
+
+def get_network_builder(name):
+    if callable(name):
+        return name
+    elif name in mapping:
+        return mapping[name]
+    else:
+        raise ValueError('Unknown network type: {}'.format(name))

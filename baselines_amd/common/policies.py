@@ -1,0 +1,42 @@
+"""build_policy with the reference's signature (common/policies.py:121-179).  Returns a
+PolicySpec: everything the learner needs to lay the model out on the device (network description,
+spaces, value-network mode, probability-distribution type = common/distributions.py:278-290)."""
+import numpy as np
+
+from .models import get_network_builder, NetworkDesc
+from .spaces import is_box, is_discrete
+
+
+class PolicySpec(object):
+    def __init__(self, ob_space, ac_space, network, value_network):
+        self.ob_space, self.ac_space = ob_space, ac_space
+        self.network = network
+        if value_network not in (None, 'shared', 'copy'):
+            raise NotImplementedError("value_network must be None, 'shared' or 'copy' on the HIP path")
+        self.value_copy = (value_network == 'copy')
+        if is_discrete(ac_space):
+            self.pd_kind, self.nact = 'categorical', int(ac_space.n)
+        elif is_box(ac_space):
+            assert len(ac_space.shape) == 1
+            self.pd_kind, self.nact = 'gaussian', int(ac_space.shape[0])
+        else:
+            raise NotImplementedError('action space {} is outside the supported hot path'.format(ac_space))
+        self.ob_shape = tuple(ob_space.shape)
+        self.ob_dtype = np.dtype(ob_space.dtype)
+
+    def device_model_kwargs(self):
+        kw = dict(network=self.network.kind, ob_shape=self.ob_shape, ob_dtype=self.ob_dtype, pd_kind=self.pd_kind,
+                  nact=self.nact, value_copy=self.value_copy)
+        kw.update(self.network.kw)
+        return kw
+
+
+def build_policy(env, policy_network, value_network=None, normalize_observations=False, estimate_q=False,
+                 **policy_kwargs):
+    if normalize_observations or estimate_q:
+        raise NotImplementedError('normalize_observations / estimate_q are outside the PPO2 hot path')
+    if isinstance(policy_network, str):
+        policy_network = get_network_builder(policy_network)(**policy_kwargs)
+    if not isinstance(policy_network, NetworkDesc):
+        raise NotImplementedError('custom TF network functions cannot run on the HIP path; register a NetworkDesc')
+    return PolicySpec(env.observation_space, env.action_space, policy_network, value_network)

@@ -36,4 +36,17 @@ __device__ __forceinline__ long envmajor_to_row(long i, int T, int N) { return (
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional HIP-event profiler (mrl_prof_*): per-label launch count / time / algorithmic work.
+// Events are recorded on the launch stream itself; nothing synchronises until the report is read.
+bool prof_enabled();
+void prof_begin(const char* label, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(const char* label, double flops, double bytes, hipStream_t s) : st(s), on(prof_enabled()) {
+        if (on) prof_begin(label, flops, bytes, st);
+    }
+    ~ProfScope() { if (on) prof_end(st); }
+};
+
 }  // namespace mrl

@@ -29,6 +29,7 @@ struct Layer {
     int act;
     long w_off, b_off;
     long out_elems;                        // per sample
+    char name[16];                         // c1, c2, c3, fc1, mlp_fc0, ...
 };
 
 struct Net {
@@ -92,6 +93,7 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
             l.w_off = add_tensor(m, prefix + "/" + nm[i] + "/w", {rf[i], rf[i], C, nf[i]}, s2);
             l.b_off = add_tensor(m, prefix + "/" + nm[i] + "/b", {1, nf[i], 1, 1}, -1.f);
             l.out_elems = (long)l.OH * l.OW * l.NF;
+            snprintf(l.name, sizeof l.name, "%s", nm[i]);
             net.L.push_back(l);
             H = l.OH; W = l.OW; C = l.NF;
         }
@@ -100,6 +102,7 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
         f.w_off = add_tensor(m, prefix + "/fc1/w", {f.K, f.N}, s2);
         f.b_off = add_tensor(m, prefix + "/fc1/b", {f.N}, -1.f);
         f.out_elems = f.N;
+        snprintf(f.name, sizeof f.name, "fc1");
         net.L.push_back(f);
         net.nlat = 512; net.lat_act = ACT_RELU;
         return 0;
@@ -114,6 +117,7 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
             f.w_off = add_tensor(m, prefix + nm + "/w", {f.K, f.N}, s2);
             f.b_off = add_tensor(m, prefix + nm + "/b", {f.N}, -1.f);
             f.out_elems = f.N;
+            snprintf(f.name, sizeof f.name, "mlp_fc%d", i);
             net.L.push_back(f);
             nin = f.N;
         }
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st) {
     int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    ProfScope ps("reduce_slabs", 0.0, 4.0 * n * (nz + 1 + (accumulate ? 1 : 0)), st);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate);
     MRL_LAUNCH_CHECK();
     return 0;
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void heads_train_kernel(HeadArgs a) {
                     dpi[j] = dnlp * (p - (j == act ? 1.f : 0.f)) + ce * p * (logp + H);
                 }
                 st[0] += (double)fmaxf(pg1, pg2);
-                st[3] += (double)((nlp - oldnlp) * (nlp - oldnlp));
+                st[3] += 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
                 st[4] += (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
             } else {
                 const float* x = static_cast<const float*>(a.actions) + r * a.nact;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void heads_train_kernel(HeadArgs a) {
                     dls[k] = dnlp * (1.f - u * u) - ce;
                 }
                 st[0] += (double)fmaxf(pg1, pg2);
-                st[3] += (double)((nlp - oldnlp) * (nlp - oldnlp));
+                st[3] += 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
                 st[4] += (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
             }
             // value loss (model.py:68-75)
@@ -642,9 +647,14 @@ struct In {               // layer-0 input description
 };
 
 template <class AF, class BF, class EF>
-static int gemm_dispatch(const AF& af, const BF& bf, const EF& ef, int M, int N, int K, int zdim, int ksplit,
-                         hipStream_t st) {
+static int gemm_dispatch(const char* lname, const char* pass, const AF& af, const BF& bf, const EF& ef, int M,
+                         int N, int K, int zdim, int ksplit, hipStream_t st) {
     hipError_t e;
+    char label[40];
+    if (prof_enabled()) snprintf(label, sizeof label, "%s.%s", lname, pass);
+    // algorithmic work of the launch: 2*M*N*K flops (for the conv data-gradient K counts the taps of
+    // all parity classes, i.e. every filter tap exactly once per output pixel -> zdim cancels)
+    ProfScope ps(label, 2.0 * M * (double)N * K * ((ksplit >= K) ? zdim : 1), 0.0, st);
     if (N <= 32) e = launch_gemm<AF, BF, EF, 4, 1, 1, 1>(af, bf, ef, M, N, K, zdim, ksplit, st);
     else if (N <= 64) e = launch_gemm<AF, BF, EF, 4, 1, 1, 2>(af, bf, ef, M, N, K, zdim, ksplit, st);
     else e = launch_gemm<AF, BF, EF, 2, 2, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st);
@@ -665,12 +675,12 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
             ConvPatchKC<true> af;
             af.p = in.obs; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
             af.OW = l.OW; af.npix = npix; af.kconv = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N;
-            return gemm_dispatch(af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+            return gemm_dispatch(l.name, "fwd", af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
         } else {
             ConvPatchKC<false> af;
             af.p = hprev; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
             af.OW = l.OW; af.npix = npix; af.kconv = l.K; af.idx = nullptr; af.T = 1; af.N = 1;
-            return gemm_dispatch(af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+            return gemm_dispatch(l.name, "fwd", af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
         }
     } else {
         EpiBiasAct ef{hout, l.N, bias, l.act};
@@ -678,10 +688,10 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
             GatherKC af;
             af.p = (const float*)in.obs; af.ld = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N; af.rows = B;
             af.kmax = l.K; af.vec = is_vec(in.obs, l.K);
-            return gemm_dispatch(af, bf, ef, B, l.N, l.K, 1, l.K, st);
+            return gemm_dispatch(l.name, "fwd", af, bf, ef, B, l.N, l.K, 1, l.K, st);
         } else {
             RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K)};
-            return gemm_dispatch(af, bf, ef, B, l.N, l.K, 1, l.K, st);
+            return gemm_dispatch(l.name, "fwd", af, bf, ef, B, l.N, l.K, 1, l.K, st);
         }
     }
 }
@@ -715,22 +725,22 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 ConvPatchMC<true> af;
                 af.p = in.obs; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
                 af.OW = l.OW; af.npix = (int)rows; af.kconv = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N;
-                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
             } else {
                 ConvPatchMC<false> af;
                 af.p = hprev; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
                 af.OW = l.OW; af.npix = (int)rows; af.kconv = l.K; af.idx = nullptr; af.T = 1; af.N = 1;
-                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
             }
         } else {
             if (first) {
                 GatherMC af;
                 af.p = (const float*)in.obs; af.ld = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N; af.rows = B;
                 af.kmax = l.K; af.vec = is_vec(in.obs, l.K);
-                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
             } else {
                 RowMC af{hprev, l.K, l.K, B, is_vec(hprev, l.K)};
-                rc = gemm_dispatch(af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
             }
         }
         if (rc) return rc;
@@ -738,7 +748,10 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         if (rc) return rc;
         // ---- bias gradient
         int nblk = (int)std::min<long>(BIAS_MAXBLK, std::max<long>(1, rows / 64));
-        hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), st, dz, rows, l.N, ws.part);
+        {
+            ProfScope ps("bias_colsum", 0.0, 4.0 * rows * l.N, st);
+            hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), st, dz, rows, l.N, ws.part);
+        }
         MRL_LAUNCH_CHECK();
         rc = reduce_slabs(ws.part, l.N, nblk, grads + l.b_off, l.N, accumulate, st);
         if (rc) return rc;
@@ -754,13 +767,13 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 DgradB bf; static_cast<DgradGeom&>(bf) = g; bf.w = params + l.w_off;
                 EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hprev; ef.act = lp.act;
                 int Kd = g.taps * g.taps * l.NF;
-                rc = gemm_dispatch(af, bf, ef, B * g.HY * g.WX, l.C, Kd, l.stride * l.stride, Kd, st);
+                rc = gemm_dispatch(l.name, "dgrad", af, bf, ef, B * g.HY * g.WX, l.C, Kd, l.stride * l.stride, Kd, st);
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N)};
                 const float* W = params + l.w_off;
                 RowKC bf{W, l.N, l.K, l.N, is_vec(W, l.N)};
                 EpiMaskAct ef{nw.dz[i - 1], l.K, hprev, lp.act};
-                rc = gemm_dispatch(af, bf, ef, B, l.K, l.N, 1, l.N, st);
+                rc = gemm_dispatch(l.name, "dgrad", af, bf, ef, B, l.K, l.N, 1, l.N, st);
             }
             if (rc) return rc;
         }
@@ -832,6 +845,7 @@ extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
+        ProfScope ps("heads_act", 0.0, (double)Bc * (4.0 * a.nlat + (a.shared ? 0 : 4.0 * a.nlatv) + 16.0), st);
         hipLaunchKernelGGL(heads_act_kernel, dim3(std::min(ntiles, HEAD_MAXBLK)), dim3(256), lds, st, a);
         MRL_LAUNCH_CHECK();
     }
@@ -856,9 +870,11 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     double* stats_acc = spart + HEAD_MAXBLK * 5;
     // minibatch advantage statistics (model.py:136-139)
     int G = std::min(ADV_G, (B + 255) / 256);
+    ProfScope* psadv = new ProfScope("adv_stats", 0.0, (idx ? 16.0 : 8.0) * B, st);
     hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, B, T, N, advpart);
     MRL_LAUNCH_CHECK();
     hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, B, ws.advstat, stats_acc);
+    delete psadv;
     MRL_LAUNCH_CHECK();
     const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
     const float invB = 1.f / (float)B;
@@ -890,7 +906,11 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(heads_train_kernel, dim3(nblk), dim3(256), lds, st, a);
+        {
+            // algorithmic traffic: latent in, dz out, per-sample rollout scalars
+            ProfScope ps("heads_loss", 0.0, (double)Bc * (8.0 * a.nlat + (a.shared ? 0 : 8.0 * a.nlatv) + 28.0), st);
+            hipLaunchKernelGGL(heads_train_kernel, dim3(nblk), dim3(256), lds, st, a);
+        }
         MRL_LAUNCH_CHECK();
         if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st))) return rc;
         hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, nblk, stats_acc);

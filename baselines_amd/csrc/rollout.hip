@@ -1,9 +1,90 @@
 // Rollout-side kernels: GAE scan (K2), gather / sf01 (K4/K3), clip+Adam (K8/K9).
+#include <string.h>
+
 #include "common.hip.h"
 
 using namespace mrl;
 
+#include <map>
+#include <string>
+#include <vector>
+
 extern "C" int mrl_version(void) { return MRL_VERSION; }
+
+// ------------------------------------------------------------------------------------------
+// profiler state (the one piece of process-global state in the library; off by default)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { int label; hipEvent_t a, b; double flops, bytes; };
+struct ProfLabel { std::string name; long count; double ms, flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+std::vector<ProfLabel> g_labels;
+std::map<std::string, int> g_label_ids;
+int g_open = -1;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void resolve() {
+    for (ProfRec& r : g_recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        ProfLabel& l = g_labels[r.label];
+        l.count += 1; l.ms += ms; l.flops += r.flops; l.bytes += r.bytes;
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+}
+}  // namespace
+
+namespace mrl {
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(const char* label, double flops, double bytes, hipStream_t st) {
+    auto it = g_label_ids.find(label);
+    int id;
+    if (it == g_label_ids.end()) {
+        id = (int)g_labels.size();
+        g_label_ids[label] = id;
+        g_labels.push_back(ProfLabel{label, 0, 0, 0, 0});
+    } else id = it->second;
+    ProfRec r{id, get_event(), get_event(), flops, bytes};
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    g_open = (int)g_recs.size() - 1;
+}
+void prof_end(hipStream_t st) {
+    if (g_open >= 0) (void)hipEventRecord(g_recs[g_open].b, st);
+    g_open = -1;
+}
+}  // namespace mrl
+
+extern "C" int mrl_prof_enable(int on) {
+    if (on) {
+        resolve();
+        for (ProfLabel& l : g_labels) { l.count = 0; l.ms = l.flops = l.bytes = 0; }
+    }
+    g_prof_on = on != 0;
+    return 0;
+}
+extern "C" int mrl_prof_num_labels(void) { resolve(); return (int)g_labels.size(); }
+extern "C" int mrl_prof_get(int i, char* name, int name_cap, long* count, double* total_ms, double* total_flops,
+                            double* total_bytes) {
+    resolve();
+    if (i < 0 || i >= (int)g_labels.size()) return MRL_EINVAL;
+    const ProfLabel& l = g_labels[i];
+    if (name && name_cap > 0) { strncpy(name, l.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (count) *count = l.count;
+    if (total_ms) *total_ms = l.ms;
+    if (total_flops) *total_flops = l.flops;
+    if (total_bytes) *total_bytes = l.bytes;
+    return 0;
+}
 
 extern "C" const char* mrl_strerror(int code) {
     switch (code) {
@@ -92,6 +173,7 @@ extern "C" int mrl_gae(const float* rew, const float* val, const uint8_t* done, 
                        int T, int N, void* stream) {
     if (T <= 0 || N <= 0 || !rew || !val || !done || !last_val || !last_done || !ret_out) return MRL_EINVAL;
     dim3 grid((N + GAE_E - 1) / GAE_E);
+    ProfScope ps("gae", 0.0, 17.0 * T * N + 9.0 * N, (hipStream_t)stream);
     hipLaunchKernelGGL(gae_kernel, grid, dim3(256), 0, (hipStream_t)stream, rew, val, done, last_val, last_done,
                        (float)gamma, gamma * lam, adv_out, ret_out, T, N);
     MRL_LAUNCH_CHECK();
@@ -218,6 +300,7 @@ extern "C" int mrl_adam_clip_step(float* params, float* grads, float* m, float* 
     if (!params || !grads || !m || !v || P <= 0 || !scratch || total_weight <= 0.f) return MRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int blocks = (int)min((P + 1023) / 1024, (long)ADAM_MAX_PART);
+    ProfScope ps("clip+adam", 0.0, (max_grad_norm >= 0.f ? 32.0 : 28.0) * P, st);
     if (max_grad_norm >= 0.f) {
         hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grads, P, total_weight, (double*)scratch);
         MRL_LAUNCH_CHECK();

@@ -1,0 +1,242 @@
+"""PPO2 learner object with the reference's protocol (ppo2/model.py:27-158):
+
+    Model(policy=, ob_space=, ac_space=, nbatch_act=, nbatch_train=, nsteps=, ent_coef=, vf_coef=,
+          max_grad_norm=, mpi_rank_weight=1, comm=None, microbatch_size=None)
+    .step(obs, S=, M=) -> (actions, values, states, neglogpacs)     .value(obs, S=, M=)
+    .train(lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None) -> 5 stats
+    .loss_names  .initial_state  .save(path)  .load(path)
+
+Where the reference builds a TF graph and calls sess.run, this object owns flat fp32 device
+buffers (params / grads / Adam m, v) and drives the HIP kernels through the C ABI:
+    mrl_model_act   (policy forward + sampling)        mrl_model_grad (gather + fwd + loss + bwd)
+    [RCCL all-reduce of the flat gradient]             mrl_adam_clip_step (avg -> clip -> Adam)
+Extra, faster entry points used by our Runner / learn (no host round trips):
+    .step_into(...)   .train_indexed(lr, cliprange, rollout, idx_dev)
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..common.dist import default_comm
+
+
+def ortho_init(shape, scale):
+    """Orthogonal init drawn from the GLOBAL NumPy stream exactly like the reference
+    (a2c/utils.py:20-35: np.random.normal -> SVD -> pick the factor with the right shape), so
+    `set_global_seeds(seed)` reproduces the reference's weights.  Host code by design: LAPACK sign
+    conventions make a device re-implementation non-reproducible."""
+    shape = tuple(shape)
+    if len(shape) == 2:
+        flat_shape = shape
+    elif len(shape) == 4:
+        flat_shape = (int(np.prod(shape[:-1])), shape[-1])
+    else:
+        raise NotImplementedError
+    a = np.random.normal(0.0, 1.0, flat_shape)
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == flat_shape else v
+    q = q.reshape(shape)
+    return (scale * q[:shape[0], :shape[1]]).astype(np.float32)
+
+
+class Model(object):
+    loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+
+    def __init__(self, *, policy, ob_space, ac_space, nbatch_act, nbatch_train, nsteps, ent_coef, vf_coef,
+                 max_grad_norm, mpi_rank_weight=1, comm=None, microbatch_size=None, chunk=None, device=None):
+        _lib.require_gpu()
+        self.device = torch.device(device or ('cuda:%d' % torch.cuda.current_device()))
+        if comm is None:
+            comm = default_comm()
+        self.comm = comm
+        self.mpi_rank_weight = mpi_rank_weight
+        self.policy = policy
+        self.nbatch_act, self.nbatch_train, self.nsteps = nbatch_act, nbatch_train, nsteps
+        self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), max_grad_norm
+        self.microbatch_size = microbatch_size
+        kw = policy.device_model_kwargs()
+        if chunk is None:
+            # samples processed per pass of the layer kernels (activations + their gradients live in
+            # the workspace: ~173 KB/sample for NatureCNN)
+            chunk = 8192 if kw['network'] == 'cnn' else 32768
+        chunk = int(max(1, min(chunk, max(nbatch_train or 1, nbatch_act or 1))))
+        self.dm = ops.DeviceModel(chunk=chunk, device=self.device, **kw)
+        self.pd_kind, self.nact = self.dm.pd_kind, self.dm.nact
+        P = self.dm.P
+        # ---- parameters: reference init order and RNG stream ----
+        flat = np.zeros(P, np.float32)
+        for t in self.dm.tensors:
+            if t['init_scale'] is not None:
+                flat[t['offset']:t['offset'] + t['size']] = ortho_init(t['shape'], t['init_scale']).reshape(-1)
+        self.params = torch.from_numpy(flat).to(self.device)
+        self.grads = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.adam_m = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self._scratch = torch.empty(int(_lib.load().mrl_adam_scratch_bytes(P)), dtype=torch.uint8, device=self.device)
+        self._gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # tf.train.AdamOptimizer(learning_rate=LR, epsilon=1e-5) (model.py:98-100): f32 slot variables
+        self.beta1, self.beta2, self.epsilon = np.float32(0.9), np.float32(0.999), np.float32(1e-5)
+        self.beta1_power, self.beta2_power = np.float32(0.9), np.float32(0.999)
+        self.initial_state = None
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(torch.initial_seed()) & 0x7fffffff)
+        self._train_calls = 0
+        # ---- multi-rank: total weight (mpi_adam_optimizer.py:25-27), sync_from_root (model.py:129-131) ----
+        self.total_weight = 1.0
+        if self.comm is not None and self.comm.Get_size() > 1:
+            self.total_weight = self.comm.total_weight(mpi_rank_weight)
+            for t in (self.params, self.adam_m, self.adam_v):
+                self.comm.bcast_(t, 0)
+        self.multi = self.comm is not None and self.comm.Get_size() > 1
+
+    # ------------------------------------------------------------------ act side
+    def _to_dev_obs(self, obs):
+        if isinstance(obs, torch.Tensor):
+            t = obs.to(self.device)
+        else:
+            a = np.asarray(obs)
+            if a.dtype == np.int8:
+                a = a.view(np.uint8)
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if t.dtype != self.dm.torch_ob_dtype:
+            t = t.to(self.dm.torch_ob_dtype)
+        # tf_util.adjust_shape (tf_util.py:377-401): anything reshapeable to [-1, *ob_shape] is accepted
+        return t.reshape((-1,) + tuple(self.policy.ob_shape)).contiguous()
+
+    def make_noise(self, n):
+        """uniform(0,1) for the Gumbel-max sampler (distributions.py:199-201), N(0,1) for the Gaussian
+        (:247-248); torch's Philox generator on the device stands in for TF's."""
+        if self.pd_kind == 'categorical':
+            return torch.rand((n, self.nact), generator=self._gen, device=self.device, dtype=torch.float32)
+        return torch.randn((n, self.nact), generator=self._gen, device=self.device, dtype=torch.float32)
+
+    def step_into(self, obs_dev, actions_out, values_out, neglogp_out, noise=None):
+        """Device fast path: obs [n, ...] device tensor; results written into the given device
+        buffers (e.g. slot t of the rollout SoA) -- K1 'rollout store' is therefore zero-copy."""
+        if noise is None:
+            noise = self.make_noise(obs_dev.shape[0])
+        self.dm.act_into(self.params, obs_dev, noise, actions_out, values_out, neglogp_out)
+
+    def step(self, observation, S=None, M=None, noise=None, **_):
+        """policies.py:77-96: returns host arrays (actions int64 [n] | f32 [n, nact], values f32,
+        None, neglogpacs f32)."""
+        obs = self._to_dev_obs(observation)
+        if noise is None:
+            noise = self.make_noise(obs.shape[0])
+        elif not isinstance(noise, torch.Tensor):
+            noise = torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float32)).to(self.device)
+        a, v, nlp, _ = self.dm.act(self.params, obs, noise)
+        a = a.cpu().numpy()
+        if self.pd_kind == 'categorical':
+            a = a.astype(np.int64)       # tf.argmax dtype
+        return a, v.cpu().numpy(), None, nlp.cpu().numpy()
+
+    def value(self, ob, *args, **kwargs):
+        obs = self._to_dev_obs(ob)
+        return self.dm.act(self.params, obs, None, want_actions=False)[1].cpu().numpy()
+
+    def value_dev(self, obs_dev):
+        return self.dm.act(self.params, obs_dev, None, want_actions=False)[1]
+
+    # ------------------------------------------------------------------ learner
+    def _apply_gradients(self, lr):
+        """[RCCL all-reduce] -> / total weight -> clip_by_global_norm -> Adam   (model.py:102-114,
+        mpi_adam_optimizer.py:21,39-40).  Everything stays on the device / on the stream."""
+        if self.multi:
+            if self.mpi_rank_weight != 1:
+                self.grads.mul_(float(self.mpi_rank_weight))
+            self.comm.allreduce_sum_(self.grads)
+            if self._train_calls % 100 == 0:          # mpi_adam_optimizer.py:41-43
+                self.comm.check_synced(self.params[:1024].sum().reshape(1))
+        one = np.float32(1)
+        alpha = np.float32(lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
+        ops.adam_clip_step(self.params, self.grads, self.adam_m, self.adam_v, alpha, self.beta1, self.beta2,
+                           self.epsilon, self.max_grad_norm, self.total_weight, self._scratch, self._gnorm)
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self._train_calls += 1
+
+    def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None):
+        """One minibatch step reading the device rollout in place: `idx_dev` (int64 device tensor) holds
+        the reference's env-major flat indices (ppo2.py:160-162); the gather is fused into the
+        first-layer loaders.  Returns a device tensor [5] (no host sync)."""
+        stats = stats_out if stats_out is not None else torch.empty(5, dtype=torch.float32, device=self.device)
+        self.dm.grad(self.params, rollout.obs, rollout.actions, rollout.returns, rollout.values, rollout.neglogpacs,
+                     idx_dev, idx_dev.numel(), rollout.T, rollout.N, cliprange, self.ent_coef, self.vf_coef,
+                     self.grads, stats)
+        self._apply_gradients(lr)
+        return stats
+
+    def _field(self, x, dtype):
+        if isinstance(x, torch.Tensor):
+            return x.to(self.device, dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(self.device).to(dtype).contiguous()
+
+    def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
+        """Reference signature (model.py:133-158): arrays of one already-gathered minibatch (host
+        NumPy or device tensors).  Returns the 5 stats as Python floats."""
+        assert states is None, 'recurrent policies are outside the supported hot path'
+        obs = self._to_dev_obs(obs)
+        B = obs.shape[0]
+        act = self._field(actions, torch.int32 if self.pd_kind == 'categorical' else torch.float32)
+        ret, val, nlp = (self._field(x, torch.float32) for x in (returns, values, neglogpacs))
+        stats = torch.empty(5, dtype=torch.float32, device=self.device)
+        self.dm.grad(self.params, obs, act, ret, val, nlp, None, B, 1, 1, cliprange, self.ent_coef, self.vf_coef,
+                     self.grads, stats)
+        self._apply_gradients(lr)
+        return [float(x) for x in stats.cpu().numpy()]
+
+    # ------------------------------------------------------------------ checkpoints
+    def _named(self, flat):
+        host = flat.detach().cpu().numpy()
+        return {t['name']: host[t['offset']:t['offset'] + t['size']].reshape(t['shape']).copy() for t in self.dm.tensors}
+
+    def save(self, save_path):
+        """joblib dict {tf_variable_name: ndarray} over ALL global variables -- parameters, Adam
+        slots and beta powers -- the reference's checkpoint format (tf_util.py:345-355; names per
+        SURVEY.md App. A.6)."""
+        import joblib
+        d = {}
+        for k, v in self._named(self.params).items():
+            d[k + ':0'] = v
+        for k, v in self._named(self.adam_m).items():
+            d[k + '/Adam:0'] = v
+        for k, v in self._named(self.adam_v).items():
+            d[k + '/Adam_1:0'] = v
+        d['beta1_power:0'] = np.float32(self.beta1_power)
+        d['beta2_power:0'] = np.float32(self.beta2_power)
+        dirname = os.path.dirname(save_path)
+        if dirname:
+            os.makedirs(dirname, exist_ok=True)
+        joblib.dump(d, save_path)
+
+    def load(self, load_path):
+        """tf_util.py:357-372: assigns by variable name (missing Adam slots keep their values)."""
+        import joblib
+        d = joblib.load(os.path.expanduser(load_path))
+
+        def fill(dst, suffix, required):
+            host = dst.detach().cpu().numpy()
+            for t in self.dm.tensors:
+                key = t['name'] + suffix
+                if key in d:
+                    host[t['offset']:t['offset'] + t['size']] = np.asarray(d[key], np.float32).reshape(-1)
+                elif required:
+                    raise KeyError(key)
+            dst.copy_(torch.from_numpy(host))
+
+        fill(self.params, ':0', True)
+        fill(self.adam_m, '/Adam:0', False)
+        fill(self.adam_v, '/Adam_1:0', False)
+        if 'beta1_power:0' in d:
+            self.beta1_power = np.float32(d['beta1_power:0'])
+            self.beta2_power = np.float32(d['beta2_power:0'])
+
+    # helpers for tests / users
+    def get_flat_params(self):
+        return self.params.detach().cpu().numpy().copy()
+
+    def set_flat_params(self, flat):
+        self.params.copy_(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)))

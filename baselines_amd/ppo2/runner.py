@@ -1,0 +1,173 @@
+"""PPO2 rollout collector with the reference's contract (ppo2/runner.py:13-74):
+
+    Runner(env=, model=, nsteps=, gamma=, lam=).run()
+        -> (obs, returns, masks, actions, values, neglogpacs, states, epinfos)
+    first six: env-major flat [N*T, ...] (index i = e*T + t), dtypes obs-dtype / f32 / bool /
+    int64-or-f32 / f32 / f32.
+
+MI355X design: the rollout lives in HBM as time-major SoA `Rollout` ([T][N] fields; coalesced for
+the act kernels, the GAE scan and the gather loaders).  The per-step Python lists + np.asarray +
+sf01 copies of the reference (3 full copies of the observations) do not exist: the act kernel
+writes slot t in place, a device env writes slot t+1 in place, GAE is one HIP kernel, and env-major
+order is an index translation inside the consumers.  `run()` still hands back env-major host arrays
+when the caller wants them (`return_host=True`, default for host environments); with
+`return_host=False` it returns `RolloutField` handles that behave like those arrays under
+`arr[mbinds]` but gather on the device.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..common.runners import AbstractEnvRunner
+
+
+class Rollout(object):
+    """Device-resident SoA rollout buffer (time-major)."""
+
+    def __init__(self, T, N, ob_shape, ob_dtype, pd_kind, nact, device):
+        self.T, self.N = T, N
+        f32 = dict(dtype=torch.float32, device=device)
+        self.obs = torch.empty((T, N) + tuple(ob_shape), dtype=ob_dtype, device=device)
+        if pd_kind == 'categorical':
+            self.actions = torch.empty((T, N), dtype=torch.int32, device=device)
+        else:
+            self.actions = torch.empty((T, N, nact), **f32)
+        self.rewards = torch.empty((T, N), **f32)
+        self.values = torch.empty((T, N), **f32)
+        self.neglogpacs = torch.empty((T, N), **f32)
+        self.returns = torch.empty((T, N), **f32)
+        self.dones = torch.empty((T, N), dtype=torch.uint8, device=device)   # done flag ENTERING step t
+        self.pd_kind = pd_kind
+
+
+class RolloutField(object):
+    """Env-major view of a time-major device field: `field[mbinds]` == the reference's
+    `sf01(arr)[mbinds]` (runner.py:69-74 + ppo2.py:162), computed by the gather kernel."""
+
+    def __init__(self, tensor, T, N, host_dtype):
+        self.tensor, self.T, self.N, self.host_dtype = tensor, T, N, host_dtype
+
+    def __len__(self):
+        return self.T * self.N
+
+    @property
+    def shape(self):
+        return (self.T * self.N,) + tuple(self.tensor.shape[2:])
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, torch.Tensor):
+            idx = torch.from_numpy(np.ascontiguousarray(np.asarray(idx, dtype=np.int64)))
+        idx = idx.to(self.tensor.device, torch.int64)
+        return ops.gather_rows(self.tensor, idx, self.T, self.N)
+
+    def to_numpy(self):
+        return ops.sf01(self.tensor).cpu().numpy().astype(self.host_dtype, copy=False)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.to_numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+
+class Runner(AbstractEnvRunner):
+    def __init__(self, *, env, model, nsteps, gamma, lam, return_host=None):
+        super().__init__(env=env, model=model, nsteps=nsteps)
+        self.lam = lam
+        self.gamma = gamma
+        self.device = getattr(model, 'device', torch.device('cuda'))
+        ob_space = env.observation_space
+        ob_np = np.dtype(ob_space.dtype)
+        ob_t = torch.uint8 if ob_np in (np.dtype(np.uint8), np.dtype(np.int8)) else torch.float32
+        pd_kind = getattr(model, 'pd_kind', None)
+        if pd_kind is None:
+            pd_kind = 'categorical' if type(env.action_space).__name__ == 'Discrete' else 'gaussian'
+        nact = getattr(model, 'nact', None) or (env.action_space.n if pd_kind == 'categorical'
+                                                else env.action_space.shape[0])
+        self.rollout = Rollout(nsteps, self.nenv, ob_space.shape, ob_t, pd_kind, nact, self.device)
+        self.return_host = (not self.device_env) if return_host is None else return_host
+        self.fast_step = hasattr(model, 'step_into')
+        self._dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=self.device)
+        self._ob_np = ob_np
+
+    # ------------------------------------------------------------------
+    def _run_device_env(self, ro):
+        T = self.nsteps
+        fin_r, fin_l = [], []
+        ro.obs[0].copy_(self.obs)                      # cursor -> slot 0
+        nxt_last = self.obs                            # reused as the landing buffer of the last step
+        for t in range(T):
+            self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
+            ro.dones[t].copy_(self._dones_dev)
+            obs_out = ro.obs[t + 1] if t + 1 < T else nxt_last
+            _, _, _, info = self.env.step_into(ro.actions[t], obs_out=obs_out, rew_out=ro.rewards[t],
+                                               done_out=self._dones_dev)
+            fin_r.append(info['fin_r'])
+            fin_l.append(info['fin_l'])
+        self.obs = nxt_last
+        last_values = self.model.value_dev(self.obs)
+        epinfos = []
+        fl = torch.stack(fin_l)
+        mask = fl > 0
+        if bool(mask.any()):                           # one host sync per rollout, not per step
+            rs = torch.stack(fin_r)[mask].cpu().numpy()
+            ls = fl[mask].cpu().numpy()
+            epinfos = [{'r': float(r), 'l': int(l)} for r, l in zip(rs, ls)]
+        return last_values, epinfos
+
+    def _run_host_env(self, ro):
+        T = self.nsteps
+        epinfos = []
+        rewards_host = np.zeros((T, self.nenv), np.float32)
+        dones_host = np.zeros((T, self.nenv), np.bool_)
+        for t in range(T):
+            obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
+            ro.obs[t].copy_(torch.from_numpy(obs_np))          # runner.py:30 snapshot, straight into HBM
+            if self.fast_step:
+                self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
+                actions = ro.actions[t].cpu().numpy()
+                if ro.pd_kind == 'categorical':
+                    actions = actions.astype(np.int64)
+            else:
+                actions, values, self.states, neglogpacs = self.model.step(self.obs, S=self.states, M=self.dones)
+                ro.actions[t].copy_(torch.from_numpy(np.asarray(actions)).to(ro.actions.dtype))
+                ro.values[t].copy_(torch.from_numpy(np.asarray(values, np.float32)))
+                ro.neglogpacs[t].copy_(torch.from_numpy(np.asarray(neglogpacs, np.float32)))
+            dones_host[t] = self.dones
+            self.obs[:], rewards, self.dones, infos = self.env.step(actions)
+            for info in infos:
+                maybeepinfo = info.get('episode')
+                if maybeepinfo:
+                    epinfos.append(maybeepinfo)
+            rewards_host[t] = rewards
+        ro.rewards.copy_(torch.from_numpy(rewards_host))
+        ro.dones.copy_(torch.from_numpy(dones_host.view(np.uint8)))
+        self._dones_dev.copy_(torch.from_numpy(np.asarray(self.dones, np.bool_).view(np.uint8)))
+        if hasattr(self.model, 'value_dev'):
+            obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
+            last_values = self.model.value_dev(torch.from_numpy(obs_np).to(self.device))
+        else:
+            last_values = torch.from_numpy(np.asarray(self.model.value(self.obs, S=self.states, M=self.dones),
+                                                      np.float32)).to(self.device)
+        return last_values, epinfos
+
+    def run(self):
+        ro = self.rollout
+        if self.device_env and self.fast_step:
+            last_values, epinfos = self._run_device_env(ro)
+        else:
+            last_values, epinfos = self._run_host_env(ro)
+        # GAE(lambda) + returns: one HIP kernel, bit-exact vs runner.py:52-65
+        ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, self._dones_dev, self.gamma, self.lam)
+        T, N = ro.T, ro.N
+        act_dtype = np.int64 if ro.pd_kind == 'categorical' else np.float32
+        fields = (RolloutField(ro.obs, T, N, self._ob_np), RolloutField(ro.returns, T, N, np.float32),
+                  RolloutField(ro.dones, T, N, np.bool_), RolloutField(ro.actions, T, N, act_dtype),
+                  RolloutField(ro.values, T, N, np.float32), RolloutField(ro.neglogpacs, T, N, np.float32))
+        if self.return_host:
+            fields = tuple(f.to_numpy() for f in fields)
+        return (*fields, self.states, epinfos)
+
+
+def sf01(arr):
+    """swap and then flatten axes 0 and 1 (runner.py:69-74); host helper kept for API parity."""
+    s = arr.shape
+    return arr.swapaxes(0, 1).reshape(s[0] * s[1], *s[2:])

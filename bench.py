@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/sec of the PPO2 update (GAE + noptepochs x nminibatches minibatch
+steps: gather -> NatureCNN fwd -> loss -> bwd -> [RCCL all-reduce] -> clip -> Adam) on a pre-filled
+device rollout, Atari-shaped (84x84x4 uint8, Discrete(6)), num_envs=4096 (whole job), nsteps=128,
+reference Atari hyper-parameters (ppo2/defaults.py:15-22: noptepochs=4, nminibatches=4,
+ent_coef=0.01, cliprange=0.1, lr=2.5e-4).  BASELINE.json metric; SURVEY.md 8(d) "update-only".
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: launched by torch.distributed.run, one rank per GPU; num_envs is SHARDED over ranks:
+     strong scaling, one RCCL all-reduce of the 6.75 MB flat gradient per minibatch step)
+
+A "step" = one update over num_envs*nsteps env-steps.  Data: synthetic (device-resident counter-hash
+env; rollout filled by one real Runner.run()).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(kind, cores_hint=None):
+    """The oracle (CPU port of the reference path: NumPy GAE / shuffle / gather / adv-norm +
+    torch-CPU restatement of the TF graph, all host cores like the reference's TF session,
+    tf_util.py:58-66) timed on a BOUNDED sample of the same workload: one full update at
+    num_envs=32 (Atari) / 256 (MuJoCo-shaped), same nsteps / epochs / minibatches."""
+    from oracle import ppo2_numpy as O
+    from oracle.ppo2_torch import OracleModel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    if kind == 'atari':
+        N, T, E, M = 32, 128, 4, 4
+        net = dict(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6,
+                   value_network=None, ent_coef=0.01)
+        lr, clip = 2.5e-4, 0.1
+    else:
+        N, T, E, M = 256, 128, 10, 32
+        net = dict(network='mlp', ob_shape=(376,), ob_dtype=np.float32, pd_kind='gaussian', nact=17,
+                   value_network='copy', ent_coef=0.0)
+        lr, clip = 3e-4, 0.2
+    np.random.seed(0)
+    om = OracleModel(vf_coef=0.5, max_grad_norm=0.5, **net)
+    ro = O.synthetic_rollout(kind, T, N, 0)
+    t0 = time.perf_counter()
+    returns, _ = O.gae(ro['rewards'], ro['values'], ro['dones'], ro['last_values'], ro['last_dones'], 0.99, 0.95)
+    f = {k: O.sf01(ro[k]) for k in ('obs', 'actions', 'values', 'neglogpacs')}
+    fret = O.sf01(returns)
+    for idx in O.minibatch_indices(T * N, T * N // M, E):
+        om.train(lr, clip, f['obs'][idx], fret[idx], None, f['actions'][idx], f['values'][idx], f['neglogpacs'][idx])
+    dt = time.perf_counter() - t0
+    return {'value': N * T / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': 'one PPO2 update (GAE + %dx%d minibatch steps) at num_envs=%d nsteps=%d, %.1f s of CPU work; '
+                      'oracle = reference NumPy path + torch-CPU fp32 restatement of the TF graph' % (E, M, N, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='atari', choices=['atari', 'mujoco'])
+    ap.add_argument('--num-envs', type=int, default=None, help='whole-job num_envs (default 4096 atari / 1024 mujoco)')
+    ap.add_argument('--nsteps', type=int, default=128)
+    ap.add_argument('--chunk', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not record HIP events per kernel in the timed region')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)' % (args.gpus, world)
+
+    from baselines_amd import _lib
+    from baselines_amd.common import set_global_seeds
+    from baselines_amd.common.dist import default_comm
+    from baselines_amd.common.policies import build_policy
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
+    from baselines_amd.ppo2 import Model, Runner
+
+    if args.workload == 'atari':
+        total_envs = args.num_envs or 4096
+        hp = dict(noptepochs=4, nminibatches=4, ent_coef=0.01, lr=2.5e-4, cliprange=0.1, network='cnn', value_network=None)
+        flops_per_sample_visit = 49.526e6      # SURVEY.md App. B (fwd+bwd)
+    else:
+        total_envs = args.num_envs or 1024
+        hp = dict(noptepochs=10, nminibatches=32, ent_coef=0.0, lr=3e-4, cliprange=0.2, network='mlp', value_network='copy')
+        flops_per_sample_visit = 248.6e3
+    assert total_envs % world == 0
+    N = total_envs // world
+    T = args.nsteps
+    nbatch = N * T
+    nbatch_train = nbatch // hp['nminibatches']
+
+    set_global_seeds(0)
+    env = SyntheticVecEnv(args.workload, N, seed=1000 + rank)
+    policy = build_policy(env, hp['network'], value_network=hp['value_network'])
+    model = Model(policy=policy, ob_space=env.observation_space, ac_space=env.action_space, nbatch_act=N,
+                  nbatch_train=nbatch_train, nsteps=T, ent_coef=hp['ent_coef'], vf_coef=0.5, max_grad_norm=0.5,
+                  comm=default_comm(), chunk=args.chunk)
+    runner = Runner(env=env, model=model, nsteps=T, gamma=0.99, lam=0.95, return_host=False)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    # one full iteration fills the rollout (and gives the "full iteration" figure)
+    sync()
+    t0 = time.perf_counter()
+    runner.run()
+    sync()
+    t_rollout = time.perf_counter() - t0
+    ro = runner.rollout
+    last_values = model.value_dev(runner.obs)
+
+    from baselines_amd import ops
+
+    def update():
+        """the PPO2 update (ppo2.py:142 GAE part + :154-166)"""
+        ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
+        inds = np.arange(nbatch)
+        stats = []
+        for _ in range(hp['noptepochs']):
+            np.random.shuffle(inds)
+            inds_dev = torch.from_numpy(inds).to(model.device)
+            for start in range(0, nbatch, nbatch_train):
+                stats.append(model.train_indexed(hp['lr'], hp['cliprange'], ro, inds_dev[start:start + nbatch_train]))
+        return torch.stack(stats).mean(dim=0)
+
+    for _ in range(args.warmup):
+        update()
+    if not args.no_prof:
+        _lib.prof_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lossvals = update()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if not args.no_prof:
+        _lib.prof_enable(False)
+        prof = _lib.prof_report()
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lossvals = lossvals.cpu().numpy()
+    assert np.all(np.isfinite(lossvals)), lossvals
+
+    if rank == 0:
+        value = total_envs * T * args.steps / dt
+        # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
+        roof = None
+        if prof:
+            tot_ms = sum(v['ms'] for v in prof.values())
+            dom = max(prof, key=lambda k: prof[k]['ms'])
+            d = prof[dom]
+            if d['flops'] > 0:
+                ach = d['flops'] / d['count'] / (d['ms'] / d['count'] * 1e-3) / 1e12
+                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                        'launches': d['count'], 'avg_ms': d['ms'] / d['count'],
+                        'share_of_kernel_time': d['ms'] / tot_ms}
+            else:
+                ach = d['bytes'] / d['count'] / (d['ms'] / d['count'] * 1e-3) / 1e9
+                roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'launches': d['count'],
+                        'avg_ms': d['ms'] / d['count'], 'share_of_kernel_time': d['ms'] / tot_ms}
+            gemm_ms = sum(v['ms'] for v in prof.values() if v['flops'] > 0)
+            gemm_fl = sum(v['flops'] for v in prof.values() if v['flops'] > 0)
+            roof['all_gemm_tflops'] = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
+            roof['gemm_share_of_kernel_time'] = gemm_ms / tot_ms
+        out = {
+            'metric': 'env-steps/sec (whole node) PPO2 update, num_envs=%d nsteps=%d' % (total_envs, T),
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ppo2 update-only (GAE + %dx%d minibatch steps) %s-shaped %s num_envs=%d nsteps=%d'
+                                   % (hp['noptepochs'], hp['nminibatches'], args.workload, hp['network'], total_envs, T),
+                       'envs_per_gpu': N, 'nbatch_train_per_gpu': nbatch_train, 'chunk': model.dm.chunk,
+                       'parallelism': 'dp%d (envs sharded, 1 RCCL all-reduce/minibatch)' % world},
+            'model_tflops': flops_per_sample_visit * total_envs * T * hp['noptepochs'] * args.steps / dt / 1e12,
+            'full_iteration_env_steps_per_s': total_envs * T / (t_rollout + dt / args.steps),
+            'rollout_s': t_rollout,
+            'loss': [float(x) for x in lossvals],
+            'roofline': roof,
+        }
+        if prof:
+            out['kernel_ms_per_step'] = {k: round(v['ms'] / args.steps, 3) for k, v in
+                                         sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

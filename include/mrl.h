@@ -116,6 +116,31 @@ int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, 
                        float beta1, float beta2, float eps, float max_grad_norm,
                        float total_weight, float* gnorm_out, void* scratch, void* stream);
 
+/* ---- synthetic device-resident VecEnv (bench/test data source) ----------------------------
+ * Stands where gym environments stand in the reference (common/vec_env/): lock-step stepping with
+ * AUTO-RESET on done (subproc_vec_env.py:8-12) and Monitor-style episode bookkeeping
+ * (bench/monitor.py:58-77).  Dynamics = counter-based integer hash (spec in csrc/envs.hip), bit-
+ * reproducible by the NumPy twin SyntheticVecEnvCPU.  State: ep u32 [N], st i32 [N], ep_ret f32 [N].
+ * step: consumes actions (int32 [N] when discrete, else ignored), advances the state, writes the
+ * NEXT observations (reset obs where done), rewards, dones and, where an episode finished, its
+ * return/length (0 elsewhere; fin_* may both be NULL). */
+int mrl_synth_env_obs(uint32_t seed, int ob_elems, int ob_u8, int N, const uint32_t* ep,
+                      const int32_t* st, void* obs_out, void* stream);
+int mrl_synth_env_step(uint32_t seed, int ob_elems, int ob_u8, int discrete, int reward_kind,
+                       int lmin, int lspan, int N, uint32_t* ep, int32_t* st, float* ep_ret,
+                       const int32_t* actions, void* obs_out, float* rew_out, uint8_t* done_out,
+                       float* fin_r_out, int32_t* fin_l_out, void* stream);
+
+/* ---- optional HIP-event profiler ------------------------------------------------------------
+ * When enabled every kernel launch of the library is bracketed by hipEvents recorded on the launch
+ * stream, accumulated per label ("c1.fwd", "c2.wgrad", "heads", "clip+adam", ...) together with
+ * the ALGORITHMIC flops / bytes of the launch.  Reading a label synchronises.
+ * This is the only process-global state in the library and is off by default. */
+int mrl_prof_enable(int on);           /* on != 0: clear counters and start; 0: stop */
+int mrl_prof_num_labels(void);
+int mrl_prof_get(int i, char* name, int name_cap, long* count, double* total_ms,
+                 double* total_flops, double* total_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,222 @@
+"""GPU: Runner / learn() end to end against the oracle and against the host-env path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo2_numpy as O
+from oracle.ppo2_torch import OracleModel
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(kind, N, seed, device_env):
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv, SyntheticVecEnvCPU
+    return SyntheticVecEnv(kind, N, seed=seed) if device_env else SyntheticVecEnvCPU(kind, N, seed=seed)
+
+
+@pytest.mark.parametrize('kind', ['atari', 'mujoco', 'cartpole'])
+def test_device_env_equals_cpu_twin(kind):
+    """DummyVecEnv-as-oracle pattern of the reference (vec_env/test_vec_env.py:14-44): the device env
+    and its NumPy twin produce identical obs / rewards / dones / episode infos for the same actions."""
+    N = 37
+    dev, cpu = _mk(kind, N, 5, True), _mk(kind, N, 5, False)
+    np.testing.assert_array_equal(dev.reset().cpu().numpy(), cpu.reset())
+    rng = np.random.RandomState(0)
+    for t in range(120):
+        if cpu.discrete:
+            a = rng.randint(0, cpu.action_space.n, N)
+            ad = torch.from_numpy(a.astype(np.int32)).cuda()
+        else:
+            a = rng.randn(N, cpu.action_space.shape[0]).astype(np.float32)
+            ad = torch.from_numpy(a).cuda()
+        o1, r1, d1, i1 = dev.step(ad)
+        o2, r2, d2, i2 = cpu.step(a)
+        np.testing.assert_array_equal(o1.cpu().numpy(), o2)
+        np.testing.assert_array_equal(r1.cpu().numpy(), r2)
+        np.testing.assert_array_equal(d1.cpu().numpy().astype(bool), d2)
+        fl = i1['fin_l'].cpu().numpy()
+        fr = i1['fin_r'].cpu().numpy()
+        for e in range(N):
+            if d2[e]:
+                assert fl[e] == i2[e]['episode']['l'] and fr[e] == np.float32(i2[e]['episode']['r'])
+            else:
+                assert fl[e] == 0 and i2[e] == {}
+
+
+def _models(kind, N, T, nmb, seed=0):
+    from baselines_amd.common import set_global_seeds
+    from baselines_amd.common.policies import build_policy
+    from baselines_amd.ppo2 import Model
+    env = _mk(kind, N, 3, False)
+    net = {'atari': 'cnn', 'mujoco': 'mlp', 'cartpole': 'mlp'}[kind]
+    vn = 'copy' if kind == 'mujoco' else None
+    set_global_seeds(seed)
+    policy = build_policy(env, net, value_network=vn)
+    model = Model(policy=policy, ob_space=env.observation_space, ac_space=env.action_space, nbatch_act=N,
+                  nbatch_train=N * T // nmb, nsteps=T, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+    np.random.seed(seed)     # the oracle draws the same ortho-init stream (a2c/utils.py:20-35)
+    om = OracleModel(network=net, ob_shape=env.observation_space.shape, ob_dtype=env.observation_space.dtype,
+                     pd_kind=model.pd_kind, nact=model.nact, value_network=vn, ent_coef=0.01, vf_coef=0.5,
+                     max_grad_norm=0.5)
+    return model, om
+
+
+@pytest.mark.parametrize('kind', ['cartpole', 'mujoco', 'atari'])
+def test_seeded_init_matches_reference_stream(kind):
+    model, om = _models(kind, 4, 4, 1)
+    np.testing.assert_array_equal(model.get_flat_params(), om.flat_params())
+
+
+class _NoiseModel(object):
+    """wraps our Model so that the Runner's act calls use a recorded noise stream (teacher forcing)"""
+
+    def __init__(self, model, noises):
+        self.m, self.noises, self.t = model, noises, 0
+        self.initial_state = None
+        self.device, self.pd_kind, self.nact = model.device, model.pd_kind, model.nact
+
+    def step_into(self, obs, a, v, nlp):
+        self.m.step_into(obs, a, v, nlp, noise=torch.from_numpy(self.noises[self.t]).cuda())
+        self.t += 1
+
+    def value_dev(self, obs):
+        return self.m.value_dev(obs)
+
+
+@pytest.mark.parametrize('kind,N,T', [('cartpole', 8, 128), ('mujoco', 12, 16), ('atari', 6, 5)])
+def test_runner_device_vs_host_env_vs_oracle(kind, N, T):
+    """Same seeded env, same noise: (a) our Runner on the device env, (b) our Runner on the NumPy twin
+    (host-env path), (c) the reference algorithm restated by the oracle -> identical rollouts;
+    returns bit-exact given the same values."""
+    from baselines_amd.ppo2 import Runner
+    model, om = _models(kind, N, T, 1)
+    rng = np.random.RandomState(4)
+    noises = [(rng.rand(N, model.nact) if model.pd_kind == 'categorical' else rng.randn(N, model.nact)).astype(np.float32)
+              for _ in range(T)]
+    outs = []
+    for device_env in (True, False):
+        env = _mk(kind, N, 11, device_env)
+        r = Runner(env=env, model=_NoiseModel(model, noises), nsteps=T, gamma=0.99, lam=0.95, return_host=True)
+        outs.append(r.run())
+    for a, b in zip(outs[0][:6], outs[1][:6]):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        np.testing.assert_array_equal(a, b)
+    assert outs[0][6] is None
+    assert sorted((e['l'], e['r']) for e in outs[0][7]) == sorted((e['l'], e['r']) for e in outs[1][7])
+    obs, returns, masks, actions, values, neglogpacs = outs[0][:6]
+    assert returns.dtype == np.float32 and masks.dtype == np.bool_ and values.dtype == np.float32
+    assert actions.dtype == (np.int64 if model.pd_kind == 'categorical' else np.float32)
+    # oracle rollout with the reference's loop structure (runner.py:20-67) on the twin
+    env = _mk(kind, N, 11, False)
+    ob = env.reset()
+    dones = np.zeros(N, bool)
+    mb = dict(obs=[], rew=[], act=[], val=[], nlp=[], done=[])
+    for t in range(T):
+        a, v, _, nlp = om.step(ob, noises[t])
+        mb['obs'].append(ob.copy()); mb['act'].append(a); mb['val'].append(v); mb['nlp'].append(nlp)
+        mb['done'].append(dones)
+        ob, rew, dones, _ = env.step(actions.reshape((N, T) + actions.shape[1:]).swapaxes(0, 1)[t])  # teacher-force OUR actions
+        mb['rew'].append(rew)
+    np.testing.assert_array_equal(O.sf01(np.asarray(mb['obs'])), obs)
+    np.testing.assert_array_equal(O.sf01(np.asarray(mb['done'])), masks)
+    if model.pd_kind == 'categorical':
+        assert (O.sf01(np.asarray(mb['act'])) == actions).mean() > 0.98      # argmax ties/rounding aside
+    np.testing.assert_allclose(O.sf01(np.asarray(mb['val'], np.float32)), values, rtol=1e-4, atol=2e-5)
+    # GAE on OUR values must be bit-exact
+    vals_tm = values.reshape(N, T).swapaxes(0, 1)
+    last_v = model.value(ob)
+    ret_o, _ = O.gae(np.asarray(mb['rew'], np.float32), np.ascontiguousarray(vals_tm), np.asarray(mb['done']), last_v,
+                     dones, 0.99, 0.95)
+    np.testing.assert_array_equal(O.sf01(ret_o), returns)
+
+
+@pytest.mark.parametrize('kind,N,T,nmb,nep', [('cartpole', 8, 128, 4, 4), ('mujoco', 16, 32, 4, 2), ('atari', 8, 8, 2, 2)])
+def test_learn_two_updates_match_oracle(kind, N, T, nmb, nep):
+    """ppo2.learn on the device env vs the reference algorithm driven by the oracle model on the
+    teacher-forced rollouts: same minibatch permutations (global NumPy stream), loss stats within
+    1e-5 and parameters after 2 updates within 1e-5."""
+    from baselines_amd import ppo2
+    from baselines_amd.ppo2 import Model
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
+    net = {'atari': 'cnn', 'mujoco': 'mlp', 'cartpole': 'mlp'}[kind]
+    vn = 'copy' if kind == 'mujoco' else None
+    rec = {}
+
+    class RecModel(Model):          # the reference's model_fn plug point (ppo2.py:103-109)
+        def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None):
+            rec.setdefault('calls', []).append(dict(
+                lr=lr, clip=cliprange, idx=idx_dev.cpu().numpy().copy(),
+                fields={k: getattr(rollout, k).cpu().numpy().copy() for k in
+                        ('obs', 'actions', 'returns', 'values', 'neglogpacs')} if len(rec.get('calls', [])) % (nmb * nep) == 0 else None,
+                params_before=self.get_flat_params()))
+            s = super().train_indexed(lr, cliprange, rollout, idx_dev, stats_out)
+            rec['calls'][-1]['stats'] = s.cpu().numpy().copy()
+            return s
+
+    env = SyntheticVecEnv(kind, N, seed=2)
+    updates = []
+    model = ppo2.learn(network=net, env=env, total_timesteps=2 * N * T, seed=0, nsteps=T, nminibatches=nmb,
+                       noptepochs=nep, ent_coef=0.01, lr=lambda f: 3e-4 * f, cliprange=0.2, log_interval=1,
+                       value_network=vn, model_fn=RecModel, update_fn=updates.append)
+    assert updates == [1, 2]
+    calls = rec['calls']
+    assert len(calls) == 2 * nmb * nep
+    # oracle replays: same init (seed 0), then for each recorded minibatch the reference's train()
+    np.random.seed(0)
+    om = OracleModel(network=net, ob_shape=env.observation_space.shape, ob_dtype=env.observation_space.dtype,
+                     pd_kind=model.pd_kind, nact=model.nact, value_network=vn, ent_coef=0.01, vf_coef=0.5,
+                     max_grad_norm=0.5)
+    np.testing.assert_array_equal(calls[0]['params_before'], om.flat_params())
+    fields = None
+    for i, c in enumerate(calls):
+        if c['fields'] is not None:
+            fields = {k: O.sf01(v) for k, v in c['fields'].items()}
+        assert c['lr'] == 3e-4 * (1.0 - (i // (nmb * nep)) / 2.0)       # ppo2.py:133-135 schedule
+        idx = c['idx']
+        so = om.train(c['lr'], c['clip'], fields['obs'][idx], fields['returns'][idx], None, fields['actions'][idx],
+                      fields['values'][idx], fields['neglogpacs'][idx])
+        np.testing.assert_allclose(c['stats'], so, rtol=1e-4, atol=1e-5)
+    # permutations: exactly the reference's stream (set_global_seeds(0) -> ortho draws -> shuffles)
+    assert sorted(np.concatenate([c['idx'] for c in calls[:nmb]]).tolist()) == list(range(N * T))
+    np.testing.assert_allclose(model.get_flat_params(), om.flat_params(), rtol=0, atol=1e-5)
+
+
+def test_model_train_reference_signature_and_save_load(tmp_path):
+    """model.train(lr, cliprange, obs, returns, masks, actions, values, neglogpacs) with host arrays
+    == train_indexed on the device rollout; save/load round trip in the reference's joblib format."""
+    from baselines_amd.ppo2 import Runner
+    model, om = _models('cartpole', 8, 16, 1)
+    model2, _ = _models('cartpole', 8, 16, 1)
+    env = _mk('cartpole', 8, 1, True)
+    r = Runner(env=env, model=model, nsteps=16, gamma=0.99, lam=0.95, return_host=True)
+    obs, returns, masks, actions, values, neglogpacs, _, _ = r.run()
+    idx = np.random.RandomState(0).permutation(128)[:64]
+    s1 = model.train(1e-3, 0.2, obs[idx], returns[idx], masks[idx], actions[idx], values[idx], neglogpacs[idx])
+    s2 = model2.train_indexed(1e-3, 0.2, r.rollout, torch.from_numpy(idx).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(np.float32(s1), s2)
+    np.testing.assert_array_equal(model.get_flat_params(), model2.get_flat_params())
+    assert model.loss_names == ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+    path = str(tmp_path / 'ckpt' / '00001')
+    model.save(path)
+    import joblib
+    d = joblib.load(path)
+    assert 'ppo2_model/pi/mlp_fc0/w:0' in d and 'ppo2_model/pi/mlp_fc0/w/Adam_1:0' in d and 'beta1_power:0' in d
+    assert d['ppo2_model/pi/mlp_fc0/w:0'].shape == (4, 64) and d['ppo2_model/vf/w:0'].shape == (64, 1)
+    model3, _ = _models('cartpole', 8, 16, 1, seed=5)
+    model3.load(path)
+    np.testing.assert_array_equal(model3.get_flat_params(), model.get_flat_params())
+    np.testing.assert_array_equal(model3.adam_v.cpu().numpy(), model.adam_v.cpu().numpy())
+    assert model3.beta1_power == model.beta1_power
+
+
+def test_total_timesteps_zero_builds_model_only():
+    """ppo2.py:128-129: total_timesteps=0 -> zero updates (used by the reference's tests to build/load)"""
+    from baselines_amd import ppo2
+    env = _mk('cartpole', 4, 0, True)
+    model = ppo2.learn(network='mlp', env=env, total_timesteps=0, seed=1, nsteps=8)
+    a, v, s, nlp = model.step(np.zeros((4, 4), np.float32))
+    assert a.shape == (4,) and a.dtype == np.int64 and v.shape == (4,) and s is None and nlp.shape == (4,)
+    with pytest.raises(ValueError):
+        ppo2.learn(network='lstm', env=env, total_timesteps=0)
