@@ -39,7 +39,7 @@ SIGNATURES = {
     'mrl_model_num_params': (c_long, [c_void_p]),
     'mrl_model_num_tensors': (c_int, [c_void_p]),
     'mrl_model_tensor_info': (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int),
-                                      ctypes.POINTER(c_int * 4), ctypes.POINTER(c_long), ctypes.POINTER(c_float)]),
+                                      ctypes.POINTER(c_int * 4), ctypes.POINTER(c_long), ctypes.POINTER(c_double)]),
     'mrl_model_workspace_bytes': (c_size_t, [c_void_p, c_int]),
     'mrl_model_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_int, c_void_p]),

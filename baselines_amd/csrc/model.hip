@@ -43,7 +43,7 @@ struct TensorInfo {
     int ndim;
     int shape[4];
     long off;
-    float scale;   // <0: zeros
+    double scale;  // <0: zeros
 };
 
 struct mrl_model {
@@ -59,7 +59,7 @@ struct mrl_model {
     std::vector<TensorInfo> tensors;
 };
 
-static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> shape, float scale) {
+static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> shape, double scale) {
     TensorInfo t;
     t.name = name;
     t.ndim = (int)shape.size();
@@ -77,7 +77,7 @@ static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> s
 
 static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
     const mrl_model_desc& d = m->d;
-    const float s2 = sqrtf(2.f);
+    const double s2 = sqrt(2.0);   // a2c/utils.py callers pass init_scale=np.sqrt(2) (f64)
     if (d.network == MRL_NET_NATURE_CNN) {
         if (d.ob_ndim != 3 || d.ob_dtype != MRL_OB_U8 || d.ob_shape[2] % 4 != 0) return MRL_EUNSUP;
         int H = d.ob_shape[0], W = d.ob_shape[1], C = d.ob_shape[2];
@@ -91,7 +91,7 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
             l.OW = (W - rf[i]) / st[i] + 1;
             l.K = rf[i] * rf[i] * C; l.N = nf[i]; l.act = ACT_RELU;
             l.w_off = add_tensor(m, prefix + "/" + nm[i] + "/w", {rf[i], rf[i], C, nf[i]}, s2);
-            l.b_off = add_tensor(m, prefix + "/" + nm[i] + "/b", {1, nf[i], 1, 1}, -1.f);
+            l.b_off = add_tensor(m, prefix + "/" + nm[i] + "/b", {1, nf[i], 1, 1}, -1.0);
             l.out_elems = (long)l.OH * l.OW * l.NF;
             snprintf(l.name, sizeof l.name, "%s", nm[i]);
             net.L.push_back(l);
@@ -100,7 +100,7 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
         Layer f{};
         f.kind = 1; f.K = H * W * C; f.N = 512; f.act = ACT_RELU;
         f.w_off = add_tensor(m, prefix + "/fc1/w", {f.K, f.N}, s2);
-        f.b_off = add_tensor(m, prefix + "/fc1/b", {f.N}, -1.f);
+        f.b_off = add_tensor(m, prefix + "/fc1/b", {f.N}, -1.0);
         f.out_elems = f.N;
         snprintf(f.name, sizeof f.name, "fc1");
         net.L.push_back(f);
@@ -115,7 +115,7 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
             char nm[32];
             snprintf(nm, sizeof nm, "/mlp_fc%d", i);
             f.w_off = add_tensor(m, prefix + nm + "/w", {f.K, f.N}, s2);
-            f.b_off = add_tensor(m, prefix + nm + "/b", {f.N}, -1.f);
+            f.b_off = add_tensor(m, prefix + nm + "/b", {f.N}, -1.0);
             f.out_elems = f.N;
             snprintf(f.name, sizeof f.name, "mlp_fc%d", i);
             net.L.push_back(f);
@@ -145,12 +145,12 @@ extern "C" int mrl_model_create(const mrl_model_desc* desc, mrl_model** out) {
     m->has_pi_head = (nlat != desc->nact);   // distributions.py:351-355
     m->pi_w = m->pi_b = m->logstd = -1;
     if (m->has_pi_head) {
-        m->pi_w = add_tensor(m, "ppo2_model/pi/w", {nlat, desc->nact}, 0.01f);
-        m->pi_b = add_tensor(m, "ppo2_model/pi/b", {desc->nact}, -1.f);
+        m->pi_w = add_tensor(m, "ppo2_model/pi/w", {nlat, desc->nact}, 0.01);
+        m->pi_b = add_tensor(m, "ppo2_model/pi/b", {desc->nact}, -1.0);
     }
-    if (desc->pd_kind == MRL_PD_DIAG_GAUSSIAN) m->logstd = add_tensor(m, "ppo2_model/pi/logstd", {1, desc->nact}, -1.f);
-    m->vf_w = add_tensor(m, "ppo2_model/vf/w", {nlatv, 1}, 1.0f);
-    m->vf_b = add_tensor(m, "ppo2_model/vf/b", {1}, -1.f);
+    if (desc->pd_kind == MRL_PD_DIAG_GAUSSIAN) m->logstd = add_tensor(m, "ppo2_model/pi/logstd", {1, desc->nact}, -1.0);
+    m->vf_w = add_tensor(m, "ppo2_model/vf/w", {nlatv, 1}, 1.0);
+    m->vf_b = add_tensor(m, "ppo2_model/vf/b", {1}, -1.0);
     m->HP = (int)(m->P - m->head_off);
     *out = m;
     return 0;
@@ -161,7 +161,7 @@ extern "C" long mrl_model_num_params(const mrl_model* m) { return m ? m->P : 0; 
 extern "C" int mrl_model_num_tensors(const mrl_model* m) { return m ? (int)m->tensors.size() : 0; }
 
 extern "C" int mrl_model_tensor_info(const mrl_model* m, int i, char* name, int name_cap, int* ndim, int shape[4],
-                                     long* offset, float* init_scale) {
+                                     long* offset, double* init_scale) {
     if (!m || i < 0 || i >= (int)m->tensors.size()) return MRL_EINVAL;
     const TensorInfo& t = m->tensors[i];
     if (name && name_cap > 0) {

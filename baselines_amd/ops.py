@@ -106,7 +106,7 @@ class DeviceModel(object):
         self.tensors = []
         name = ctypes.create_string_buffer(128)
         for i in range(lib.mrl_model_num_tensors(h)):
-            nd, shp, off, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_float()
+            nd, shp, off, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_double()
             check(lib.mrl_model_tensor_info(h, i, name, 128, ctypes.byref(nd), ctypes.byref(shp), ctypes.byref(off),
                                             ctypes.byref(sc)), 'mrl_model_tensor_info')
             shape = tuple(shp[k] for k in range(nd.value))

@@ -77,9 +77,10 @@ void mrl_model_destroy(mrl_model* m);
 long mrl_model_num_params(const mrl_model* m);          /* P (floats) */
 int  mrl_model_num_tensors(const mrl_model* m);
 /* tensor i in TF variable-creation order: name (e.g. "ppo2_model/pi/c1/w"),
- * shape (<=4 dims, TF shapes incl. conv bias [1,nf,1,1]), flat offset, init scale (<0: zeros). */
+ * shape (<=4 dims, TF shapes incl. conv bias [1,nf,1,1]), flat offset, orthogonal-init scale as the
+ * f64 the reference multiplies with (np.sqrt(2), 0.01, 1.0; <0: zeros). */
 int  mrl_model_tensor_info(const mrl_model* m, int i, char* name, int name_cap, int* ndim,
-                           int shape[4], long* offset, float* init_scale);
+                           int shape[4], long* offset, double* init_scale);
 /* workspace bytes needed to process `chunk` samples at a time (forward+backward). */
 size_t mrl_model_workspace_bytes(const mrl_model* m, int chunk);
 
