@@ -53,6 +53,7 @@ SIGNATURES = {
     'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    'mrl_tune_set': (c_int, [c_char_p, c_int]),
     'mrl_prof_enable': (c_int, [c_int]),
     'mrl_prof_num_labels': (c_int, []),
     'mrl_prof_get': (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_double),
@@ -145,3 +146,8 @@ def prof_report():
         if cnt.value:
             out[name.value.decode()] = dict(count=cnt.value, ms=ms.value, flops=fl.value, bytes=by.value)
     return out
+
+
+def tune_set(label, variant):
+    """Override the GEMM tile variant of one launch site ("c1.fwd", ...); variant < 0 restores the default."""
+    check(load().mrl_tune_set(label.encode(), int(variant)), 'mrl_tune_set')

@@ -5,19 +5,26 @@
 //
 // One kernel serves every dense op of the PPO2 learner (reference: TF ops reached from
 // baselines/a2c/utils.py:37-63 `conv`/`fc` and their tf.gradients): conv forward (im2col
-// addressing done in the A loader), conv data-gradient (gather form), conv/fc weight-gradient
-// (split-K over the batch*pixels dimension), fc forward / data-gradient.  Operands are described
-// by loader functors so gather (minibatch indices, ppo2.py:162-164), u8->f32 /255
-// (models.py:19) and im2col never materialise in HBM; results leave through epilogue functors
-// (bias+activation, activation-derivative masking, split-K partial slabs).
+// addressing done in the A loader), conv data-gradient (gather form per stride-parity class),
+// conv/fc weight-gradient (split-K over the batch*pixels dimension, bias gradient folded in),
+// fc forward / data-gradient.  Operands are described by loader functors so the minibatch gather
+// (ppo2.py:162-164), u8->f32 /255 (models.py:19) and im2col never materialise in HBM; results
+// leave through epilogue functors (bias+activation, activation-derivative masking, split-K slabs).
 //
-// Tiling: 256 threads = 4 waves (WM x WN), each wave TM x TN tiles of 32x32; BK = 32.
-// LDS images: "KC" operand (k contiguous in memory) -> S[row][36] read with ds_read_b128
-// (row stride 36 floats = conflict-free for the 16-lane b128 groups); "MC" operand (row
-// contiguous in memory) -> S[k][rows+4] read with ds_read_b32.  Within every K-block of 8 the
-// MFMA step s (0..3) of half-wave h consumes k = 8*kb + 4*h + s on BOTH operands, so a KC
-// operand needs one b128 per 4 MFMAs.  Next tile's global loads are issued before the MFMA
-// block and written to LDS after it (register-staged software pipeline).
+// Structure (MI355X-first):
+//   * 256 threads = 4 waves (WM x WN), one per SIMD; each wave owns TM x TN tiles of 32x32; BK = 32.
+//   * every loader keeps PER-THREAD STATE (row bases computed once, the k decomposition advanced
+//     incrementally) so the K loop issues ~1 address add per 16-byte load instead of integer
+//     divisions: at 64 cycles per fp32 MFMA the VALU budget is ~16 issue slots per MFMA and the
+//     im2col index math was what bound the first version of this kernel.
+//   * LDS is double buffered (one s_barrier per K tile); the next tile's global loads are issued
+//     before the MFMA block and land in LDS after it (register-staged software pipeline).
+//   * LDS images: "KC" operand (k contiguous in memory) -> S[row][36], fragments read with
+//     ds_read_b128 (row stride 36 floats: conflict-free for the 16-lane b128 groups); "MC" operand
+//     (row contiguous in memory) -> S[k][rows+4], fragments read with 4 ds_read_b32.  Within every
+//     K-block of 8 the MFMA step s (0..3) of half-wave h consumes k = 8*kb + 4*h + s on BOTH operands.
+//   * blockIdx -> tile mapping is XCD-aware: block b runs on XCD b%8, so the N-tiles that share an
+//     A row-panel are given consecutive slots on the SAME XCD (shared L2) instead of round-robin.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,125 +50,208 @@ __device__ __forceinline__ float act_bwd_from_out(float h, int act) {
     return 1.f;
 }
 
+// exact unsigned 32-bit division by a runtime constant (Granlund-Montgomery): 4 VALU ops.
+struct FastDiv {
+    uint32_t m, s1, s2, d;
+    static FastDiv make(uint32_t d) {
+        FastDiv f;
+        f.d = d;
+        uint32_t L = 0;
+        while ((1ull << L) < d) ++L;
+        f.m = (uint32_t)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+        f.s1 = L < 1 ? L : 1;
+        f.s2 = L < 1 ? 0 : L - 1;
+        return f;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+};
+
+// uint8 pixel -> float(x)/255.f, bit-exact with the IEEE division for all 256 inputs
+// (q = x*r; one Newton correction), 3 VALU ops instead of the ~10 of a true divide.
+__device__ __forceinline__ float u8_over_255(float x) {
+    const float r = 1.f / 255.f;
+    float q = __fmul_rn(x, r);
+    float e = __fmaf_rn(-q, 255.f, x);
+    return __fmaf_rn(e, r, q);
+}
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 load_partial(const float* q, int nvalid) {
+    float4 v = f4zero();
+    if (nvalid > 0) v.x = q[0];
+    if (nvalid > 1) v.y = q[1];
+    if (nvalid > 2) v.z = q[2];
+    if (nvalid > 3) v.w = q[3];
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
-// Loader functors.  Interface:
-//   static constexpr bool KC;            // true: 4 consecutive k for one row; false: 4 consecutive rows for one k
-//   float4 load(int row, int k, int z)   // zero-filled outside [0,rows) x [0,kmax)
+// Loader functors.  Interface (NV = float4 staged per thread per K tile = tile_rows / 32):
+//   static constexpr bool KC;     true : a thread stages 4 consecutive k of NV rows
+//                                        (row = r0 + p*32 + tid/8, k = k0 + (tid%8)*4)
+//                                 false: a thread stages 4 consecutive rows of NV k-lines
+//                                        (rows r0 + (tid%V4)*4.., k = k0 + p*LPP + tid/V4; V4 = 8*NV, LPP = 32/NV)
+//   template<int NV> struct State;
+//   init(State&, r0, k0, z, tid)      once per workgroup tile
+//   fetch(State&, float4 (&v)[NV])    loads the current K tile (zero-filled outside the operand)
+//                                     and advances the state by GEMM_BK
+// Rows beyond the operand are clamped / zeroed: they only feed C rows/columns that are never stored.
 // ------------------------------------------------------------------------------------------
 
-// Dense row-major matrix P[row*ld + k], k contiguous.
+// Dense row-major operand P[row*ld + k] (k contiguous), optionally row-gathered through srow
+// (minibatch gather of f32 observations: element (b, k) = obs[srow[b]*ld + k]).
 struct RowKC {
     static constexpr bool KC = true;
-    const float* p; long ld; int rows; int kmax; int vec;
-    __device__ __forceinline__ float4 load(int row, int k, int) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= rows || k >= kmax) return v;
-        const float* q = p + (long)row * ld + k;
-        if (vec && k + 3 < kmax) return *reinterpret_cast<const float4*>(q);
-        v.x = q[0];
-        if (k + 1 < kmax) v.y = q[1];
-        if (k + 2 < kmax) v.z = q[2];
-        if (k + 3 < kmax) v.w = q[3];
-        return v;
+    const float* p; long ld; int rows; int kmax; int vec; const int32_t* srow;
+    template <int NV> struct State { const float* q[NV]; int k; };
+    template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
+        s.k = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int row = min(r0 + i * 32 + (tid >> 3), rows - 1);
+            long sr = srow ? (long)srow[row] : (long)row;
+            s.q[i] = p + sr * ld + s.k;
+        }
+    }
+    template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
+        if (vec && s.k + 3 < kmax) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(s.q[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = load_partial(s.q[i], kmax - s.k);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s.q[i] += GEMM_BK;
+        s.k += GEMM_BK;
     }
 };
 
-// Dense matrix P[k*ld + row], row contiguous (the GEMM "k" is the slow index).
+// Dense operand P[k*ld + row] (row contiguous; the GEMM k is the slow index), optionally k-gathered
+// through srow (weight-gradient view of gathered f32 observations: GEMM k = sample).
 struct RowMC {
     static constexpr bool KC = false;
-    const float* p; long ld; int rows; int kmax; int vec;
-    __device__ __forceinline__ float4 load(int row, int k, int) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= rows || k >= kmax) return v;
-        const float* q = p + (long)k * ld + row;
-        if (vec && row + 3 < rows) return *reinterpret_cast<const float4*>(q);
-        v.x = q[0];
-        if (row + 1 < rows) v.y = q[1];
-        if (row + 2 < rows) v.z = q[2];
-        if (row + 3 < rows) v.w = q[3];
-        return v;
+    const float* p; long ld; int rows; int kmax; int vec; const int32_t* srow;
+    template <int NV> struct State { const float* q; int k; int nrow; };
+    template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
+        constexpr int V4 = NV * 8;
+        int row = r0 + (tid % V4) * 4;
+        s.nrow = max(0, min(4, rows - row));
+        s.k = k0 + tid / V4;
+        s.q = p + row + (srow ? 0 : (long)s.k * ld);
     }
-};
-
-// Minibatch-gathered observation rows (f32), KC: element (b, k) = obs[srow(b)*ld + k].
-// idx holds the reference's env-major flat index i = e*T + t (runner.py:69-74); storage is
-// time-major [T][N] so srow = (i % T) * N + i / T.  idx == nullptr: srow = b.
-struct GatherRowsBase {
-    const float* p; long ld; const int64_t* idx; int T; int N; int rows; int kmax; int vec;
-    __device__ __forceinline__ long srow(int b) const {
-        if (!idx) return b;
-        long i = idx[b];
-        return (i % T) * (long)N + i / T;
-    }
-};
-struct GatherKC : GatherRowsBase {
-    static constexpr bool KC = true;
-    __device__ __forceinline__ float4 load(int row, int k, int) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= rows || k >= kmax) return v;
-        const float* q = p + srow(row) * ld + k;
-        if (vec && k + 3 < kmax) return *reinterpret_cast<const float4*>(q);
-        v.x = q[0];
-        if (k + 1 < kmax) v.y = q[1];
-        if (k + 2 < kmax) v.z = q[2];
-        if (k + 3 < kmax) v.w = q[3];
-        return v;
-    }
-};
-// Same data seen as the A' operand of a weight-gradient GEMM: GEMM row = feature (contiguous),
-// GEMM k = sample b.
-struct GatherMC : GatherRowsBase {
-    static constexpr bool KC = false;
-    __device__ __forceinline__ float4 load(int row, int k, int) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= kmax || k >= rows) return v;   // here: rows = #samples (GEMM k), kmax = #features (GEMM rows)
-        const float* q = p + srow(k) * ld + row;
-        if (vec && row + 3 < kmax) return *reinterpret_cast<const float4*>(q);
-        v.x = q[0];
-        if (row + 1 < kmax) v.y = q[1];
-        if (row + 2 < kmax) v.z = q[2];
-        if (row + 3 < kmax) v.w = q[3];
-        return v;
+    template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
+        constexpr int LPP = 32 / NV;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int k = s.k + i * LPP;
+            v[i] = f4zero();
+            if (k < kmax && s.nrow > 0) {
+                const float* q = srow ? s.q + (long)srow[k] * ld : s.q + (long)(i * LPP) * ld;
+                if (vec && s.nrow == 4) v[i] = *reinterpret_cast<const float4*>(q);
+                else v[i] = load_partial(q, s.nrow);
+            }
+        }
+        if (!srow) s.q += (long)GEMM_BK * ld;
+        s.k += GEMM_BK;
     }
 };
 
 // im2col view of an NHWC image batch (VALID padding): pixel m = (b, oy, ox), conv-k = (ky, kx, c);
 // 4 consecutive conv-k never straddle a patch row because C % 4 == 0.
-// U8: input is uint8 and is scaled by /255 on load (models.py:19), optionally gathered through idx.
-template <bool U8>
-struct ConvPatch {
+// U8: input is uint8 and is scaled by /255 on load (models.py:19); srow (optional) gathers images.
+struct ConvGeom {
     const void* p; int H, W, C, rf, stride, OH, OW; int npix; int kconv;   // npix = B*OH*OW, kconv = rf*rf*C
-    const int64_t* idx; int T; int N;
-    __device__ __forceinline__ float4 at(int m, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m >= npix || k >= kconv) return v;
-        int ohw = OH * OW;
-        int b = m / ohw, r = m - b * ohw;
-        int oy = r / OW, ox = r - oy * OW;
-        int rowk = rf * C;
-        int ky = k / rowk, kr = k - ky * rowk;
-        long img = b;
-        if (idx) { long i = idx[b]; img = (i % T) * (long)N + i / T; }
-        long off = ((img * H + (oy * stride + ky)) * W + ox * stride) * C + kr;
-        if (U8) {
-            uint32_t u = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p) + off);
-            v.x = (float)(u & 0xff) / 255.f;
-            v.y = (float)((u >> 8) & 0xff) / 255.f;
-            v.z = (float)((u >> 16) & 0xff) / 255.f;
-            v.w = (float)(u >> 24) / 255.f;
-            return v;
-        } else {
-            return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + off);
-        }
+    int rowk;                                                              // rf*C
+    const int32_t* srow;
+    FastDiv d_ohw, d_ow, d_rowk;
+    void finish() {
+        rowk = rf * C;
+        d_ohw = FastDiv::make(OH * OW); d_ow = FastDiv::make(OW); d_rowk = FastDiv::make(rowk);
     }
 };
-template <bool U8> struct ConvPatchKC : ConvPatch<U8> {   // forward: GEMM row = pixel, GEMM k = conv-k
+template <bool U8> __device__ __forceinline__ float4 conv_ld(const void* p, long off) {
+    if (U8) {
+        uint32_t u = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p) + off);
+        float4 v;
+        v.x = u8_over_255((float)(u & 0xff));
+        v.y = u8_over_255((float)((u >> 8) & 0xff));
+        v.z = u8_over_255((float)((u >> 16) & 0xff));
+        v.w = u8_over_255((float)(u >> 24));
+        return v;
+    } else {
+        return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + off);
+    }
+}
+template <bool U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixel, GEMM k = conv-k
     static constexpr bool KC = true;
-    __device__ __forceinline__ float4 load(int row, int k, int) const { return this->at(row, k); }
+    template <int NV> struct State { long base[NV]; int k, ky, kr; };
+    template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
+        s.k = k0 + (tid & 7) * 4;
+        s.ky = (int)d_rowk.div((uint32_t)s.k);
+        s.kr = s.k - s.ky * rowk;
+        const int ohw = OH * OW;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int m = min(r0 + i * 32 + (tid >> 3), npix - 1);
+            int b = (int)d_ohw.div((uint32_t)m), r = m - b * ohw;
+            int oy = (int)d_ow.div((uint32_t)r), ox = r - oy * OW;
+            long img = srow ? (long)srow[b] : (long)b;
+            s.base[i] = ((img * H + oy * stride) * W + ox * stride) * C;
+        }
+    }
+    template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
+        const long koff = (long)s.ky * W * C + s.kr;
+        if (s.k < kconv) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = conv_ld<U8>(p, s.base[i] + koff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = f4zero();
+        }
+        s.k += GEMM_BK;
+        s.kr += GEMM_BK;
+        while (s.kr >= rowk) { s.kr -= rowk; ++s.ky; }
+    }
 };
-template <bool U8> struct ConvPatchMC : ConvPatch<U8> {   // wgrad: GEMM row = conv-k, GEMM k = pixel
+template <bool U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k, GEMM k = pixel
     static constexpr bool KC = false;
-    __device__ __forceinline__ float4 load(int row, int k, int) const { return this->at(k, row); }
+    template <int NV> struct State { long koff; int m; int b[NV]; int r[NV]; bool rvalid; };
+    template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
+        constexpr int V4 = NV * 8, LPP = 32 / NV;
+        int row = r0 + (tid % V4) * 4;
+        s.rvalid = row < kconv;                       // kconv % 4 == 0: all four or none
+        int rc = min(row, kconv - 4);
+        int ky = (int)d_rowk.div((uint32_t)rc), kr = rc - ky * rowk;
+        s.koff = (long)ky * W * C + kr;
+        s.m = k0 + tid / V4;
+        const int ohw = OH * OW;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int m = s.m + i * LPP;
+            s.b[i] = (int)d_ohw.div((uint32_t)m);
+            s.r[i] = m - s.b[i] * ohw;
+        }
+    }
+    template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
+        constexpr int LPP = 32 / NV;
+        const int ohw = OH * OW;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = f4zero();
+            if (s.rvalid && s.m + i * LPP < npix) {
+                int oy = (int)d_ow.div((uint32_t)s.r[i]), ox = s.r[i] - oy * OW;
+                long img = srow ? (long)srow[s.b[i]] : (long)s.b[i];
+                v[i] = conv_ld<U8>(p, ((img * H + oy * stride) * W + ox * stride) * C + s.koff);
+            }
+            s.r[i] += GEMM_BK;
+            while (s.r[i] >= ohw) { s.r[i] -= ohw; ++s.b[i]; }
+        }
+        s.m += GEMM_BK;
+    }
 };
 
 // Data-gradient (gather form) of a VALID strided conv.  Input pixels are enumerated per stride
@@ -171,35 +261,83 @@ struct DgradGeom {
     int H, W, C, rf, stride, OH, OW, NF, taps;   // taps per dim = ceil(rf/stride)
     int HY, WX;                                   // class grid extents: ceil(H/stride), ceil(W/stride)
     int B;
+    FastDiv d_per, d_wx, d_nf, d_taps;
+    void finish() {
+        d_per = FastDiv::make(HY * WX); d_wx = FastDiv::make(WX); d_nf = FastDiv::make(NF); d_taps = FastDiv::make(taps);
+    }
 };
+struct DgradKState { int k, n, a, b2; };
+__device__ __forceinline__ void dgrad_k_init(const DgradGeom& g, DgradKState& s, int k) {
+    s.k = k;
+    int tap = (int)g.d_nf.div((uint32_t)k);
+    s.n = k - tap * g.NF;
+    s.a = (int)g.d_taps.div((uint32_t)tap);
+    s.b2 = tap - s.a * g.taps;
+}
+__device__ __forceinline__ void dgrad_k_advance(const DgradGeom& g, DgradKState& s) {
+    s.k += GEMM_BK;
+    s.n += GEMM_BK;
+    while (s.n >= g.NF) {
+        s.n -= g.NF;
+        if (++s.b2 == g.taps) { s.b2 = 0; ++s.a; }
+    }
+}
 struct DgradA : DgradGeom {   // KC over n
     static constexpr bool KC = true;
     const float* dz;            // [B, OH, OW, NF]
-    __device__ __forceinline__ float4 load(int row, int k, int z) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int per = HY * WX;
-        if (row >= B * per || k >= taps * taps * NF) return v;
-        int b = row / per, r = row - b * per;
-        int yy = r / WX, xx = r - yy * WX;
-        int tap = k / NF, n = k - tap * NF;
-        int a = tap / taps, b2 = tap - a * taps;
-        int oy = yy - a, ox = xx - b2;
-        if (oy < 0 || oy >= OH || ox < 0 || ox >= OW) return v;
-        return *reinterpret_cast<const float4*>(dz + ((long)(b * OH + oy) * OW + ox) * NF + n);
+    template <int NV> struct State { DgradKState ks; int pb[NV], yy[NV], xx[NV]; };
+    template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
+        dgrad_k_init(*this, s.ks, k0 + (tid & 7) * 4);
+        const int per = HY * WX;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int m = r0 + i * 32 + (tid >> 3);
+            if (m < B * per) {
+                int b = (int)d_per.div((uint32_t)m), r = m - b * per;
+                s.yy[i] = (int)d_wx.div((uint32_t)r);
+                s.xx[i] = r - s.yy[i] * WX;
+                s.pb[i] = b * OH * OW;
+            } else {
+                s.yy[i] = -0x10000; s.xx[i] = 0; s.pb[i] = 0;   // never in range
+            }
+        }
+    }
+    template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
+        const bool kv = s.ks.k < taps * taps * NF;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int oy = s.yy[i] - s.ks.a, ox = s.xx[i] - s.ks.b2;
+            v[i] = f4zero();
+            if (kv && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW)
+                v[i] = *reinterpret_cast<const float4*>(dz + (long)(s.pb[i] + oy * OW + ox) * NF + s.ks.n);
+        }
+        dgrad_k_advance(*this, s.ks);
     }
 };
 struct DgradB : DgradGeom {   // GEMM row = input channel c, KC over n;  W is HWIO [ky][kx][c][n]
     static constexpr bool KC = true;
     const float* w;
-    __device__ __forceinline__ float4 load(int row, int k, int z) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= C || k >= taps * taps * NF) return v;
-        int py = z / stride, px = z - py * stride;
-        int tap = k / NF, n = k - tap * NF;
-        int a = tap / taps, b2 = tap - a * taps;
-        int ky = py + stride * a, kx = px + stride * b2;
-        if (ky >= rf || kx >= rf) return v;
-        return *reinterpret_cast<const float4*>(w + ((long)(ky * rf + kx) * C + row) * NF + n);
+    template <int NV> struct State { DgradKState ks; int c[NV]; int py, px; };
+    template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int z, int tid) const {
+        dgrad_k_init(*this, s.ks, k0 + (tid & 7) * 4);
+        s.py = z / stride;
+        s.px = z - s.py * stride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = r0 + i * 32 + (tid >> 3);
+            s.c[i] = c < C ? c : -1;
+        }
+    }
+    template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
+        const int ky = s.py + stride * s.ks.a, kx = s.px + stride * s.ks.b2;
+        const bool kv = s.ks.k < taps * taps * NF && ky < rf && kx < rf;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = f4zero();
+            if (kv && s.c[i] >= 0)
+                v[i] = *reinterpret_cast<const float4*>(w + ((long)(ky * rf + kx) * C + s.c[i]) * NF + s.ks.n);
+        }
+        dgrad_k_advance(*this, s.ks);
     }
 };
 
@@ -207,12 +345,14 @@ struct DgradB : DgradGeom {   // GEMM row = input channel c, KC over n;  W is HW
 // Epilogue functors:  void store(int m, int n, float acc, int z)
 // ------------------------------------------------------------------------------------------
 struct EpiBiasAct {       // out[m*ld + n] = act(acc + bias[n])
+    static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* bias; int act;
     __device__ __forceinline__ void store(int m, int n, float acc, int) const {
         out[(long)m * ld + n] = act_fwd(acc + bias[n], act);
     }
 };
 struct EpiMaskAct {       // out[m*ld + n] = acc * act'(h[m*ld + n])      (fc data-gradient)
+    static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* h; int act;
     __device__ __forceinline__ void store(int m, int n, float acc, int) const {
         long o = (long)m * ld + n;
@@ -220,11 +360,12 @@ struct EpiMaskAct {       // out[m*ld + n] = acc * act'(h[m*ld + n])      (fc da
     }
 };
 struct EpiDgradConv : DgradGeom {   // scatter rows of class z back to NHWC, masked by act'(h_prev)
+    static constexpr bool HAS_BIAS = false;
     float* out; const float* h; int act;
     __device__ __forceinline__ void store(int m, int n, float acc, int z) const {
-        int per = HY * WX;
-        int b = m / per, r = m - b * per;
-        int yy = r / WX, xx = r - yy * WX;
+        const int per = HY * WX;
+        int b = (int)d_per.div((uint32_t)m), r = m - b * per;
+        int yy = (int)d_wx.div((uint32_t)r), xx = r - yy * WX;
         int py = z / stride, px = z - py * stride;
         int iy = yy * stride + py, ix = xx * stride + px;
         if (iy >= H || ix >= W) return;
@@ -232,32 +373,27 @@ struct EpiDgradConv : DgradGeom {   // scatter rows of class z back to NHWC, mas
         out[o] = acc * act_bwd_from_out(h[o], act);
     }
 };
-struct EpiPartial {       // split-K slab: part[z][m*N + n] = acc
-    float* part; long slab; int N;
+// split-K slab of a weight-gradient GEMM: part[z][m*N + n] = acc, followed (same slab) by the bias
+// gradient part[z][M*N + n] = sum over this split's rows of dz[row][n] (the B operand's column sums).
+struct EpiPartial {
+    static constexpr bool HAS_BIAS = true;
+    float* part; long slab; int N; long bias_off;
     __device__ __forceinline__ void store(int m, int n, float acc, int z) const {
         part[(long)z * slab + (long)m * N + n] = acc;
+    }
+    __device__ __forceinline__ void store_bias(int n, float acc, int z) const {
+        part[(long)z * slab + bias_off + n] = acc;
     }
 };
 
 // ------------------------------------------------------------------------------------------
 template <class F, int R>
 struct Stage {
-    // number of float4 a thread stages per tile
-    static constexpr int NV = R / 32;
+    static constexpr int NV = R / 32;                    // float4 a thread stages per tile
     // KC image: [R][LDK];  MC image: [BK][R+4]
     static constexpr int ELEMS = F::KC ? R * GEMM_LDK : GEMM_BK * (R + 4);
+    using State = typename F::template State<NV>;
 
-    __device__ static __forceinline__ void gload(const F& f, float4 (&v)[NV], int r0, int k0, int z, int tid) {
-        if (F::KC) {
-#pragma unroll
-            for (int p = 0; p < NV; ++p) v[p] = f.load(r0 + p * 32 + (tid >> 3), k0 + (tid & 7) * 4, z);
-        } else {
-            constexpr int V4 = R / 4;            // float4 per k-line
-            constexpr int LPP = 256 / V4;        // k-lines per pass
-#pragma unroll
-            for (int p = 0; p < NV; ++p) v[p] = f.load(r0 + (tid % V4) * 4, k0 + p * LPP + tid / V4, z);
-        }
-    }
     __device__ static __forceinline__ void swrite(float* s, const float4 (&v)[NV], int tid) {
         if (F::KC) {
 #pragma unroll
@@ -283,21 +419,27 @@ struct Stage {
 };
 
 template <class AF, class BF, class EF, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, int N, int K, int ksplit) {
+__global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, int N, int K, int ksplit,
+                                                   int mtiles, int ntiles) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using SA = Stage<AF, BM>;
     using SB = Stage<BF, BN>;
+    constexpr int BUF = SA::ELEMS + SB::ELEMS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + SA::ELEMS;
+
+    // XCD-aware tile mapping: slot j of XCD x -> (m tile (j / ntiles)*8 + x, n tile j % ntiles)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt_i = slot % ntiles, mt_i = (slot / ntiles) * 8 + xcd;
+    if (mt_i >= mtiles) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+    const int m0 = mt_i * BM, n0 = nt_i * BN, z = blockIdx.y;
     int kbeg = 0, kend = K;
     if (ksplit < K) { kbeg = z * ksplit; kend = min(K, kbeg + ksplit); }
+    const int ntile = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -306,20 +448,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;     // bias-gradient column sum (EF::HAS_BIAS, m tile 0, thread = column)
 
+    typename SA::State sa;
+    typename SB::State sb;
     float4 ra[SA::NV], rb[SB::NV];
-    if (kbeg < kend) {
-        SA::gload(af, ra, m0, kbeg, z, tid);
-        SB::gload(bf, rb, n0, kbeg, z, tid);
+    if (ntile > 0) {
+        af.template init<SA::NV>(sa, m0, kbeg, z, tid);
+        bf.template init<SB::NV>(sb, n0, kbeg, z, tid);
+        af.template fetch<SA::NV>(sa, ra);
+        bf.template fetch<SB::NV>(sb, rb);
+        SA::swrite(smem, ra, tid);
+        SB::swrite(smem + SA::ELEMS, rb, tid);
     }
-    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-        __syncthreads();                       // previous tile's fragment reads are done
-        SA::swrite(As, ra, tid);
-        SB::swrite(Bs, rb, tid);
-        __syncthreads();
-        if (k0 + GEMM_BK < kend) {             // next tile in flight during the MFMA block
-            SA::gload(af, ra, m0, k0 + GEMM_BK, z, tid);
-            SB::gload(bf, rb, n0, k0 + GEMM_BK, z, tid);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const float* As = smem + (t & 1) * BUF;
+        const float* Bs = As + SA::ELEMS;
+        const bool more = t + 1 < ntile;
+        if (more) {                            // next tile in flight during the MFMA block
+            af.template fetch<SA::NV>(sa, ra);
+            bf.template fetch<SB::NV>(sb, rb);
         }
 #pragma unroll
         for (int kb = 0; kb < GEMM_BK / 8; ++kb) {
@@ -338,6 +487,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
                 }
         }
+        if (EF::HAS_BIAS && !BF::KC && mt_i == 0 && tid < BN) {   // B image is [k][BN+4]: column sums in k order
+#pragma unroll 8
+            for (int kk = 0; kk < GEMM_BK; ++kk) bsum += Bs[kk * (BN + 4) + tid];
+        }
+        if (more) {
+            float* An = smem + ((t + 1) & 1) * BUF;
+            SA::swrite(An, ra, tid);
+            SB::swrite(An + SA::ELEMS, rb, tid);
+        }
+        __syncthreads();
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -350,17 +509,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
                 int col = n0 + (wn * TN + b) * 32 + i;
                 if (row < M && col < N) ef.store(row, col, acc[a][b][r], z);
             }
+    if constexpr (EF::HAS_BIAS) {
+        if (!BF::KC && mt_i == 0 && tid < BN && n0 + tid < N) ef.store_bias(n0 + tid, bsum, z);
+    }
 }
 
 template <class AF, class BF, class EF, int WM, int WN, int TM, int TN>
 inline hipError_t launch_gemm(const AF& af, const BF& bf, const EF& ef, int M, int N, int K,
                               int zdim, int ksplit, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    size_t lds = (size_t)(Stage<AF, BM>::ELEMS + Stage<BF, BN>::ELEMS) * sizeof(float);
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, zdim);
+    const size_t lds = 2 * (size_t)(Stage<AF, BM>::ELEMS + Stage<BF, BN>::ELEMS) * sizeof(float);
     if (M <= 0 || N <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm_kernel<AF, BF, EF, WM, WN, TM, TN>), grid, dim3(256), lds, stream,
-                       af, bf, ef, M, N, K, ksplit);
+    const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
+    const long blocks = (long)((mtiles + 7) / 8) * 8 * ntiles;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    auto kern = gemm_kernel<AF, BF, EF, WM, WN, TM, TN>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;            // per instantiation
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, zdim), dim3(256), lds, stream, af, bf, ef, M, N, K, ksplit,
+                       mtiles, ntiles);
     return hipGetLastError();
 }
 

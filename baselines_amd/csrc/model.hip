@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -186,20 +187,43 @@ struct Ws {
     size_t part_floats;
     double* dscratch;    // adv partials [ADV_G][2] | head stat partials [HEAD_MAXBLK][5] | stats acc [5]
     float* advstat;      // [2]
+    int32_t* srow;       // [chunk] storage rows of the minibatch samples (env-major index translated)
     size_t total;
 };
 
 constexpr int ADV_G = 256;
 constexpr int HEAD_MAXBLK = 512;
-constexpr int BIAS_MAXBLK = 512;
 constexpr int WGRAD_TARGET_WGS = 1536;
 
+// ---- tile variants of the GEMM template (gemm.hip.h) and the process-wide tuning table ----------
+enum { V_128x32 = 0, V_256x32, V_128x64_W41, V_128x64_W22, V_256x64, V_128x128, V_COUNT };
+static const int kVariantBM[V_COUNT] = {128, 256, 128, 128, 256, 128};
+static const int kVariantBN[V_COUNT] = {32, 32, 64, 64, 64, 128};
+
+static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
+extern "C" int mrl_tune_set(const char* label, int variant) {
+    if (!label || variant >= V_COUNT) return MRL_EINVAL;
+    if (variant < 0) tune_table().erase(label);
+    else tune_table()[label] = variant;
+    return 0;
+}
+// default tile choice by GEMM shape; `label` ("c1.fwd", "fc1.wgrad", ...) may override it
+static int pick_variant(const char* lname, const char* pass, int M, int N) {
+    if (!tune_table().empty()) {
+        auto it = tune_table().find(std::string(lname) + "." + pass);
+        if (it != tune_table().end()) return it->second;
+    }
+    if (N <= 32) return M >= 4096 ? V_256x32 : V_128x32;
+    if (N <= 64) return M >= 4096 ? V_256x64 : V_128x64_W22;
+    return V_128x128;
+}
+
 struct Split { int nsplit, ksplit; };
-static Split pick_split(int Mp, int Np, long Kp) {
-    int bn = Np <= 32 ? 32 : (Np <= 64 ? 64 : 128);
-    long tiles = (long)((Mp + 127) / 128) * ((Np + bn - 1) / bn);
+static Split pick_split(int variant, int Mp, int Np, long Kp) {
+    const int bm = kVariantBM[variant], bn = kVariantBN[variant];
+    long tiles = (long)((Mp + bm - 1) / bm) * ((Np + bn - 1) / bn);
     long ns = std::max<long>(1, WGRAD_TARGET_WGS / std::max<long>(1, tiles));
-    long maxns = std::max<long>(1, Kp / 128);
+    long maxns = std::max<long>(1, Kp / 256);
     ns = std::min(ns, maxns);
     long ks = (Kp + ns - 1) / ns;
     ks = (ks + 31) / 32 * 32;
@@ -207,6 +231,14 @@ static Split pick_split(int Mp, int Np, long Kp) {
     s.ksplit = (int)ks;
     s.nsplit = (int)((Kp + ks - 1) / ks);
     return s;
+}
+static long max_split_floats(int Mp, int Np, long Kp) {     // worst case over the tile variants
+    long worst = 0;
+    for (int v = 0; v < V_COUNT; ++v) {
+        Split s = pick_split(v, Mp, Np, Kp);
+        worst = std::max(worst, (long)s.nsplit * ((long)Mp * Np + Np));
+    }
+    return worst;
 }
 
 static long layer_rows(const Layer& l, int B) { return l.kind == 0 ? (long)B * l.OH * l.OW : (long)B; }
@@ -220,9 +252,7 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
         for (const Layer& l : net.L) {
             nw.h.push_back((float*)take((size_t)chunk * l.out_elems * 4));
             nw.dz.push_back((float*)take((size_t)chunk * l.out_elems * 4));
-            Split s = pick_split(l.K, l.N, layer_rows(l, chunk));
-            part_floats = std::max(part_floats, (size_t)s.nsplit * l.K * l.N);
-            part_floats = std::max(part_floats, (size_t)BIAS_MAXBLK * l.N);
+            part_floats = std::max(part_floats, (size_t)max_split_floats(l.K, l.N, layer_rows(l, chunk)));
         }
     };
     do_net(m->pi, ws.pi);
@@ -232,6 +262,7 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     ws.part_floats = part_floats;
     ws.dscratch = (double*)take((size_t)(ADV_G * 2 + HEAD_MAXBLK * 5 + 8) * 8);
     ws.advstat = (float*)take(64);
+    ws.srow = (int32_t*)take((size_t)chunk * 4);
     ws.total = off;
 }
 
@@ -246,48 +277,48 @@ extern "C" size_t mrl_model_workspace_bytes(const mrl_model* m, int chunk) {
 // small kernels
 // ============================================================================================
 
-// out[i] = (accumulate ? out[i] : 0) + sum_z part[z*slab + i]   (fixed order -> deterministic)
+// out[i] = (accumulate ? out[i] : 0) + sum_z part[z*slab + i]   (fixed order -> deterministic).
+// 64 outputs x 4 z-lanes per block: lane q sums z = q, q+4, ... with 4 loads in flight, the four
+// lane sums are combined in a fixed order through LDS.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, long slab, int nz,
                                                            float* __restrict__ out, long n, int accumulate) {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
-        float s = accumulate ? out[i] : 0.f;
-        for (int z = 0; z < nz; ++z) s += part[(long)z * slab + i];
-        out[i] = s;
+    __shared__ float sh[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (long i0 = blockIdx.x * 64L; i0 < n; i0 += (long)gridDim.x * 64L) {
+        const long i = i0 + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (i < n) {
+            int zz = q;
+            for (; zz + 12 < nz; zz += 16) {
+                s0 += part[(long)zz * slab + i];
+                s1 += part[(long)(zz + 4) * slab + i];
+                s2 += part[(long)(zz + 8) * slab + i];
+                s3 += part[(long)(zz + 12) * slab + i];
+            }
+            for (; zz < nz; zz += 4) s0 += part[(long)zz * slab + i];
+        }
+        sh[q][c] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && i < n) {
+            float t = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+            out[i] = accumulate ? out[i] + t : t;
+        }
+        __syncthreads();
     }
 }
 static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st) {
-    int blocks = (int)std::min<long>((n + 255) / 256, 4096);
+    int blocks = (int)std::min<long>((n + 63) / 64, 8192);
     ProfScope ps("reduce_slabs", 0.0, 4.0 * n * (nz + 1 + (accumulate ? 1 : 0)), st);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate);
     MRL_LAUNCH_CHECK();
     return 0;
 }
 
-// column sums of dz [rows][N] -> part[blk][N]   (bias gradient, tf.gradients of `+ b`)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, long rows, int N,
-                                                     float* __restrict__ part) {
-    extern __shared__ float sh[];   // [256]
-    const int tid = threadIdx.x;
-    long rpb = (rows + gridDim.x - 1) / gridDim.x;
-    long r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
-    if (N <= 256 && 256 % N == 0) {
-        int RL = 256 / N, c = tid % N, rl = tid / N;
-        float s = 0.f;
-        for (long r = r0 + rl; r < r1; r += RL) s += dz[r * N + c];
-        sh[tid] = s;
-        __syncthreads();
-        if (rl == 0) {
-            float t = 0.f;
-            for (int q = 0; q < RL; ++q) t += sh[q * N + c];
-            part[(long)blockIdx.x * N + c] = t;
-        }
-    } else {
-        for (int c = tid; c < N; c += 256) {
-            float s = 0.f;
-            for (long r = r0; r < r1; ++r) s += dz[r * N + c];
-            part[(long)blockIdx.x * N + c] = s;
-        }
-    }
+// env-major flat minibatch indices (ppo2.py:160-162, runner.py:69-74) -> time-major storage rows
+__global__ __launch_bounds__(256) void translate_idx_kernel(const int64_t* __restrict__ idx, int B, int T, int N,
+                                                            int32_t* __restrict__ srow) {
+    int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) srow[b] = (int32_t)envmajor_to_row(idx[b], T, N);
 }
 
 // advantage statistics over the minibatch (model.py:136-139), f64 accumulation
@@ -643,55 +674,64 @@ __global__ __launch_bounds__(256) void heads_act_kernel(HeadArgs a) {
 // layer launches
 // ============================================================================================
 struct In {               // layer-0 input description
-    const void* obs; const int64_t* idx; int T, N;
+    const void* obs; const int32_t* srow;   // srow: storage row of sample b (nullptr: b itself)
 };
 
 template <class AF, class BF, class EF>
-static int gemm_dispatch(const char* lname, const char* pass, const AF& af, const BF& bf, const EF& ef, int M,
-                         int N, int K, int zdim, int ksplit, hipStream_t st) {
+static int gemm_dispatch(const char* lname, const char* pass, int variant, const AF& af, const BF& bf, const EF& ef,
+                         int M, int N, int K, int zdim, int ksplit, hipStream_t st) {
     hipError_t e;
     char label[40];
     if (prof_enabled()) snprintf(label, sizeof label, "%s.%s", lname, pass);
     // algorithmic work of the launch: 2*M*N*K flops (for the conv data-gradient K counts the taps of
     // all parity classes, i.e. every filter tap exactly once per output pixel -> zdim cancels)
     ProfScope ps(label, 2.0 * M * (double)N * K * ((ksplit >= K) ? zdim : 1), 0.0, st);
-    if (N <= 32) e = launch_gemm<AF, BF, EF, 4, 1, 1, 1>(af, bf, ef, M, N, K, zdim, ksplit, st);
-    else if (N <= 64) e = launch_gemm<AF, BF, EF, 4, 1, 1, 2>(af, bf, ef, M, N, K, zdim, ksplit, st);
-    else e = launch_gemm<AF, BF, EF, 2, 2, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st);
+    switch (variant) {
+        case V_128x32:     e = launch_gemm<AF, BF, EF, 4, 1, 1, 1>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+        case V_256x32:     e = launch_gemm<AF, BF, EF, 4, 1, 2, 1>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+        case V_128x64_W41: e = launch_gemm<AF, BF, EF, 4, 1, 1, 2>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+        case V_128x64_W22: e = launch_gemm<AF, BF, EF, 2, 2, 2, 1>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+        case V_256x64:     e = launch_gemm<AF, BF, EF, 4, 1, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+        default:           e = launch_gemm<AF, BF, EF, 2, 2, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+    }
     return (int)e;
 }
 
 static inline int is_vec(const void* p, long ld) { return (ld % 4 == 0) && ((uintptr_t)p % 16 == 0); }
 
+static void fill_conv(ConvGeom& g, const Layer& l, const void* p, int npix, const int32_t* srow) {
+    g.p = p; g.H = l.H; g.W = l.W; g.C = l.C; g.rf = l.rf; g.stride = l.stride; g.OH = l.OH; g.OW = l.OW;
+    g.npix = npix; g.kconv = l.K; g.srow = srow;
+    g.finish();
+}
+
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
                          const float* params, float* hout, int B, hipStream_t st) {
     const float* W = params + l.w_off;
     const float* bias = params + l.b_off;
-    RowMC bf{W, l.N, l.N, l.K, is_vec(W, l.N)};
+    RowMC bf{W, l.N, l.N, l.K, is_vec(W, l.N), nullptr};
     if (l.kind == 0) {
         int npix = B * l.OH * l.OW;
+        int var = pick_variant(l.name, "fwd", npix, l.NF);
         EpiBiasAct ef{hout, l.NF, bias, l.act};
         if (first) {
             ConvPatchKC<true> af;
-            af.p = in.obs; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
-            af.OW = l.OW; af.npix = npix; af.kconv = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N;
-            return gemm_dispatch(l.name, "fwd", af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+            fill_conv(af, l, in.obs, npix, in.srow);
+            return gemm_dispatch(l.name, "fwd", var, af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
         } else {
             ConvPatchKC<false> af;
-            af.p = hprev; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
-            af.OW = l.OW; af.npix = npix; af.kconv = l.K; af.idx = nullptr; af.T = 1; af.N = 1;
-            return gemm_dispatch(l.name, "fwd", af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+            fill_conv(af, l, hprev, npix, nullptr);
+            return gemm_dispatch(l.name, "fwd", var, af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
         }
     } else {
+        int var = pick_variant(l.name, "fwd", B, l.N);
         EpiBiasAct ef{hout, l.N, bias, l.act};
         if (first) {
-            GatherKC af;
-            af.p = (const float*)in.obs; af.ld = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N; af.rows = B;
-            af.kmax = l.K; af.vec = is_vec(in.obs, l.K);
-            return gemm_dispatch(l.name, "fwd", af, bf, ef, B, l.N, l.K, 1, l.K, st);
+            RowKC af{(const float*)in.obs, l.K, B, l.K, is_vec(in.obs, l.K), in.srow};
+            return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
         } else {
-            RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K)};
-            return gemm_dispatch(l.name, "fwd", af, bf, ef, B, l.N, l.K, 1, l.K, st);
+            RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K), nullptr};
+            return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
         }
     }
 }
@@ -714,46 +754,37 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         const float* hprev = i ? nw.h[i - 1] : nullptr;
         const long rows = layer_rows(l, B);
         const bool first = (i == 0);
-        // ---- weight gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n]  (split-K over rows)
-        Split sp = pick_split(l.K, l.N, rows);
-        if ((size_t)sp.nsplit * l.K * l.N > ws.part_floats) return MRL_ENOSPC;
-        EpiPartial ep{ws.part, (long)l.K * l.N, l.N};
-        RowMC bfm{dz, l.N, l.N, (int)rows, is_vec(dz, l.N)};
+        if (rows > 0x7fffffffL || l.b_off != l.w_off + (long)l.K * l.N) return MRL_EUNSUP;
+        // ---- weight + bias gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n], db[n] = sum_rows dz[row][n]
+        //      (split-K over rows; the bias column sums ride on the B operand's LDS image)
+        const int var = pick_variant(l.name, "wgrad", l.K, l.N);
+        const Split sp = pick_split(var, l.K, l.N, rows);
+        const long slab = (long)l.K * l.N + l.N;
+        if ((size_t)sp.nsplit * slab > ws.part_floats) return MRL_ENOSPC;
+        EpiPartial ep{ws.part, slab, l.N, (long)l.K * l.N};
+        RowMC bfm{dz, l.N, l.N, (int)rows, is_vec(dz, l.N), nullptr};
         int rc;
         if (l.kind == 0) {
             if (first) {
                 ConvPatchMC<true> af;
-                af.p = in.obs; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
-                af.OW = l.OW; af.npix = (int)rows; af.kconv = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N;
-                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                fill_conv(af, l, in.obs, (int)rows, in.srow);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
             } else {
                 ConvPatchMC<false> af;
-                af.p = hprev; af.H = l.H; af.W = l.W; af.C = l.C; af.rf = l.rf; af.stride = l.stride; af.OH = l.OH;
-                af.OW = l.OW; af.npix = (int)rows; af.kconv = l.K; af.idx = nullptr; af.T = 1; af.N = 1;
-                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                fill_conv(af, l, hprev, (int)rows, nullptr);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
             }
         } else {
             if (first) {
-                GatherMC af;
-                af.p = (const float*)in.obs; af.ld = l.K; af.idx = in.idx; af.T = in.T; af.N = in.N; af.rows = B;
-                af.kmax = l.K; af.vec = is_vec(in.obs, l.K);
-                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+                RowMC af{(const float*)in.obs, l.K, l.K, B, is_vec(in.obs, l.K), in.srow};
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
             } else {
-                RowMC af{hprev, l.K, l.K, B, is_vec(hprev, l.K)};
-                rc = gemm_dispatch(l.name, "wgrad", af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+                RowMC af{hprev, l.K, l.K, B, is_vec(hprev, l.K), nullptr};
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
             }
         }
         if (rc) return rc;
-        rc = reduce_slabs(ws.part, (long)l.K * l.N, sp.nsplit, grads + l.w_off, (long)l.K * l.N, accumulate, st);
-        if (rc) return rc;
-        // ---- bias gradient
-        int nblk = (int)std::min<long>(BIAS_MAXBLK, std::max<long>(1, rows / 64));
-        {
-            ProfScope ps("bias_colsum", 0.0, 4.0 * rows * l.N, st);
-            hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), st, dz, rows, l.N, ws.part);
-        }
-        MRL_LAUNCH_CHECK();
-        rc = reduce_slabs(ws.part, l.N, nblk, grads + l.b_off, l.N, accumulate, st);
+        rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, st);
         if (rc) return rc;
         // ---- data gradient into dz[i-1] (masked by act' of layer i-1)
         if (!first) {
@@ -763,17 +794,22 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 g.H = l.H; g.W = l.W; g.C = l.C; g.rf = l.rf; g.stride = l.stride; g.OH = l.OH; g.OW = l.OW;
                 g.NF = l.NF; g.taps = (l.rf + l.stride - 1) / l.stride;
                 g.HY = (l.H + l.stride - 1) / l.stride; g.WX = (l.W + l.stride - 1) / l.stride; g.B = B;
+                g.finish();
+                if (l.NF % 4 != 0 || (long)B * g.HY * g.WX > 0x7fffffffL) return MRL_EUNSUP;
                 DgradA af; static_cast<DgradGeom&>(af) = g; af.dz = dz;
                 DgradB bf; static_cast<DgradGeom&>(bf) = g; bf.w = params + l.w_off;
                 EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hprev; ef.act = lp.act;
                 int Kd = g.taps * g.taps * l.NF;
-                rc = gemm_dispatch(l.name, "dgrad", af, bf, ef, B * g.HY * g.WX, l.C, Kd, l.stride * l.stride, Kd, st);
+                int Md = B * g.HY * g.WX;
+                int dv = pick_variant(l.name, "dgrad", Md, l.C);
+                rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, Md, l.C, Kd, l.stride * l.stride, Kd, st);
             } else {
-                RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N)};
+                RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
                 const float* W = params + l.w_off;
-                RowKC bf{W, l.N, l.K, l.N, is_vec(W, l.N)};
+                RowKC bf{W, l.N, l.K, l.N, is_vec(W, l.N), nullptr};
                 EpiMaskAct ef{nw.dz[i - 1], l.K, hprev, lp.act};
-                rc = gemm_dispatch(l.name, "dgrad", af, bf, ef, B, l.K, l.N, 1, l.N, st);
+                int dv = pick_variant(l.name, "dgrad", B, l.K);
+                rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, B, l.K, l.N, 1, l.N, st);
             }
             if (rc) return rc;
         }
@@ -824,7 +860,7 @@ extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void
     const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int Bc = std::min(chunk, n - c0);
-        In in{(const char*)obs + (size_t)c0 * ob_bytes, nullptr, 1, 1};
+        In in{(const char*)obs + (size_t)c0 * ob_bytes, nullptr};
         int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
         if (rc) return rc;
         if (m->vf_copy) {
@@ -861,6 +897,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
         !workspace || B <= 0 || chunk <= 0)
         return MRL_EINVAL;
     if (idx && (T <= 0 || N <= 0)) return MRL_EINVAL;
+    if (idx && (long)T * N > 0x7fffffffL) return MRL_EUNSUP;
     hipStream_t st = (hipStream_t)stream;
     Ws ws;
     carve(m, chunk, (char*)workspace, ws);
@@ -882,8 +919,13 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
         const int Bc = std::min(chunk, B - c0);
         const int accumulate = c0 > 0;
         In in;
-        if (idx) { in.obs = obs; in.idx = idx + c0; in.T = T; in.N = N; }
-        else { in.obs = (const char*)obs + (size_t)c0 * ob_bytes; in.idx = nullptr; in.T = 1; in.N = 1; }
+        if (idx) {
+            hipLaunchKernelGGL(translate_idx_kernel, dim3((Bc + 255) / 256), dim3(256), 0, st, idx + c0, Bc, T, N, ws.srow);
+            MRL_LAUNCH_CHECK();
+            in.obs = obs; in.srow = ws.srow;
+        } else {
+            in.obs = (const char*)obs + (size_t)c0 * ob_bytes; in.srow = nullptr;
+        }
         int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
         if (rc) return rc;
         if (m->vf_copy && (rc = net_forward(m, m->vf, in, params, ws.vf, Bc, st))) return rc;

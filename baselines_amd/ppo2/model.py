@@ -58,9 +58,10 @@ class Model(object):
         self.microbatch_size = microbatch_size
         kw = policy.device_model_kwargs()
         if chunk is None:
-            # samples processed per pass of the layer kernels (activations + their gradients live in
-            # the workspace: ~173 KB/sample for NatureCNN)
-            chunk = 8192 if kw['network'] == 'cnn' else 32768
+            # samples processed per pass of the layer kernels.  Activations and their gradients live in
+            # the workspace (~173 KB/sample for NatureCNN): with 288 GB of HBM a whole 131072-sample
+            # minibatch (22.7 GB) fits, which means ONE split-K reduction per layer per minibatch step.
+            chunk = 131072 if kw['network'] == 'cnn' else 1 << 20
         chunk = int(max(1, min(chunk, max(nbatch_train or 1, nbatch_act or 1))))
         self.dm = ops.DeviceModel(chunk=chunk, device=self.device, **kw)
         self.pd_kind, self.nact = self.dm.pd_kind, self.dm.nact

@@ -142,6 +142,12 @@ int mrl_prof_num_labels(void);
 int mrl_prof_get(int i, char* name, int name_cap, long* count, double* total_ms,
                  double* total_flops, double* total_bytes);
 
+/* ---- tile-shape tuning hook (bench / profiling only) ------------------------------------------
+ * Overrides the GEMM tile variant used for one launch site, label = "<layer>.<fwd|wgrad|dgrad>"
+ * (e.g. "c1.fwd"); variant < 0 restores the built-in choice.  Results are identical for every
+ * variant of the forward / data-gradient GEMMs; weight-gradient split-K changes summation order. */
+int mrl_tune_set(const char* label, int variant);
+
 #ifdef __cplusplus
 }
 #endif
