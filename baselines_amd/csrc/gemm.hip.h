@@ -418,9 +418,9 @@ struct Stage {
     }
 };
 
-template <class AF, class BF, class EF, int WM, int WN, int TM, int TN>
+template <class AF, class BF, class EF, int WM, int WN, int TM, int TN, bool DB>
 __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, int N, int K, int ksplit,
-                                                   int mtiles, int ntiles) {
+                                                   int mtiles, int ntiles, int zdim) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using SA = Stage<AF, BM>;
@@ -428,15 +428,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
     constexpr int BUF = SA::ELEMS + SB::ELEMS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    // XCD-aware tile mapping: slot j of XCD x -> (m tile (j / ntiles)*8 + x, n tile j % ntiles)
+    // XCD-aware tile mapping.  A "panel" p = (z, m tile) owns the N tiles that share its A row-panel;
+    // panel p lives on XCD p % 8 and its N tiles take consecutive slots there (shared L2), while
+    // consecutive panels (m tiles of one z, then the next z) round-robin over the 8 XCDs.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int nt_i = slot % ntiles, mt_i = (slot / ntiles) * 8 + xcd;
-    if (mt_i >= mtiles) return;
+    const int nt_i = slot % ntiles;
+    const long panel = (long)(slot / ntiles) * 8 + xcd;
+    if (panel >= (long)mtiles * zdim) return;
+    const int z = (int)(panel / mtiles), mt_i = (int)(panel - (long)z * mtiles);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = mt_i * BM, n0 = nt_i * BN, z = blockIdx.y;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
     int kbeg = 0, kend = K;
     if (ksplit < K) { kbeg = z * ksplit; kend = min(K, kbeg + ksplit); }
     const int ntile = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
@@ -458,14 +462,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
         bf.template init<SB::NV>(sb, n0, kbeg, z, tid);
         af.template fetch<SA::NV>(sa, ra);
         bf.template fetch<SB::NV>(sb, rb);
-        SA::swrite(smem, ra, tid);
-        SB::swrite(smem + SA::ELEMS, rb, tid);
+        if (DB) {
+            SA::swrite(smem, ra, tid);
+            SB::swrite(smem + SA::ELEMS, rb, tid);
+        }
     }
-    __syncthreads();
+    if (DB) __syncthreads();
     for (int t = 0; t < ntile; ++t) {
-        const float* As = smem + (t & 1) * BUF;
+        const float* As = smem + (DB ? (t & 1) * BUF : 0);
         const float* Bs = As + SA::ELEMS;
         const bool more = t + 1 < ntile;
+        if (!DB) {
+            __syncthreads();                   // previous tile's fragment reads are done
+            SA::swrite(smem, ra, tid);
+            SB::swrite(smem + SA::ELEMS, rb, tid);
+            __syncthreads();
+        }
         if (more) {                            // next tile in flight during the MFMA block
             af.template fetch<SA::NV>(sa, ra);
             bf.template fetch<SB::NV>(sb, rb);
@@ -487,16 +499,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
                 }
         }
-        if (EF::HAS_BIAS && !BF::KC && mt_i == 0 && tid < BN) {   // B image is [k][BN+4]: column sums in k order
-#pragma unroll 8
-            for (int kk = 0; kk < GEMM_BK; ++kk) bsum += Bs[kk * (BN + 4) + tid];
+        if (EF::HAS_BIAS && !BF::KC && mt_i == 0) {
+            // B image is [k][BN+4]: column sums in k order.  Spread over the 4 waves (8 k each) so no
+            // single wave carries a 32-deep dependent chain; combined in fixed order at the end.
+            const int c = tid % BN, part = tid / BN;          // BN in {32,64,128}: 256/BN parts
+            constexpr int PARTS = 256 / BN, KP = GEMM_BK / PARTS;
+            float t0 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) t0 += Bs[(part * KP + kk) * (BN + 4) + c];
+            bsum += t0;
         }
-        if (more) {
-            float* An = smem + ((t + 1) & 1) * BUF;
-            SA::swrite(An, ra, tid);
-            SB::swrite(An + SA::ELEMS, rb, tid);
+        if (DB) {
+            if (more) {
+                float* An = smem + ((t + 1) & 1) * BUF;
+                SA::swrite(An, ra, tid);
+                SB::swrite(An + SA::ELEMS, rb, tid);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -510,20 +530,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
                 if (row < M && col < N) ef.store(row, col, acc[a][b][r], z);
             }
     if constexpr (EF::HAS_BIAS) {
-        if (!BF::KC && mt_i == 0 && tid < BN && n0 + tid < N) ef.store_bias(n0 + tid, bsum, z);
+        if (!BF::KC && mt_i == 0) {            // combine the per-part column sums in fixed order
+            __syncthreads();
+            smem[tid] = bsum;
+            __syncthreads();
+            if (tid < BN && n0 + tid < N) {
+                float t = 0.f;
+                for (int q = 0; q < 256 / BN; ++q) t += smem[q * BN + tid];
+                ef.store_bias(n0 + tid, t, z);
+            }
+        }
     }
 }
 
-template <class AF, class BF, class EF, int WM, int WN, int TM, int TN>
+template <class AF, class BF, class EF, int WM, int WN, int TM, int TN, bool DB>
 inline hipError_t launch_gemm(const AF& af, const BF& bf, const EF& ef, int M, int N, int K,
                               int zdim, int ksplit, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const size_t lds = 2 * (size_t)(Stage<AF, BM>::ELEMS + Stage<BF, BN>::ELEMS) * sizeof(float);
-    if (M <= 0 || N <= 0) return hipSuccess;
+    const size_t lds = (DB ? 2 : 1) * (size_t)(Stage<AF, BM>::ELEMS + Stage<BF, BN>::ELEMS) * sizeof(float);
+    if (M <= 0 || N <= 0 || zdim <= 0) return hipSuccess;
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
-    const long blocks = (long)((mtiles + 7) / 8) * 8 * ntiles;
+    const long panels = (long)mtiles * zdim;
+    const long blocks = (panels + 7) / 8 * 8 * ntiles;
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
-    auto kern = gemm_kernel<AF, BF, EF, WM, WN, TM, TN>;
+    auto kern = gemm_kernel<AF, BF, EF, WM, WN, TM, TN, DB>;
     if (lds > 64 * 1024) {
         static bool raised = false;            // per instantiation
         if (!raised) {
@@ -532,8 +562,8 @@ inline hipError_t launch_gemm(const AF& af, const BF& bf, const EF& ef, int M, i
             raised = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, zdim), dim3(256), lds, stream, af, bf, ef, M, N, K, ksplit,
-                       mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, bf, ef, M, N, K, ksplit,
+                       mtiles, ntiles, zdim);
     return hipGetLastError();
 }
 

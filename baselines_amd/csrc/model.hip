@@ -202,7 +202,7 @@ static const int kVariantBN[V_COUNT] = {32, 32, 64, 64, 64, 128};
 
 static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
 extern "C" int mrl_tune_set(const char* label, int variant) {
-    if (!label || variant >= V_COUNT) return MRL_EINVAL;
+    if (!label || variant >= 2 * V_COUNT) return MRL_EINVAL;
     if (variant < 0) tune_table().erase(label);
     else tune_table()[label] = variant;
     return 0;
@@ -213,14 +213,14 @@ static int pick_variant(const char* lname, const char* pass, int M, int N) {
         auto it = tune_table().find(std::string(lname) + "." + pass);
         if (it != tune_table().end()) return it->second;
     }
-    if (N <= 32) return M >= 4096 ? V_256x32 : V_128x32;
-    if (N <= 64) return M >= 4096 ? V_256x64 : V_128x64_W22;
+    if (N <= 32) return V_128x32;
+    if (N <= 64) return V_128x64_W41;
     return V_128x128;
 }
 
 struct Split { int nsplit, ksplit; };
 static Split pick_split(int variant, int Mp, int Np, long Kp) {
-    const int bm = kVariantBM[variant], bn = kVariantBN[variant];
+    const int bm = kVariantBM[variant % V_COUNT], bn = kVariantBN[variant % V_COUNT];
     long tiles = (long)((Mp + bm - 1) / bm) * ((Np + bn - 1) / bn);
     long ns = std::max<long>(1, WGRAD_TARGET_WGS / std::max<long>(1, tiles));
     long maxns = std::max<long>(1, Kp / 256);
@@ -679,20 +679,29 @@ struct In {               // layer-0 input description
 
 template <class AF, class BF, class EF>
 static int gemm_dispatch(const char* lname, const char* pass, int variant, const AF& af, const BF& bf, const EF& ef,
-                         int M, int N, int K, int zdim, int ksplit, hipStream_t st) {
+                         int M, int N, int K, int zdim, int ksplit, hipStream_t st, double alg_flops = -1.0) {
     hipError_t e;
     char label[40];
     if (prof_enabled()) snprintf(label, sizeof label, "%s.%s", lname, pass);
-    // algorithmic work of the launch: 2*M*N*K flops (for the conv data-gradient K counts the taps of
-    // all parity classes, i.e. every filter tap exactly once per output pixel -> zdim cancels)
-    ProfScope ps(label, 2.0 * M * (double)N * K * ((ksplit >= K) ? zdim : 1), 0.0, st);
-    switch (variant) {
-        case V_128x32:     e = launch_gemm<AF, BF, EF, 4, 1, 1, 1>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
-        case V_256x32:     e = launch_gemm<AF, BF, EF, 4, 1, 2, 1>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
-        case V_128x64_W41: e = launch_gemm<AF, BF, EF, 4, 1, 1, 2>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
-        case V_128x64_W22: e = launch_gemm<AF, BF, EF, 2, 2, 2, 1>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
-        case V_256x64:     e = launch_gemm<AF, BF, EF, 4, 1, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
-        default:           e = launch_gemm<AF, BF, EF, 2, 2, 2, 2>(af, bf, ef, M, N, K, zdim, ksplit, st); break;
+    // algorithmic work of the launch: 2*M*N*K flops unless the caller states it (the gather-form conv
+    // data-gradient also multiplies zero padding at the image border: only the true
+    // 2 * out_pixels * K_conv * NF count is reported)
+    ProfScope ps(label, alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K * ((ksplit >= K) ? zdim : 1), 0.0, st);
+    const bool db = variant >= V_COUNT;     // variants V_COUNT.. are the double-buffered forms
+    switch (db ? variant - V_COUNT : variant) {
+#define MRL_CASE(V, WM, WN, TM, TN)                                                                          \
+        case V:                                                                                              \
+            e = db ? launch_gemm<AF, BF, EF, WM, WN, TM, TN, true>(af, bf, ef, M, N, K, zdim, ksplit, st)     \
+                   : launch_gemm<AF, BF, EF, WM, WN, TM, TN, false>(af, bf, ef, M, N, K, zdim, ksplit, st);   \
+            break;
+        MRL_CASE(V_128x32, 4, 1, 1, 1)
+        MRL_CASE(V_256x32, 4, 1, 2, 1)
+        MRL_CASE(V_128x64_W41, 4, 1, 1, 2)
+        MRL_CASE(V_128x64_W22, 2, 2, 2, 1)
+        MRL_CASE(V_256x64, 4, 1, 2, 2)
+        default:
+        MRL_CASE(V_128x128, 2, 2, 2, 2)
+#undef MRL_CASE
     }
     return (int)e;
 }
@@ -802,7 +811,8 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 int Kd = g.taps * g.taps * l.NF;
                 int Md = B * g.HY * g.WX;
                 int dv = pick_variant(l.name, "dgrad", Md, l.C);
-                rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, Md, l.C, Kd, l.stride * l.stride, Kd, st);
+                rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, Md, l.C, Kd, l.stride * l.stride, Kd, st,
+                                   2.0 * B * l.OH * l.OW * (double)l.K * l.NF);
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
                 const float* W = params + l.w_off;

@@ -18,6 +18,7 @@ from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv  # no
 from baselines_amd.ppo2 import Model, Runner  # noqa: E402
 
 VARIANTS = ['128x32', '256x32', '128x64w41', '128x64w22', '256x64', '128x128']
+VARIANTS = VARIANTS + [v + 'db' for v in VARIANTS]
 LABELS = ['c1.fwd', 'c2.fwd', 'c3.fwd', 'fc1.fwd', 'c1.wgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad', 'c2.dgrad',
           'c3.dgrad', 'fc1.dgrad']
 
@@ -59,14 +60,14 @@ def main():
         name = 'default' if v < 0 else VARIANTS[v]
         res[name] = {k: dict(ms=d['ms'], tflops=(d['flops'] / d['ms'] / 1e9 if d['flops'] else None)) for k, d in rep.items()}
     labs = sorted({k for r in res.values() for k in r})
-    print('%-14s' % 'label' + ''.join('%14s' % n for n in res))
+    print('%-12s' % 'label' + ''.join('%13s' % n for n in res))
     for k in labs:
-        row = '%-14s' % k
+        row = '%-12s' % k
         for n in res:
             d = res[n].get(k)
-            row += '%14s' % ('%.2fms/%5.1fT' % (d['ms'], d['tflops']) if d and d['tflops'] else ('%.2fms' % d['ms'] if d else '-'))
+            row += '%13s' % ('%.1f/%5.1fT' % (d['ms'], d['tflops']) if d and d['tflops'] else ('%.2fms' % d['ms'] if d else '-'))
         print(row)
-    print('TOTAL_MS     ' + ''.join('%14.1f' % sum(d['ms'] for d in res[n].values()) for n in res))
+    print('TOTAL_MS    ' + ''.join('%13.1f' % sum(d['ms'] for d in res[n].values()) for n in res))
     best = {k: max((n for n in res if n != 'default' and k in res[n]), key=lambda n: -res[n][k]['ms']) for k in LABELS}
     print('best per label:', json.dumps(best))
     print('sum of best ms: %.1f' % (sum(res[best[k]][k]['ms'] for k in LABELS)))
