@@ -1,0 +1,307 @@
+// "Weights-resident" fp32-MFMA convolution GEMM for gfx950 (MI355X): the second GEMM engine of
+// libmrl, used where the WHOLE B operand (a conv layer's filter bank: 32-148 KB) fits the CU's
+// 160 KB LDS -- NatureCNN conv forward (a2c/utils.py:37-56 via common/models.py:15-26) and conv
+// data-gradient.
+//
+// Why it exists (measured on MI355X, profiles/): with v_mfma_f32_32x32x2_f32 at 64 cycles per
+// instruction the tiled kernel (gemm.hip.h) is bound by what happens BETWEEN MFMAs -- barriers,
+// LDS round trips of the A tile, staging VALU -- and by occupancy, not by any bandwidth.  For an
+// operand whose fragment is consumed by exactly one wave the LDS round trip is a pure pass-through:
+// the MFMA A fragment of lane (i, h) is 4 consecutive k of row i, i.e. one 16-byte global load.  So:
+//   * the filter bank is transposed into LDS ONCE per workgroup (Wt[n][K+4], conflict-free
+//     ds_read_b128 fragments) and stays there for the kernel's lifetime;
+//   * each wave owns whole 32-row output tiles and streams its A fragments global -> VGPR directly
+//     (im2col / gather / u8->f32 addressing done per lane, PF blocks in flight), no LDS, NO BARRIER
+//     in the main loop; waves are fully independent, 8-16 of them per CU hide each other's latency;
+//   * one persistent workgroup per CU (grid = #CUs), tiles handed out round-robin; the last group of
+//     a tile already prefetches the first group of the wave's next tile (no per-tile pipeline bubble).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+
+namespace mrl {
+
+// ------------------------------------------------------------------------------------------
+// A-fragment loaders.  A row's K dimension is consumed in GROUPS of PF blocks; a block is 2*KL k
+// (lane half h holds KL consecutive k).  Interface:
+//   static constexpr int KL;
+//   struct RowState { int z; ... };     per (wave, tile): class + row addressing + group cursor
+//   struct Frag;                        raw registers of one block
+//   row_init(rs, tile, i, h)            tile -> class z, row (clamped), cursor at group 0
+//   prep_group<PF>(rs)                  fixes the base address of the next group, advances the cursor
+//   load_one<PF>(rs, u) -> Frag         block u of the prepared group (constant offsets from its base)
+//   convert(Frag, float (&a)[KL])
+// Everything in prep_group / load_one is straight-line code: the software pipeline of the kernel
+// must not contain control flow or the compiler serialises the loads (s_waitcnt vmcnt(0) per block).
+// ------------------------------------------------------------------------------------------
+
+// conv forward: rows = output pixels m = (b, oy, ox) (optionally image-gathered through srow),
+// k = (ky, kx, c) in HWIO order.
+//   U8 : pixels are uint8 scaled by 1/255 (models.py:19); a lane holds 16 consecutive k (16 bytes);
+//        requires rf*C == 32 (one block per patch row) and rf % PF == 0 -- group = PF patch rows.
+//   F32: a lane holds 4 consecutive k; requires (rf*C) % (8*PF) == 0 -- group = 8*PF k of one patch row.
+template <bool U8>
+struct WresFwdA : ConvGeom {
+    static constexpr int KL = U8 ? 16 : 4;
+    struct RowState { int z; long base; long koff; int kr; const uint8_t* g; };
+    struct Frag { uint4 u; };
+    __device__ __forceinline__ void row_init(RowState& s, long tile, int i, int h) const {
+        s.z = 0;
+        int m = (int)min(tile * 32 + i, (long)npix - 1);
+        const int ohw = OH * OW;
+        int b = (int)d_ohw.div((uint32_t)m), r = m - b * ohw;
+        int oy = (int)d_ow.div((uint32_t)r), ox = r - oy * OW;
+        long img = srow ? (long)srow[b] : (long)b;
+        s.base = ((img * H + oy * stride) * W + ox * stride) * C + h * KL;
+        s.koff = 0;
+        s.kr = 0;
+    }
+    template <int PF> __device__ __forceinline__ void prep_group(RowState& s) const {
+        if constexpr (U8) {
+            s.g = static_cast<const uint8_t*>(p) + s.base + s.koff;
+            s.koff += (long)PF * W * C;
+        } else {
+            s.g = reinterpret_cast<const uint8_t*>(static_cast<const float*>(p) + s.base + s.koff + s.kr);
+            s.kr += 8 * PF;
+            if (s.kr >= rowk) { s.kr = 0; s.koff += (long)W * C; }
+        }
+    }
+    template <int PF> __device__ __forceinline__ Frag load_one(const RowState& s, int u) const {
+        Frag f;
+        if constexpr (U8) f.u = *reinterpret_cast<const uint4*>(s.g + (long)u * W * C);
+        else f.u = *reinterpret_cast<const uint4*>(s.g + u * 32);
+        return f;
+    }
+    __device__ __forceinline__ void convert(const Frag& f, float (&a)[KL]) const {
+        if constexpr (U8) {
+            const uint32_t w[4] = {f.u.x, f.u.y, f.u.z, f.u.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q * 4 + 0] = u8_over_255((float)(w[q] & 0xff));
+                a[q * 4 + 1] = u8_over_255((float)((w[q] >> 8) & 0xff));
+                a[q * 4 + 2] = u8_over_255((float)((w[q] >> 16) & 0xff));
+                a[q * 4 + 3] = u8_over_255((float)(w[q] >> 24));
+            }
+        } else {
+            a[0] = __uint_as_float(f.u.x); a[1] = __uint_as_float(f.u.y);
+            a[2] = __uint_as_float(f.u.z); a[3] = __uint_as_float(f.u.w);
+        }
+    }
+};
+
+// conv data-gradient (gather form, see DgradGeom in gemm.hip.h): tile -> (parity class z, 32 rows
+// (b, yy, xx) of that class); k = (tap (a, b2), n); a lane holds 4 consecutive n of one tap.
+// Requires NF == 8*PF: one group = one tap.  Taps that fall outside the output map read `zeros`
+// (>= NF floats of 0.0f) so the load stays unconditional.
+struct WresDgradA : DgradGeom {
+    static constexpr int KL = 4;
+    const float* dz;             // [B, OH, OW, NF]
+    const float* zeros;
+    long tiles_per_class;
+    struct RowState { int z; long pbo; int yy, xx; int a, b2; const float* g; const float* zq; };
+    struct Frag { float4 v; };
+    __device__ __forceinline__ void row_init(RowState& s, long tile, int i, int h) const {
+        s.z = (int)(tile / tiles_per_class);
+        long m = (tile - (long)s.z * tiles_per_class) * 32 + i;
+        const int per = HY * WX;
+        int pb = 0;
+        if (m < (long)B * per) {
+            int b = (int)d_per.div((uint32_t)m), r = (int)m - b * per;
+            s.yy = (int)d_wx.div((uint32_t)r);
+            s.xx = r - s.yy * WX;
+            pb = b * OH * OW;
+        } else {
+            s.yy = -0x10000; s.xx = 0;                 // never in range -> zeros
+        }
+        s.a = 0; s.b2 = 0;
+        s.zq = zeros + h * 4;
+        s.g = s.zq;
+        s.pbo = (long)pb * NF + h * 4;                 // element offset of (b, 0, 0, n = 4h)
+    }
+    template <int PF> __device__ __forceinline__ void prep_group(RowState& s) const {
+        const int oy = s.yy - s.a, ox = s.xx - s.b2;
+        const bool ok = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+        const float* q = dz + (s.pbo + (long)(oy * OW + ox) * NF);
+        s.g = ok ? q : s.zq;
+        if (++s.b2 == taps) { s.b2 = 0; ++s.a; }
+    }
+    template <int PF> __device__ __forceinline__ Frag load_one(const RowState& s, int u) const {
+        Frag f;
+        f.v = *reinterpret_cast<const float4*>(s.g + u * 8);
+        return f;
+    }
+    __device__ __forceinline__ void convert(const Frag& f, float (&a)[KL]) const {
+        a[0] = f.v.x; a[1] = f.v.y; a[2] = f.v.z; a[3] = f.v.w;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// B (filter bank) descriptions: element (z, k, n) of the GEMM's B operand, read from HBM once per WG
+// ------------------------------------------------------------------------------------------
+struct WresFwdB {            // W is HWIO flattened [K][N]
+    const float* w; int N;
+    __device__ __forceinline__ float get(int, int k, int n) const { return w[(long)k * N + n]; }
+};
+struct WresDgradB : DgradGeom {   // class z = (py, px); k = (tap, n'); column = input channel c
+    const float* w;
+    __device__ __forceinline__ float get(int z, int k, int c) const {
+        int py = z / stride, px = z - py * stride;
+        int tap = k / NF, n = k - tap * NF;
+        int a = tap / taps, b2 = tap - a * taps;
+        int ky = py + stride * a, kx = px + stride * b2;
+        if (ky >= rf || kx >= rf) return 0.f;
+        return w[((long)(ky * rf + kx) * C + c) * NF + n];
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Epilogues: store(tile, z, row_in_tile(0..31), col, value)
+// ------------------------------------------------------------------------------------------
+struct WresEpiBiasAct {      // out[m*ld + n] = act(acc + bias[n]),  m = tile*32 + row
+    float* out; long ld; const float* bias; int act; long rows; int ncols;
+    __device__ __forceinline__ void store(long tile, int, int row, int col, float acc) const {
+        long m = tile * 32 + row;
+        if (m < rows && col < ncols) out[m * ld + col] = act_fwd(acc + bias[col], act);
+    }
+};
+struct WresEpiDgrad : DgradGeom {   // scatter class rows back to NHWC, masked by act'(h_prev)
+    float* out; const float* hprev; int act; long tiles_per_class;
+    __device__ __forceinline__ void store(long tile, int z, int row, int col, float acc) const {
+        long m = (tile - (long)z * tiles_per_class) * 32 + row;
+        const int per = HY * WX;
+        if (m >= (long)B * per || col >= C) return;
+        int b = (int)d_per.div((uint32_t)m), r = (int)m - b * per;
+        int yy = (int)d_wx.div((uint32_t)r), xx = r - yy * WX;
+        int py = z / stride, px = z - py * stride;
+        int iy = yy * stride + py, ix = xx * stride + px;
+        if (iy >= H || ix >= W) return;
+        long o = ((long)(b * H + iy) * W + ix) * C + col;
+        out[o] = acc * act_bwd_from_out(hprev[o], act);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+template <class AL, class BL, class EF, int NT, int PF, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void wres_kernel(AL al, BL bl, EF ef, int zc, int K, int N, int KP,
+                                                          long total_tiles) {
+    constexpr int KL = AL::KL;
+    extern __shared__ __attribute__((aligned(16))) float wt[];   // [zc][NT*32][KP]
+    const int tid = threadIdx.x;
+    // ---- one-time transpose of the filter bank into LDS (columns >= N and the k pad are zeroed)
+    {
+        const int rowsz = NT * 32;
+        const int tot = zc * rowsz * KP;
+        for (int e = tid; e < tot; e += WAVES * 64) wt[e] = 0.f;
+        __syncthreads();
+        const int nel = zc * K * N;
+        for (int e = tid; e < nel; e += WAVES * 64) {
+            int t = e / N, n = e - t * N;
+            int z = t / K, k = t - z * K;
+            wt[(z * rowsz + n) * KP + k] = bl.get(z, k, n);
+        }
+        __syncthreads();
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int NG = K / (2 * KL * PF);            // groups of PF blocks per row (host guarantees exact)
+    const long stride_t = (long)gridDim.x * WAVES;
+    long tile = (long)blockIdx.x * WAVES + wave;
+    if (tile >= total_tiles) return;
+
+    typename AL::RowState rs;
+    typename AL::Frag fr[PF];
+    al.row_init(rs, tile, i, h);
+    al.template prep_group<PF>(rs);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fr[u] = al.template load_one<PF>(rs, u);
+    int zcur = rs.z;
+
+    // one group of PF blocks.  The NEXT group's PF loads are issued first, into a second register
+    // set, and fenced with sched_barrier so the compiler cannot sink them behind the MFMAs (it does,
+    // which exposes the full memory latency once per group); they have the whole group -- PF*KL*NT
+    // MFMAs = 2-4k cycles -- to land.
+    auto body = [&](const typename AL::RowState& src, const float* wb, f32x16 (&acc)[NT]) {
+        typename AL::Frag fn[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fn[u] = al.template load_one<PF>(src, u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            float a[KL];
+            al.convert(fr[u], a);
+#pragma unroll
+            for (int q = 0; q < KL / 4; ++q) {
+                float4 bq[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[nt] = *reinterpret_cast<const float4*>(wb + (long)nt * 32 * KP + u * 2 * KL + q * 4);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q * 4 + 0], bq[nt].x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q * 4 + 1], bq[nt].y, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q * 4 + 2], bq[nt].z, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q * 4 + 3], bq[nt].w, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fr[u] = fn[u];
+    };
+
+    while (true) {
+        const float* wz = wt + ((long)zcur * NT * 32 + i) * KP + h * KL;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int g = 0; g + 1 < NG; ++g) {       // steady state: refill from the same row's next group
+            al.template prep_group<PF>(rs);
+            body(rs, wz + g * (2 * KL * PF), acc);
+        }
+        // last group of this tile: refill from the NEXT tile's first group (clamped to a valid tile so
+        // the loads stay unconditional; the surplus of the final tile is simply never consumed)
+        const long next = tile + stride_t;
+        typename AL::RowState rn;
+        al.row_init(rn, min(next, total_tiles - 1), i, h);
+        al.template prep_group<PF>(rn);
+        body(rn, wz + (NG - 1) * (2 * KL * PF), acc);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ef.store(tile, zcur, (r & 3) + 8 * (r >> 2) + 4 * h, nt * 32 + i, acc[nt][r]);
+        if (next >= total_tiles) break;
+        rs = rn;
+        zcur = rn.z;
+        tile = next;
+    }
+}
+
+inline int wres_kp(int K) { return (K + 63) / 64 * 64 + 4; }
+inline size_t wres_lds_bytes(int zc, int ncols, int K) {
+    return (size_t)zc * ((ncols + 31) / 32 * 32) * wres_kp(K) * sizeof(float);
+}
+
+template <class AL, class BL, class EF, int NT, int PF, int WAVES>
+inline hipError_t launch_wres(const AL& al, const BL& bl, const EF& ef, int zc, int K, int N, long total_tiles,
+                              int num_cus, hipStream_t stream) {
+    const int KP = wres_kp(K);
+    const size_t lds = (size_t)zc * NT * 32 * KP * sizeof(float);
+    auto kern = wres_kernel<AL, BL, EF, NT, PF, WAVES>;
+    static bool raised = false;                // per instantiation
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    long want = (total_tiles + WAVES - 1) / WAVES;
+    int grid = (int)std::min<long>(std::max<long>(want, 1), num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, al, bl, ef, zc, K, N, KP, total_tiles);
+    return hipGetLastError();
+}
+
+}  // namespace mrl

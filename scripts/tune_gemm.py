@@ -17,8 +17,7 @@ from baselines_amd.common.policies import build_policy  # noqa: E402
 from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv  # noqa: E402
 from baselines_amd.ppo2 import Model, Runner  # noqa: E402
 
-VARIANTS = ['128x32', '256x32', '128x64w41', '128x64w22', '256x64', '128x128']
-VARIANTS = VARIANTS + [v + 'db' for v in VARIANTS]
+VARIANTS = [('128x32', 0), ('128x64w41', 2), ('128x64w22', 3), ('128x128', 5), ('wres16', 100), ('wres8', 101)]
 LABELS = ['c1.fwd', 'c2.fwd', 'c3.fwd', 'fc1.fwd', 'c1.wgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad', 'c2.dgrad',
           'c3.dgrad', 'fc1.dgrad']
 
@@ -47,7 +46,7 @@ def main():
             model.train_indexed(2.5e-4, 0.1, ro, inds_dev[s:s + B])
 
     res = {}
-    for v in [-1] + list(range(len(VARIANTS))):
+    for name, v in [('default', -1)] + VARIANTS:
         for lab in LABELS:
             _lib.tune_set(lab, v)
         one_epoch()
@@ -57,7 +56,6 @@ def main():
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         rep = _lib.prof_report()
-        name = 'default' if v < 0 else VARIANTS[v]
         res[name] = {k: dict(ms=d['ms'], tflops=(d['flops'] / d['ms'] / 1e9 if d['flops'] else None)) for k, d in rep.items()}
     labs = sorted({k for r in res.values() for k in r})
     print('%-12s' % 'label' + ''.join('%13s' % n for n in res))
