@@ -51,3 +51,11 @@ def default_comm():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return Comm()
     return None
+
+
+def shard_envs(num_envs, rank, world):
+    """Contiguous environment shard [lo, hi) owned by `rank` (GPU g owns envs
+    [g*N/G, (g+1)*N/G)); remainders go to the lowest ranks so sizes differ by at most one."""
+    base, extra = divmod(int(num_envs), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)

@@ -1,0 +1,134 @@
+"""CPU: the C-ABI shared library loads without a GPU, exports every symbol include/mrl.h declares,
+and its host-only entry points (layout object, error strings) behave.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from baselines_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from baselines_amd.csrc.build import build
+        build(verbose=False)
+    return _lib.load()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'mrl.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mrl_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    names = _declared()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), 'libmrl.so does not export %s' % n
+        assert n in _lib.SIGNATURES, 'no ctypes signature for %s' % n
+    assert set(_lib.SIGNATURES) <= set(names), 'binding lists symbols the header does not declare'
+
+
+def test_version_and_errors(lib):
+    assert lib.mrl_version() == 1
+    assert lib.mrl_strerror(0) == b'ok'
+    assert b'invalid' in lib.mrl_strerror(-1)
+    assert b'workspace' in lib.mrl_strerror(-2)
+    assert b'unsupported' in lib.mrl_strerror(-3)
+
+
+def _layout(lib, **kw):
+    d = _lib.ModelDesc()
+    d.network = kw['network']
+    shape = kw['ob_shape']
+    d.ob_ndim = len(shape)
+    for i, s in enumerate(shape):
+        d.ob_shape[i] = s
+    d.ob_dtype = kw['ob_dtype']
+    d.num_layers, d.num_hidden, d.activation = kw.get('num_layers', 2), kw.get('num_hidden', 64), _lib.ACT_TANH
+    d.value_copy, d.pd_kind, d.nact = kw.get('value_copy', 0), kw['pd_kind'], kw['nact']
+    h = ctypes.c_void_p()
+    rc = lib.mrl_model_create(ctypes.byref(d), ctypes.byref(h))
+    return rc, h
+
+
+def _tensors(lib, h):
+    out = []
+    name = ctypes.create_string_buffer(128)
+    for i in range(lib.mrl_model_num_tensors(h)):
+        nd, shp, off, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_double()
+        assert lib.mrl_model_tensor_info(h, i, name, 128, ctypes.byref(nd), ctypes.byref(shp), ctypes.byref(off),
+                                         ctypes.byref(sc)) == 0
+        out.append((name.value.decode(), tuple(shp[k] for k in range(nd.value)), off.value, sc.value))
+    return out
+
+
+def test_layout_nature_cnn_matches_reference_inventory(lib):
+    """variable names, shapes, creation order, P = 1,687,719 (nA = 6)."""
+    rc, h = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 4), ob_dtype=_lib.OB_U8,
+                    pd_kind=_lib.PD_CATEGORICAL, nact=6)
+    assert rc == 0
+    assert lib.mrl_model_num_params(h) == 1687719
+    t = _tensors(lib, h)
+    assert [x[0] for x in t] == ['ppo2_model/pi/c1/w', 'ppo2_model/pi/c1/b', 'ppo2_model/pi/c2/w', 'ppo2_model/pi/c2/b',
+                                 'ppo2_model/pi/c3/w', 'ppo2_model/pi/c3/b', 'ppo2_model/pi/fc1/w', 'ppo2_model/pi/fc1/b',
+                                 'ppo2_model/pi/w', 'ppo2_model/pi/b', 'ppo2_model/vf/w', 'ppo2_model/vf/b']
+    shapes = dict((x[0], x[1]) for x in t)
+    assert shapes['ppo2_model/pi/c1/w'] == (8, 8, 4, 32) and shapes['ppo2_model/pi/c1/b'] == (1, 32, 1, 1)
+    assert shapes['ppo2_model/pi/c3/w'] == (3, 3, 64, 64) and shapes['ppo2_model/pi/fc1/w'] == (3136, 512)
+    scales = dict((x[0], x[3]) for x in t)
+    assert scales['ppo2_model/pi/c1/w'] == np.sqrt(2) and scales['ppo2_model/pi/w'] == 0.01 and scales['ppo2_model/vf/w'] == 1.0
+    assert scales['ppo2_model/pi/c1/b'] < 0            # zeros
+    offs = [x[2] for x in t]
+    assert offs == sorted(offs) and offs[0] == 0       # flat buffer in creation order
+    assert lib.mrl_model_workspace_bytes(h, 1024) > 1024 * 173000
+    lib.mrl_model_destroy(h)
+
+
+def test_layout_mlp_variants(lib):
+    rc, h = _layout(lib, network=_lib.NET_MLP, ob_shape=(376,), ob_dtype=_lib.OB_F32, pd_kind=_lib.PD_DIAG_GAUSSIAN,
+                    nact=17, value_copy=1)
+    assert rc == 0 and lib.mrl_model_num_params(h) == 57763         # Humanoid-shaped, value_network='copy'
+    names = [x[0] for x in _tensors(lib, h)]
+    assert names.index('ppo2_model/vf/mlp_fc0/w') > names.index('ppo2_model/pi/mlp_fc1/b')
+    assert 'ppo2_model/pi/logstd' in names
+    lib.mrl_model_destroy(h)
+    rc, h = _layout(lib, network=_lib.NET_MLP, ob_shape=(4,), ob_dtype=_lib.OB_F32, pd_kind=_lib.PD_CATEGORICAL, nact=2)
+    assert rc == 0 and lib.mrl_model_num_params(h) == 4675          # CartPole, shared latent
+    lib.mrl_model_destroy(h)
+    # distributions.py:351-355 quirk: latent width == action dim -> no pi head
+    rc, h = _layout(lib, network=_lib.NET_MLP, ob_shape=(8,), ob_dtype=_lib.OB_F32, pd_kind=_lib.PD_DIAG_GAUSSIAN,
+                    nact=17, num_hidden=17)
+    assert rc == 0
+    assert 'ppo2_model/pi/w' not in [x[0] for x in _tensors(lib, h)]
+    lib.mrl_model_destroy(h)
+
+
+def test_layout_rejects_unsupported(lib):
+    rc, _ = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 3), ob_dtype=_lib.OB_U8,
+                    pd_kind=_lib.PD_CATEGORICAL, nact=6)
+    assert rc == -3            # MRL_EUNSUP: channel count must be a multiple of 4
+    rc, _ = _layout(lib, network=_lib.NET_MLP, ob_shape=(4,), ob_dtype=_lib.OB_F32, pd_kind=7, nact=2)
+    assert rc == -3
+
+
+def test_product_has_no_cpu_path():
+    """The package must fail loudly without a HIP device (no oracle / CPU fallback behind it)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError):
+        _lib.require_gpu()
+    src = ''
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'baselines_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src += open(os.path.join(dirpath, f)).read()
+    assert 'import oracle' not in src and 'from oracle' not in src

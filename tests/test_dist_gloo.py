@@ -1,0 +1,130 @@
+"""CPU, world_size 2 over gloo: the data-parallel path of SURVEY.md 8(e) -- contiguous env shards,
+rank-local advantage normalisation, ONE all-reduce(sum) of the flat gradient per minibatch step,
+/ sum of rank weights BEFORE the global-norm clip, replicated Adam, broadcast of the initial state
+(common/mpi_adam_optimizer.py:18-51, common/mpi_util.py:15-26, ppo2/model.py:97-131).
+
+The communicator under test is the product's `baselines_amd.common.dist.Comm` (RCCL on the GPU box,
+gloo here); the arithmetic around it is the oracle's torch-CPU restatement of the TF graph."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORLD = 2
+KW = dict(network='mlp', ob_shape=(11,), ob_dtype=np.float32, pd_kind='gaussian', nact=3, value_network='copy',
+          ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _data(N, T, seed):
+    rng = np.random.RandomState(seed)
+    return dict(obs=rng.randn(N * T, 11).astype(np.float32), returns=rng.randn(N * T).astype(np.float32),
+                actions=rng.randn(N * T, 3).astype(np.float32), values=rng.randn(N * T).astype(np.float32),
+                neglogpacs=(3.0 + 0.1 * rng.randn(N * T)).astype(np.float32))
+
+
+def _worker(rank, port, weights, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    torch.set_num_threads(1)
+    from baselines_amd.common.dist import Comm, default_comm, shard_envs
+    from oracle.ppo2_torch import OracleModel
+    comm = default_comm()
+    assert isinstance(comm, Comm) and comm.Get_size() == WORLD and comm.Get_rank() == rank
+    total_w = comm.total_weight(weights[rank])
+    assert total_w == pytest.approx(sum(weights))
+    # every rank draws the same init stream (Appendix D: set_global_seeds never applies the rank offset);
+    # perturb rank 1 on purpose and let sync_from_root repair it
+    np.random.seed(0)
+    om = OracleModel(**KW)
+    if rank == 1:
+        with torch.no_grad():
+            for p in om.p.values():
+                p.add_(1.0)
+    for p in om.p.values():
+        comm.bcast_(p.data, 0)
+    comm.check_synced(torch.from_numpy(om.flat_params()[:64].copy()).sum().reshape(1))
+    om.allreduce = lambda flat: comm.allreduce_sum_(flat.clone())
+    om.rank_weight, om.total_weight = float(weights[rank]), float(total_w)
+    N, T = 8, 4
+    d = _data(N, T, 123)                                  # the WHOLE job's batch, env-major
+    lo, hi = shard_envs(N, rank, WORLD)
+    rows = np.arange(lo * T, hi * T)                      # this rank's envs (contiguous shard)
+    stats = []
+    for step in range(3):
+        np.random.seed(step)
+        idx = rows[np.random.permutation(len(rows))[:len(rows) // 2 * 2]]
+        stats.append(om.train(3e-4, 0.2, d['obs'][idx], d['returns'][idx], None, d['actions'][idx], d['values'][idx],
+                              d['neglogpacs'][idx]))
+    comm.check_synced(torch.from_numpy(om.flat_params().copy()).sum().reshape(1))
+    out[rank] = (om.flat_params(), np.asarray(stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _emulate(weights):
+    """single-process statement of the same algebra: g = sum_r w_r g_r / sum_r w_r -> clip -> Adam on every replica"""
+    from baselines_amd.common.dist import shard_envs
+    from oracle.ppo2_torch import OracleModel
+    np.random.seed(0)
+    reps = [OracleModel(**KW) for _ in range(WORLD)]
+    for r in reps[1:]:
+        for k in r.p:
+            r.p[k].data.copy_(reps[0].p[k].data)
+    N, T = 8, 4
+    d = _data(N, T, 123)
+    for step in range(3):
+        flats = []
+        for rank, om in enumerate(reps):
+            lo, hi = shard_envs(N, rank, WORLD)
+            rows = np.arange(lo * T, hi * T)
+            np.random.seed(step)
+            idx = rows[np.random.permutation(len(rows))[:len(rows) // 2 * 2]]
+            _, flat = om.compute_grads(0.2, d['obs'][idx], d['returns'][idx], d['actions'][idx], d['values'][idx],
+                                       d['neglogpacs'][idx])
+            flats.append(flat * float(weights[rank]))
+        avg = (flats[0] + flats[1]) / float(sum(weights))
+        for om in reps:
+            om.apply_flat_grad(3e-4, avg.clone())
+    return reps[0].flat_params()
+
+
+@pytest.mark.parametrize('weights', [(1, 1), (1, 3)])
+def test_two_rank_gradient_allreduce_matches_reference_algebra(weights):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(port, weights, out), nprocs=WORLD, join=True)
+    p0, s0 = out[0]
+    p1, s1 = out[1]
+    np.testing.assert_array_equal(p0, p1)                 # replicas stay bit-identical
+    assert not np.array_equal(s0, s1)                     # loss statistics are rank-local (not reduced)
+    ref = _emulate(weights)
+    np.testing.assert_allclose(p0, ref, rtol=0, atol=1e-7)
+
+
+def test_shard_envs_contiguous_cover():
+    from baselines_amd.common.dist import shard_envs
+    for n, w in [(4096, 8), (256, 2), (7, 3), (5, 8)]:
+        spans = [shard_envs(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
