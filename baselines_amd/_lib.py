@@ -53,6 +53,17 @@ SIGNATURES = {
     'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    'mrl_replay_insert': (c_int, [c_void_p] * 5 + [c_long, c_long, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    'mrl_replay_gather': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    'mrl_segtree_init': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    'mrl_segtree_set': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
+    'mrl_segtree_set_ring': (c_int, [c_void_p, c_void_p, c_long, c_long, c_long, c_int, c_double, c_void_p]),
+    'mrl_per_update_from_td': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_double, c_double, c_void_p,
+                                       c_int, c_void_p]),
+    'mrl_per_sample': (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_double, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    'mrl_dqn_td_scratch_bytes': (c_size_t, [c_int]),
+    'mrl_dqn_td': (c_int, [c_void_p] * 7 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     'mrl_tune_set': (c_int, [c_char_p, c_int]),
     'mrl_prof_enable': (c_int, [c_int]),
     'mrl_prof_num_labels': (c_int, []),

@@ -1,0 +1,365 @@
+// DQN replay slice on gfx950: HBM-resident transition ring, float64
+// sum/min segment trees with the reference's heap layout and association order, stratified
+// proportional sampling + importance weights, priority update, double-Q TD target + Huber.
+//
+// Reference map (paths relative to baselines/):
+//   ring           deepq/replay_buffer.py:24-43
+//   trees          common/segment_tree.py:36-86 (reduce order, point update), :105-131 (prefix-sum descent)
+//   PER            deepq/replay_buffer.py:100-115 (add / _sample_proportional), :155-165 (weights),
+//                  :169-191 (update_priorities, sequential => last duplicate wins)
+//   TD + Huber     deepq/build_graph.py:396-413, common/tf_util.py:39-45
+//
+// These are latency / HBM-bound integer+f64 kernels (no MFMA): a 2^20-leaf tree pair is 33.6 MB and
+// stays resident in L2 / Infinity Cache; a batch touches B*21 nodes per tree.  Tree nodes are read and
+// written with agent-scope relaxed atomics (L1 bypass) because a refresh of level L must observe the
+// level L-1 values written by other lanes of the same launch.
+#include <math.h>
+
+#include "common.hip.h"
+
+using namespace mrl;
+
+namespace {
+
+__device__ __forceinline__ double tload(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tstore(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- ring ------------------------------------------------------------------------------------
+// rows (next_idx + j) % maxsize, j < n, 16 B per lane when the row size allows
+template <typename V>
+__global__ __launch_bounds__(256) void ring_rows_kernel(V* __restrict__ dst, const V* __restrict__ src, long maxsize,
+                                                        long next_idx, long n, int rowv) {
+    const long total = n * rowv;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += (long)gridDim.x * 256L) {
+        long j = q / rowv;
+        int c = (int)(q - j * rowv);
+        long slot = (next_idx + j) % maxsize;
+        dst[slot * rowv + c] = src[q];
+    }
+}
+template <typename V>
+__global__ __launch_bounds__(256) void take_rows_kernel(const V* __restrict__ src, const int32_t* __restrict__ idx,
+                                                        V* __restrict__ dst, long B, int rowv) {
+    const long total = B * rowv;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += (long)gridDim.x * 256L) {
+        long b = q / rowv;
+        int c = (int)(q - b * rowv);
+        dst[q] = src[(long)idx[b] * rowv + c];
+    }
+}
+
+static int pick_unit(int row_bytes, const void* a, const void* b) {
+    auto al = [](const void* p, int k) { return ((uintptr_t)p % k) == 0; };
+    if (row_bytes % 16 == 0 && al(a, 16) && al(b, 16)) return 16;
+    if (row_bytes % 4 == 0 && al(a, 4) && al(b, 4)) return 4;
+    return 1;
+}
+static int ring_rows(void* dst, const void* src, long maxsize, long next_idx, long n, int row_bytes, hipStream_t st) {
+    if (n <= 0) return 0;
+    int unit = pick_unit(row_bytes, dst, src), rowv = row_bytes / unit;
+    int blocks = (int)std::min<long>((n * rowv + 255) / 256, 8192);
+    if (unit == 16) hipLaunchKernelGGL(ring_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, maxsize, next_idx, n, rowv);
+    else if (unit == 4) hipLaunchKernelGGL(ring_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (uint32_t*)dst, (const uint32_t*)src, maxsize, next_idx, n, rowv);
+    else hipLaunchKernelGGL(ring_rows_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (uint8_t*)dst, (const uint8_t*)src, maxsize, next_idx, n, rowv);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+static int take_rows(const void* src, const int32_t* idx, void* dst, long B, int row_bytes, hipStream_t st) {
+    if (B <= 0) return 0;
+    int unit = pick_unit(row_bytes, dst, src), rowv = row_bytes / unit;
+    int blocks = (int)std::min<long>((B * rowv + 255) / 256, 8192);
+    if (unit == 16) hipLaunchKernelGGL(take_rows_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, idx, (uint4*)dst, B, rowv);
+    else if (unit == 4) hipLaunchKernelGGL(take_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, idx, (uint32_t*)dst, B, rowv);
+    else hipLaunchKernelGGL(take_rows_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)src, idx, (uint8_t*)dst, B, rowv);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- trees -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tree_fill_kernel(double* __restrict__ sum_tree, double* __restrict__ min_tree, long nodes) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nodes; i += (long)gridDim.x * 256L) {
+        sum_tree[i] = 0.0;                                  // segment_tree.py:33 neutral elements
+        min_tree[i] = INFINITY;
+    }
+}
+
+// Batched point update with the reference's SEQUENTIAL semantics (segment_tree.py:76-86 called in a
+// loop): leaf j is written unless a later entry names the same leaf; then every touched ancestor is
+// recomputed level by level from its two children.  The final tree equals the sequential result
+// because an inner node is always exactly op(left, right) of its current children.
+// One workgroup (levels are separated by __syncthreads); entries are strided over the threads.
+// leaf_mode 0: leaf[j] given (f64); 1: leaf = pow(|td[j]| + eps, alpha) computed here (device pow);
+// ring_mode: idx == nullptr -> leaves (start + j) % maxsize all get leaf_const.
+__global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, double* min_tree, long capacity,
+                                                           const int32_t* __restrict__ idx, const double* __restrict__ leaf,
+                                                           const float* __restrict__ td, double eps, double alpha,
+                                                           double* __restrict__ max_priority, long ring_start,
+                                                           long ring_maxsize, double leaf_const, int n) {
+    __shared__ double smax[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double lmax = 0.0;
+    for (int j = tid; j < n; j += nt) {
+        long i;
+        double v;
+        bool write = true;
+        if (idx) {
+            i = idx[j];
+            if (td) {
+                double p = fabs((double)td[j]) + eps;       // deepq.py:302  new_priorities = |td| + eps
+                v = pow(p, alpha);
+                lmax = fmax(lmax, p);
+            } else {
+                v = leaf[j];
+            }
+            for (int k = j + 1; k < n; ++k)
+                if (idx[k] == i) { write = false; break; }   // a later duplicate wins
+        } else {
+            i = (ring_start + j) % ring_maxsize;
+            v = leaf_const;
+            // a wrapped ring range cannot name a slot twice unless n > maxsize (rejected on the host)
+        }
+        if (write) {
+            tstore(sum_tree + capacity + i, v);
+            tstore(min_tree + capacity + i, v);
+        }
+    }
+    if (td && max_priority) {                                // replay_buffer.py:191 running max
+        smax[tid] = lmax;
+        __syncthreads();
+        for (int s = nt >> 1; s > 0; s >>= 1) {
+            if (tid < s) smax[tid] = fmax(smax[tid], smax[tid + s]);
+            __syncthreads();
+        }
+        if (tid == 0) max_priority[0] = fmax(max_priority[0], smax[0]);
+    }
+    __syncthreads();
+    for (long width = capacity >> 1, shift = 1; width >= 1; width >>= 1, ++shift) {
+        for (int j = tid; j < n; j += nt) {
+            long i = idx ? (long)idx[j] : (ring_start + j) % ring_maxsize;
+            long node = (capacity + i) >> shift;
+            double a = tload(sum_tree + 2 * node), b = tload(sum_tree + 2 * node + 1);
+            tstore(sum_tree + node, __dadd_rn(a, b));
+            double c = tload(min_tree + 2 * node), d = tload(min_tree + 2 * node + 1);
+            tstore(min_tree + node, d < c ? d : c);          // python min(a, b): b only if b < a
+        }
+        __syncthreads();
+    }
+}
+
+// reduce(0, end_excl) of the sum tree with the reference's association order (segment_tree.py:36-49):
+// a PREFIX query descends from the root; whenever it continues into a right child the left sibling's
+// value is combined as op(left, rest) -- i.e. the result is left_k + (left_{k+1} + (... + deepest)).
+__device__ double sum_prefix(const double* tree, long capacity, long end_incl) {
+    // path: record the left siblings met on the way down, then fold from the deepest node upward
+    long node = 1, lo = 0, hi = capacity - 1;
+    (void)lo;
+    double sib[64];
+    int ns = 0;
+    while (end_incl != hi) {                                 // stop when the (prefix) query covers the node exactly
+        long mid = (lo + hi) >> 1;
+        if (end_incl <= mid) {
+            node = 2 * node; hi = mid;
+        } else {                                             // split: full left child + prefix of the right child
+            sib[ns++] = tload(tree + 2 * node);
+            node = 2 * node + 1; lo = mid + 1;
+        }
+    }
+    double acc = tload(tree + node);
+    for (int k = ns - 1; k >= 0; --k) acc = __dadd_rn(sib[k], acc);
+    return acc;
+}
+
+// stratified proportional sampling + importance weights (replay_buffer.py:107-115, 155-165)
+__global__ __launch_bounds__(256) void per_sample_kernel(const double* sum_tree, const double* min_tree, long capacity,
+                                                         long length, int B, const double* __restrict__ uniforms,
+                                                         double beta, int32_t* __restrict__ idx_out,
+                                                         double* __restrict__ w_out, float* __restrict__ w32_out) {
+    __shared__ double s_total, s_all, s_maxw;
+    if (threadIdx.x == 0 && blockIdx.x >= 0) {
+        s_total = sum_prefix(sum_tree, capacity, length - 2);       // sum(0, len-1): newest element excluded (quirk)
+        s_all = tload(sum_tree + 1);                                 // sum()
+        double p_min = tload(min_tree + 1) / s_all;                  // min() / sum()
+        s_maxw = pow(p_min * (double)length, -beta);
+    }
+    __syncthreads();
+    const double every = s_total / (double)B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256) {
+        double mass = __dadd_rn(__dmul_rn(uniforms[i], every), __dmul_rn((double)i, every));
+        long node = 1;
+        while (node < capacity) {
+            double left = tload(sum_tree + 2 * node);
+            if (left > mass) node = 2 * node;
+            else { mass = __dsub_rn(mass, left); node = 2 * node + 1; }
+        }
+        long leaf = node - capacity;
+        idx_out[i] = (int32_t)leaf;
+        double p_sample = tload(sum_tree + node) / s_all;
+        double w = pow(p_sample * (double)length, -beta) / s_maxw;
+        if (w_out) w_out[i] = w;
+        if (w32_out) w32_out[i] = (float)w;
+    }
+}
+
+// double-Q TD target, Huber(delta=1), importance-weighted mean and its gradient w.r.t. q_t
+__global__ __launch_bounds__(256) void dqn_td_kernel(const float* __restrict__ q_t, const float* __restrict__ q_tp1,
+                                                     const float* __restrict__ q_tp1_online, const int32_t* __restrict__ act,
+                                                     const float* __restrict__ rew, const float* __restrict__ done,
+                                                     const float* __restrict__ w, float gamma, int B, int nA,
+                                                     float* __restrict__ td_out, float* __restrict__ dq_out,
+                                                     double* __restrict__ part) {
+    __shared__ double sh[4];
+    double lsum = 0.0;
+    const float invB = 1.f / (float)B;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        const float* qn = q_tp1 + (long)b * nA;
+        const float* sel = q_tp1_online ? q_tp1_online + (long)b * nA : qn;
+        int best = 0;
+        float bv = sel[0];
+        for (int j = 1; j < nA; ++j)
+            if (sel[j] > bv) { bv = sel[j]; best = j; }      // first max wins (tf.argmax / reduce_max)
+        const float q_best = qn[best];
+        const float masked = (1.f - done[b]) * q_best;
+        const float target = rew[b] + gamma * masked;
+        const int a = act[b];
+        const float td = q_t[(long)b * nA + a] - target;
+        td_out[b] = td;
+        const float ad = fabsf(td);
+        const float hub = ad < 1.f ? 0.5f * td * td : (ad - 0.5f);
+        const float wb = w ? w[b] : 1.f;
+        lsum += (double)(wb * hub);
+        if (dq_out) {
+            const float g = wb * (ad < 1.f ? td : (td > 0.f ? 1.f : -1.f)) * invB;
+            for (int j = 0; j < nA; ++j) dq_out[(long)b * nA + j] = (j == a) ? g : 0.f;
+        }
+    }
+    double t = block_sum_256(lsum, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void dqn_td_final_kernel(const double* __restrict__ part, int nblk, int B, float* __restrict__ loss_out) {
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nblk; ++i) s += part[i];
+        loss_out[0] = (float)(s / (double)B);
+    }
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" int mrl_replay_insert(void* obs_t_buf, void* obs_tp1_buf, int32_t* act_buf, float* rew_buf, float* done_buf,
+                                 long maxsize, long next_idx, int n, int ob_bytes, const void* obs_t,
+                                 const void* obs_tp1, const int32_t* act, const float* rew, const float* done,
+                                 void* stream) {
+    if (!obs_t_buf || !obs_tp1_buf || !act_buf || !rew_buf || !done_buf || !obs_t || !obs_tp1 || !act || !rew || !done)
+        return MRL_EINVAL;
+    if (maxsize <= 0 || next_idx < 0 || next_idx >= maxsize || n < 0 || n > maxsize || ob_bytes <= 0) return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("replay_insert", 0.0, 2.0 * n * (2.0 * ob_bytes + 12.0), st);
+    int rc;
+    if ((rc = ring_rows(obs_t_buf, obs_t, maxsize, next_idx, n, ob_bytes, st))) return rc;
+    if ((rc = ring_rows(obs_tp1_buf, obs_tp1, maxsize, next_idx, n, ob_bytes, st))) return rc;
+    if ((rc = ring_rows(act_buf, act, maxsize, next_idx, n, 4, st))) return rc;
+    if ((rc = ring_rows(rew_buf, rew, maxsize, next_idx, n, 4, st))) return rc;
+    return ring_rows(done_buf, done, maxsize, next_idx, n, 4, st);
+}
+
+extern "C" int mrl_replay_gather(const void* obs_t_buf, const void* obs_tp1_buf, const int32_t* act_buf,
+                                 const float* rew_buf, const float* done_buf, const int32_t* idx, int B, int ob_bytes,
+                                 void* obs_t_out, void* obs_tp1_out, int32_t* act_out, float* rew_out, float* done_out,
+                                 void* stream) {
+    if (!obs_t_buf || !obs_tp1_buf || !act_buf || !rew_buf || !done_buf || !idx || !obs_t_out || !obs_tp1_out ||
+        !act_out || !rew_out || !done_out || B < 0 || ob_bytes <= 0)
+        return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("replay_gather", 0.0, 2.0 * B * (2.0 * ob_bytes + 12.0) + 4.0 * B, st);
+    int rc;
+    if ((rc = take_rows(obs_t_buf, idx, obs_t_out, B, ob_bytes, st))) return rc;
+    if ((rc = take_rows(obs_tp1_buf, idx, obs_tp1_out, B, ob_bytes, st))) return rc;
+    if ((rc = take_rows(act_buf, idx, act_out, B, 4, st))) return rc;
+    if ((rc = take_rows(rew_buf, idx, rew_out, B, 4, st))) return rc;
+    return take_rows(done_buf, idx, done_out, B, 4, st);
+}
+
+static bool pow2(long c) { return c > 0 && (c & (c - 1)) == 0; }
+
+extern "C" int mrl_segtree_init(double* sum_tree, double* min_tree, long capacity, void* stream) {
+    if (!sum_tree || !min_tree || !pow2(capacity)) return MRL_EINVAL;
+    long nodes = 2 * capacity;
+    int blocks = (int)std::min<long>((nodes + 255) / 256, 4096);
+    hipLaunchKernelGGL(tree_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sum_tree, min_tree, nodes);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int tree_update(double* sum_tree, double* min_tree, long capacity, const int32_t* idx, const double* leaf,
+                       const float* td, double eps, double alpha, double* max_priority, long ring_start,
+                       long ring_maxsize, double leaf_const, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    int threads = n >= 1024 ? 1024 : (n > 256 ? 512 : 256);
+    ProfScope ps("segtree_update", 0.0, 2.0 * n * 16.0 * 21.0, st);
+    hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(threads), 0, st, sum_tree, min_tree, capacity, idx, leaf, td, eps,
+                       alpha, max_priority, ring_start, ring_maxsize, leaf_const, n);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrl_segtree_set(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,
+                               const double* leaf, int n, void* stream) {
+    if (!sum_tree || !min_tree || !pow2(capacity) || !idx || !leaf || n < 0) return MRL_EINVAL;
+    return tree_update(sum_tree, min_tree, capacity, idx, leaf, nullptr, 0.0, 0.0, nullptr, 0, 1, 0.0, n, (hipStream_t)stream);
+}
+
+extern "C" int mrl_segtree_set_ring(double* sum_tree, double* min_tree, long capacity, long start, long maxsize, int n,
+                                    double leaf, void* stream) {
+    if (!sum_tree || !min_tree || !pow2(capacity) || maxsize <= 0 || maxsize > capacity || start < 0 || start >= maxsize ||
+        n < 0 || n > maxsize)
+        return MRL_EINVAL;
+    return tree_update(sum_tree, min_tree, capacity, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr, start, maxsize, leaf, n,
+                       (hipStream_t)stream);
+}
+
+extern "C" int mrl_per_update_from_td(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,
+                                      const float* td, double eps, double alpha, double* max_priority, int n,
+                                      void* stream) {
+    if (!sum_tree || !min_tree || !pow2(capacity) || !idx || !td || !max_priority || n < 0) return MRL_EINVAL;
+    return tree_update(sum_tree, min_tree, capacity, idx, nullptr, td, eps, alpha, max_priority, 0, 1, 0.0, n,
+                       (hipStream_t)stream);
+}
+
+extern "C" int mrl_per_sample(const double* sum_tree, const double* min_tree, long capacity, long length, int B,
+                              const double* uniforms, double beta, int32_t* idx_out, double* weights_out,
+                              float* weights_f32_out, void* stream) {
+    if (!sum_tree || !min_tree || !pow2(capacity) || !uniforms || !idx_out || B <= 0) return MRL_EINVAL;
+    if (length < 2 || length > capacity || !(beta > 0.0)) return MRL_EINVAL;   // len 1 recurses forever in the reference
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("per_sample", 0.0, (double)B * (21.0 * 8.0 + 8.0 + 16.0), st);
+    // one workgroup computes p_total etc. per block: keep it to a single block up to 1024 samples per
+    // 256 threads stride; larger batches use more blocks (each recomputes the three scalars: 60 loads)
+    int blocks = std::max(1, std::min((B + 255) / 256, 256));
+    hipLaunchKernelGGL(per_sample_kernel, dim3(blocks), dim3(256), 0, st, sum_tree, min_tree, capacity, length, B,
+                       uniforms, beta, idx_out, weights_out, weights_f32_out);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t mrl_dqn_td_scratch_bytes(int B) { return (size_t)std::max(1, std::min((B + 255) / 256, 1024)) * sizeof(double); }
+
+extern "C" int mrl_dqn_td(const float* q_t, const float* q_tp1_target, const float* q_tp1_online, const int32_t* act,
+                          const float* rew, const float* done, const float* weights, float gamma, int B, int nA,
+                          float* td_out, float* loss_out, float* dq_out, void* scratch, void* stream) {
+    if (!q_t || !q_tp1_target || !act || !rew || !done || !td_out || !loss_out || !scratch || B <= 0 || nA <= 0)
+        return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = std::max(1, std::min((B + 255) / 256, 1024));
+    ProfScope ps("dqn_td", 0.0, (double)B * ((q_tp1_online ? 12.0 : 8.0) * nA + 24.0 + (dq_out ? 4.0 * nA : 0.0)), st);
+    hipLaunchKernelGGL(dqn_td_kernel, dim3(blocks), dim3(256), 0, st, q_t, q_tp1_target, q_tp1_online, act, rew, done,
+                       weights, gamma, B, nA, td_out, dq_out, (double*)scratch);
+    MRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dqn_td_final_kernel, dim3(1), dim3(64), 0, st, (const double*)scratch, blocks, B, loss_out);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}

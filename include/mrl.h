@@ -117,6 +117,54 @@ int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, 
                        float beta1, float beta2, float eps, float max_grad_norm,
                        float total_weight, float* gnorm_out, void* scratch, void* stream);
 
+/* ---- K13: HBM replay ring --- deepq/replay_buffer.py:24-43 ----------------------------------
+ * SoA ring buffers [maxsize][...]: obs_t / obs_tp1 raw bytes (ob_bytes per transition), act int32,
+ * rew f32, done f32.  insert: rows (next_idx + j) % maxsize, j < n, from contiguous batches.
+ * gather: rows idx[b] (int32) into contiguous outputs (`_encode_sample`). */
+int mrl_replay_insert(void* obs_t_buf, void* obs_tp1_buf, int32_t* act_buf, float* rew_buf, float* done_buf,
+                      long maxsize, long next_idx, int n, int ob_bytes, const void* obs_t,
+                      const void* obs_tp1, const int32_t* act, const float* rew, const float* done,
+                      void* stream);
+int mrl_replay_gather(const void* obs_t_buf, const void* obs_tp1_buf, const int32_t* act_buf,
+                      const float* rew_buf, const float* done_buf, const int32_t* idx, int B, int ob_bytes,
+                      void* obs_t_out, void* obs_tp1_out, int32_t* act_out, float* rew_out, float* done_out,
+                      void* stream);
+
+/* ---- K14: sum / min segment trees --- common/segment_tree.py:4-145 --------------------------
+ * f64 arrays of 2*capacity nodes, heap layout (node 1 = root, leaves at [capacity, 2*capacity)),
+ * capacity a power of two; neutral elements 0.0 / +inf.  All updates have the reference's SEQUENTIAL
+ * semantics (with duplicate leaves the last entry wins) and every ancestor is op(left, right).
+ *   mrl_segtree_set       leaf values given (host computes priority**alpha with Python-float pow
+ *                         for bit parity: deepq/replay_buffer.py:100-105, 169-191)
+ *   mrl_segtree_set_ring  n consecutive ring slots from `start` (mod maxsize) all get `leaf`
+ *                         (PrioritizedReplayBuffer.add of a batch: max_priority**alpha)
+ *   mrl_per_update_from_td  device fast path: leaf = pow(|td|+eps, alpha) (ocml pow, <= 2 ulp off
+ *                         libm) and *max_priority = max(*max_priority, |td|+eps)  (deepq.py:302) */
+int mrl_segtree_init(double* sum_tree, double* min_tree, long capacity, void* stream);
+int mrl_segtree_set(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,
+                    const double* leaf, int n, void* stream);
+int mrl_segtree_set_ring(double* sum_tree, double* min_tree, long capacity, long start, long maxsize, int n,
+                         double leaf, void* stream);
+int mrl_per_update_from_td(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,
+                           const float* td, double eps, double alpha, double* max_priority, int n,
+                           void* stream);
+/* stratified proportional sampling + importance weights --- deepq/replay_buffer.py:107-115, 155-165
+ * uniforms f64 [B] are the `random.random()` draws; p_total = sum(0, length-1) EXCLUDES the newest
+ * element (reference quirk, segment_tree.py:69-74); idx_out int32 [B] bit-exact vs the reference;
+ * weights_out f64 [B] and/or weights_f32_out may be NULL.  length >= 2 (the reference recurses
+ * forever on 1). */
+int mrl_per_sample(const double* sum_tree, const double* min_tree, long capacity, long length, int B,
+                   const double* uniforms, double beta, int32_t* idx_out, double* weights_out,
+                   float* weights_f32_out, void* stream);
+
+/* ---- K15: double-Q TD target + Huber --- deepq/build_graph.py:396-413, common/tf_util.py:39-45
+ * q_* f32 [B][nA]; q_tp1_online == NULL: plain max over the target net.  td_out f32 [B];
+ * loss_out f32 [1] = mean(w * huber(td)); dq_out (may be NULL) f32 [B][nA] = d loss / d q_t. */
+size_t mrl_dqn_td_scratch_bytes(int B);
+int mrl_dqn_td(const float* q_t, const float* q_tp1_target, const float* q_tp1_online, const int32_t* act,
+               const float* rew, const float* done, const float* weights, float gamma, int B, int nA,
+               float* td_out, float* loss_out, float* dq_out, void* scratch, void* stream);
+
 /* ---- synthetic device-resident VecEnv (bench/test data source) ----------------------------
  * Stands where gym environments stand in the reference (common/vec_env/): lock-step stepping with
  * AUTO-RESET on done (subproc_vec_env.py:8-12) and Monitor-style episode bookkeeping

@@ -46,3 +46,94 @@ def test_explained_variance(golden_dir):
     g = np.load(os.path.join(golden_dir, 'misc.npz'))
     assert O.explained_variance(g['ev_ypred'], g['ev_y']) == float(g['ev'])
     assert np.isnan(O.explained_variance(np.zeros(4, np.float32), np.ones(4, np.float32)))
+
+
+# ---------------------------------------------------------------- DQN replay slice (rows d1-d5)
+from oracle import replay_numpy as R   # noqa: E402
+
+
+def test_segment_tree_stream_matches_reference(golden_dir):
+    log = np.load(os.path.join(golden_dir, 'segment_tree.npz'))['log']
+    st, mt = R.SumSegmentTree(16), R.MinSegmentTree(16)
+    for i, v, a, b, ssum, smin, ps, found in log:
+        st[int(i)] = v
+        mt[int(i)] = v
+        assert st.sum(int(a), int(b)) == ssum            # bit-exact (same association order)
+        assert mt.min(int(a), int(b)) == smin
+        assert st.find_prefixsum_idx(ps) == int(found)
+
+
+def test_segment_tree_known_answers():
+    """the reference's own known-answer tests (common/tests/test_segment_tree.py:6-95), restated"""
+    t = R.SumSegmentTree(4)
+    t[2] = 1.0
+    t[3] = 3.0
+    assert np.isclose(t.sum(), 4.0) and np.isclose(t.sum(0, 2), 0.0) and np.isclose(t.sum(0, 3), 1.0)
+    assert np.isclose(t.sum(2, 3), 1.0) and np.isclose(t.sum(2, -1), 1.0) and np.isclose(t.sum(2, 4), 4.0)
+    t = R.SumSegmentTree(4)
+    t[2] = 1.0
+    t[3] = 3.0
+    assert [t.find_prefixsum_idx(x) for x in (0.0, 0.5, 0.99, 1.01, 3.0, 4.0)] == [2, 2, 2, 3, 3, 3]
+    t = R.SumSegmentTree(4)
+    for i, v in enumerate([0.5, 1.0, 1.0, 3.0]):
+        t[i] = v
+    assert [t.find_prefixsum_idx(x) for x in (0.0, 0.55, 0.99, 1.51, 3.0, 5.50)] == [0, 1, 1, 2, 3, 3]
+    m = R.MinSegmentTree(4)
+    m[0] = 1.0
+    m[2] = 0.5
+    m[3] = 3.0
+    assert np.isclose(m.min(), 0.5) and np.isclose(m.min(0, 2), 1.0) and np.isclose(m.min(2, 4), 0.5)
+    assert np.isclose(m.min(3, 4), 3.0) and np.isclose(m.min(0, -1), 0.5)
+
+
+def test_prioritized_replay_matches_reference_run(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'replay.npz'))
+    buf = R.PrioritizedReplayBuffer(int(g['cap']), float(g['alpha']))
+    batch = int(g['batch'])
+    by_i = {int(g['s%d_i' % j]): j for j in range(int(g['nsamples']))}
+    for i in range(len(g['add_act'])):
+        buf.add(g['add_obs'][i], np.array(g['add_act'][i]), float(g['add_rew'][i]), g['add_obs2'][i], float(g['add_done'][i]))
+        if i in by_i:
+            j = by_i[i]
+            out = buf.sample(batch, float(g['s%d_beta' % j]), g['s%d_u' % j])
+            obs_t, act, rew, obs_tp1, done, w, idx = out
+            np.testing.assert_array_equal(np.asarray(idx), g['s%d_idx' % j])
+            np.testing.assert_array_equal(w, g['s%d_w' % j])                 # f64, bit-exact
+            np.testing.assert_array_equal(obs_t, g['s%d_obs_t' % j])
+            np.testing.assert_array_equal(obs_tp1, g['s%d_obs_tp1' % j])
+            np.testing.assert_array_equal(act, g['s%d_act' % j])
+            np.testing.assert_array_equal(rew, g['s%d_rew' % j])
+            np.testing.assert_array_equal(done, g['s%d_done' % j])
+            buf.update_priorities(idx, g['s%d_newp' % j])
+    np.testing.assert_array_equal(buf.it_sum.value, g['final_sum_tree'])
+    np.testing.assert_array_equal(buf.it_min.value, g['final_min_tree'])
+    assert buf.max_priority == float(g['final_max_priority'])
+
+
+def test_linear_schedule(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'misc.npz'))
+    got = [R.linear_schedule(t, 1000, 0.02, 1.0) for t in (0, 1, 500, 999, 1000, 5000)]
+    np.testing.assert_array_equal(np.array(got), g['linsched'])
+
+
+def test_dqn_td_against_torch_autograd():
+    import torch
+    rng = np.random.RandomState(0)
+    B, nA = 64, 6
+    q_t, q1, q2 = (rng.randn(B, nA).astype(np.float32) * 2 for _ in range(3))
+    a = rng.randint(0, nA, B)
+    r = rng.randn(B).astype(np.float32)
+    d = (rng.rand(B) < 0.2).astype(np.float32)
+    w = rng.rand(B).astype(np.float32) + 0.1
+    td, loss, dq = R.dqn_td(q_t, q1, q2, a, r, d, w, 0.99)
+    tq = torch.tensor(q_t, requires_grad=True)
+    sel = tq[torch.arange(B), torch.tensor(a)]
+    best = torch.tensor(q2).argmax(1)
+    tgt = torch.tensor(r) + 0.99 * (1 - torch.tensor(d)) * torch.tensor(q1)[torch.arange(B), best]
+    tdt = sel - tgt
+    hub = torch.where(tdt.abs() < 1, 0.5 * tdt * tdt, tdt.abs() - 0.5)
+    lt = (torch.tensor(w) * hub).mean()
+    lt.backward()
+    np.testing.assert_allclose(td, tdt.detach().numpy(), atol=1e-6)
+    np.testing.assert_allclose(loss, float(lt), rtol=1e-6)
+    np.testing.assert_allclose(dq, tq.grad.numpy(), atol=1e-7)
