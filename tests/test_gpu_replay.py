@@ -67,7 +67,8 @@ def test_segtree_batched_update_equals_sequential(cap, n):
         for i, v in zip(idx, val):
             st[int(i)] = float(v)
             mt[int(i)] = float(v)
-        check(lib.mrl_segtree_set(ptr(ds), ptr(dm), cap, ptr(_dev(idx)), ptr(_dev(val)), b, stream_ptr()))
+        idx_d, val_d = _dev(idx), _dev(val)            # keep the temporaries alive across the launch
+        check(lib.mrl_segtree_set(ptr(ds), ptr(dm), cap, ptr(idx_d), ptr(val_d), b, stream_ptr()))
         done += b
     np.testing.assert_array_equal(ds.cpu().numpy(), st.value)
     np.testing.assert_array_equal(dm.cpu().numpy(), mt.value)
@@ -79,7 +80,8 @@ def test_segtree_batched_update_equals_sequential(cap, n):
         want = [st.find_prefixsum_idx(float(x) * (p_total / B) + i * (p_total / B)) for i, x in enumerate(u)]
         idx = torch.empty(B, dtype=torch.int32, device='cuda')
         w = torch.empty(B, dtype=torch.float64, device='cuda')
-        check(lib.mrl_per_sample(ptr(ds), ptr(dm), cap, length, B, ptr(_dev(u)), 0.7, ptr(idx), ptr(w), ptr(None), stream_ptr()))
+        u_d = _dev(u)
+        check(lib.mrl_per_sample(ptr(ds), ptr(dm), cap, length, B, ptr(u_d), 0.7, ptr(idx), ptr(w), ptr(None), stream_ptr()))
         np.testing.assert_array_equal(idx.cpu().numpy(), np.asarray(want, np.int32))
         tot = st.sum()
         maxw = ((mt.min() / tot) * length) ** (-0.7)
