@@ -1,0 +1,297 @@
+// "Image-resident" fp32-MFMA weight-gradient kernel for gfx950 (MI355X): the third GEMM engine of
+// libmrl, for the conv layers' dW / db (tf.gradients of a2c/utils.py:37-56 `conv`).
+//
+//   dW[(ky,kx,c)][n] = sum over (b, oy, ox) of  X[b, oy*s+ky, ox*s+kx, c] * dz[b, oy, ox, n]
+//   db[n]            = sum over (b, oy, ox) of  dz[b, oy, ox, n]
+//
+// The reduction dimension (batch x pixels) is huge and both operands are streamed once, the output is
+// tiny (256x32 ... 576x64).  The tiled kernel spends its time gathering 4-byte im2col fragments from
+// global memory (c1.wgrad: 41 % MFMA utilisation, profiles/r01b_pmc_*).  Here instead:
+//   * one persistent workgroup per CU owns whole IMAGES: the raw input image (28 KB u8 / 51 KB f32) and
+//     its dz map are copied into LDS with fully coalesced 16-byte loads -- 160 KB of LDS holds two
+//     such stages, so the next image streams in (global -> VGPR -> LDS) while the current one is consumed;
+//   * im2col happens in the LDS ADDRESS: conv-k tile t of 32 rows is 32 consecutive elements of an input
+//     row, so the MFMA A operand of lane (i, h) for pixel p is Xs[rowbase(p) + i] -- one conflict-free
+//     ds_read (u8 or b32) per MFMA with a compile-time offset, no index arithmetic at run time
+//     (geometry is a template parameter; the whole pixel loop is unrolled);
+//   * every wave keeps its TMW x TNW accumulator tiles in registers for the kernel's lifetime; one barrier
+//     per image; partial sums leave as one slab per workgroup, combined in fixed order by reduce_slabs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+
+namespace mrl {
+
+template <bool U8, int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TMW, int TNW>
+struct ImgResCfg {
+    static constexpr int OH = (H - RF) / STRIDE + 1, OW = (W - RF) / STRIDE + 1;
+    static constexpr int NPIX = OH * OW, NSTEP = (NPIX + 1) / 2;
+    static constexpr int ROWK = RF * C, K = RF * RF * C;
+    static constexpr int MT = K / 32, NTN = NF / 32;
+    static constexpr int NT = WAVES * 64;
+    static constexpr int XBYTES = (U8 ? 1 : 4) * H * W * C;
+    static constexpr int XV = XBYTES / 16;                         // 16-byte vectors per image
+    static constexpr int DZV = NPIX * NF / 4;                      // float4 per dz map
+    static constexpr int DZ_FLOATS = (NPIX + (NPIX & 1)) * NF;     // + one zero pixel when NPIX is odd
+    static constexpr int STAGE_BYTES = XBYTES + DZ_FLOATS * 4;
+    static constexpr int NXV = (XV + NT - 1) / NT, NDV = (DZV + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES;
+    static_assert(K % 32 == 0 && ROWK % 32 == 0 && NF % 32 == 0, "32-wide MFMA tiles");
+    static_assert(WAVES * TMW * TNW == MT * NTN, "waves x tiles must cover the output exactly");
+    static_assert(NTN % TNW == 0 && XBYTES % 16 == 0 && (NPIX * NF) % 4 == 0 && (NT * 4) % NF == 0, "layout");
+    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's LDS");
+    // element offset of output pixel p's patch origin inside the image
+    static constexpr int a_off(int p) { return ((p / OW) * STRIDE * W + (p % OW) * STRIDE) * C; }
+};
+
+template <bool U8, int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TMW, int TNW, int NACC>
+__global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __restrict__ x,
+                                                                   const int32_t* __restrict__ srow,
+                                                                   const float* __restrict__ dz, int B,
+                                                                   float* __restrict__ part) {
+    using G = ImgResCfg<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    // this wave's tiles: TNW consecutive n tiles x TMW consecutive m tiles
+    constexpr int NGRP = G::NTN / TNW;                 // n groups
+    const int mt0 = (wave / NGRP) * TMW, nt0 = (wave % NGRP) * TNW;
+
+    // NACC independent accumulator sets (pixel steps are dealt round-robin, summed at the end): dependent
+    // MFMAs on ONE accumulator do not sustain the 64-cycle issue rate, a wave needs >= 2-4 chains
+    f32x16 acc[NACC][TMW][TNW];
+#pragma unroll
+    for (int u = 0; u < NACC; ++u)
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][a][b][r] = 0.f;
+    float4 bias4 = f4zero();                           // this thread's 4 dz columns, all its loads
+
+    // zero the pad pixel of both stages once
+    if (G::NPIX & 1) {
+        for (int e = tid; e < 2 * NF; e += G::NT) {
+            int st = e / NF, n = e - st * NF;
+            reinterpret_cast<float*>(lds + st * G::STAGE_BYTES + G::XBYTES)[G::NPIX * NF + n] = 0.f;
+        }
+    }
+
+    // ---- streaming copy of the NEXT image into the other stage, one 16-byte vector per thread per
+    // "chunk" (chunks 0..NXV-1: image, NXV..NCHUNK-1: dz map).  A chunk is loaded into one of two
+    // register slots and written to LDS two chunk-slots later, so only 8 VGPRs are held across the MFMA
+    // stream (holding the whole 79 KB stage in registers made the compiler spill and serialise the loads).
+    constexpr int NCHUNK = G::NXV + G::NDV;
+    const uint4* gx = nullptr;
+    const float4* gd = nullptr;
+    auto set_src = [&](int bb) {
+        const long img = srow ? (long)srow[bb] : (long)bb;
+        gx = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(x) + img * G::XBYTES);
+        gd = reinterpret_cast<const float4*>(dz + (long)bb * G::NPIX * NF);
+    };
+    auto load_chunk = [&](int c) -> uint4 {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (c < G::NXV) {
+            const int e = tid + c * G::NT;
+            if (e < G::XV) v = gx[e];
+        } else {
+            const int e = tid + (c - G::NXV) * G::NT;
+            if (e < G::DZV) {
+                const float4 f = gd[e];
+                v = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+            }
+        }
+        return v;
+    };
+    auto store_chunk = [&](int c, const uint4& v, int st) {
+        if (c < G::NXV) {
+            const int e = tid + c * G::NT;
+            if (e < G::XV) reinterpret_cast<uint4*>(lds + st * G::STAGE_BYTES)[e] = v;
+        } else {
+            const int e = tid + (c - G::NXV) * G::NT;
+            if (e < G::DZV) reinterpret_cast<uint4*>(lds + st * G::STAGE_BYTES + G::XBYTES)[e] = v;
+            bias4.x += __uint_as_float(v.x); bias4.y += __uint_as_float(v.y);     // zeros beyond the map
+            bias4.z += __uint_as_float(v.z); bias4.w += __uint_as_float(v.w);
+        }
+    };
+
+    int b = blockIdx.x;
+    if (b < B) {                                       // first image: plain copy
+        set_src(b);
+        for (int c = 0; c < NCHUNK; ++c) store_chunk(c, load_chunk(c), 0);
+    }
+    __syncthreads();
+    int stage = 0;
+    for (; b < B; b += gridDim.x) {
+        const int bn = b + gridDim.x;
+        const bool more = bn < B;
+        if (more) set_src(bn);
+        const uint8_t* xs8 = lds + stage * G::STAGE_BYTES;
+        const float* xs32 = reinterpret_cast<const float*>(xs8);
+        const float* dzs = reinterpret_cast<const float*>(lds + stage * G::STAGE_BYTES + G::XBYTES) + nt0 * 32 + i + h * NF;
+        // per-lane element base of each m tile: conv-k tile t starts at (ky = t*32/ROWK, in-row offset (t*32)%ROWK)
+        int abase[TMW];
+#pragma unroll
+        for (int a = 0; a < TMW; ++a) {
+            const int t = mt0 + a;
+            abase[a] = ((t * 32) / G::ROWK) * W * C + (t * 32) % G::ROWK + i;
+        }
+        // Explicit operand pipeline, D steps deep: the ds_reads of step s+D are issued before the MFMAs of
+        // step s (and, for u8, the /255 conversion of step s+1 runs under them); sched_barrier pins it.
+        constexpr int D = 4;
+        uint32_t raw[D][TMW];                 // u8: the byte (converted one step before use);  f32: operand bits
+        float fb[D][TNW];
+        float cur[TMW];
+        uint4 creg[2];
+        // xo / dzo: element offsets of the current block (image row pair) -- 0 for the fully unrolled form
+        auto issue = [&](int s, int slot, int xo, int dzo) {
+            const int A0 = G::a_off(2 * s < G::NPIX ? 2 * s : 0);
+            const int A1 = (2 * s + 1 < G::NPIX) ? G::a_off(2 * s + 1) : A0;
+            const int ao = (h ? A1 : A0) + xo;
+#pragma unroll
+            for (int a = 0; a < TMW; ++a) {
+                if constexpr (U8) raw[slot][a] = xs8[abase[a] + ao];
+                else raw[slot][a] = __float_as_uint(xs32[abase[a] + ao]);
+            }
+#pragma unroll
+            for (int c = 0; c < TNW; ++c) fb[slot][c] = dzs[dzo + 2 * s * NF + c * 32];
+        };
+        auto convert = [&](int slot, float (&dst)[TMW]) {
+#pragma unroll
+            for (int a = 0; a < TMW; ++a) {
+                if constexpr (U8) dst[a] = u8_over_255((float)raw[slot][a]);
+                else dst[a] = __uint_as_float(raw[slot][a]);
+            }
+        };
+        // one step: MFMAs of step s (operands in `cur`), conversion of s+1, ds_reads of s+D
+        auto step = [&](int s, bool has_next, bool has_ahead, int s_ahead, int xo, int dzo) {
+            const int slot = s % D, nslot = (s + 1) % D;
+            float fbs[TNW], nxt[TMW];
+#pragma unroll
+            for (int c = 0; c < TNW; ++c) fbs[c] = fb[slot][c];
+            if (has_next) convert(nslot, nxt);
+            if (has_ahead) issue(s_ahead, slot, xo, dzo);
+#pragma unroll
+            for (int a = 0; a < TMW; ++a)
+#pragma unroll
+                for (int c = 0; c < TNW; ++c)
+                    acc[s % NACC][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[a], fbs[c], acc[s % NACC][a][c], 0, 0, 0);
+            if (has_next) {
+#pragma unroll
+                for (int a = 0; a < TMW; ++a) cur[a] = nxt[a];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        if constexpr (G::OW % 2 == 0 && G::OH % 2 == 0) {
+            // ---- runtime loop over row PAIRS, 2 x OW/2 steps unrolled; pixel offsets are affine in the row
+            constexpr int SPR = G::OW / 2, SPI = 2 * SPR;            // steps per row / per iteration
+            constexpr int XROW = STRIDE * W * C, DZROW = G::OW * NF;  // element strides of one output row
+            static_assert(D <= SPR && SPI % D == 0, "pipeline depth vs row length");
+#pragma unroll
+            for (int s = 0; s < D; ++s) issue(s, s, 0, 0);
+            convert(0, cur);
+            for (int q = 0; q < G::OH / 2; ++q) {
+                const int xo = q * 2 * XROW, dzo = q * 2 * DZROW;
+                const bool last = q + 1 == G::OH / 2;
+#pragma unroll
+                for (int s = 0; s < SPI; ++s) {
+                    if (s == 0 || s == SPR) {                     // chunk slot boundaries: one per row
+                        const int cs = s == 0 ? 0 : 1, c = 2 * q + cs;
+                        if (more && c >= 2 && c - 2 < NCHUNK) store_chunk(c - 2, creg[cs], stage ^ 1);
+                        if (more && c < NCHUNK) creg[cs] = load_chunk(c);
+                    }
+                    // steps s+1 / s+D may belong to the next iteration: same code, offsets advance by 2 rows
+                    const int sa = s + D;
+                    if (sa < SPI) step(s, true, true, sa, xo, dzo);
+                    else step(s, !last || s + 1 < SPI, !last, sa - SPI, xo + 2 * XROW, dzo + 2 * DZROW);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int c = G::OH; c < NCHUNK + 2; ++c) {           // chunk slots the row loop did not reach
+                    if (c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], stage ^ 1);
+                    if (c < NCHUNK) creg[c & 1] = load_chunk(c);
+                }
+            }
+        } else {
+            // ---- fully unrolled pixel loop (odd map sizes); chunk slots every SP steps
+            constexpr int SP = (G::NSTEP - 2) / (NCHUNK + 2) > 0 ? (G::NSTEP - 2) / (NCHUNK + 2) : 1;
+#pragma unroll
+            for (int s = 0; s < D; ++s)
+                if (s < G::NSTEP) issue(s, s, 0, 0);
+            convert(0, cur);
+#pragma unroll
+            for (int s = 0; s < G::NSTEP; ++s) {
+                if (s % SP == 0) {
+                    const int c = s / SP;
+                    if (more && c >= 2 && c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], stage ^ 1);
+                    if (more && c < NCHUNK) creg[c & 1] = load_chunk(c);
+                }
+                step(s, s + 1 < G::NSTEP, s + D < G::NSTEP, s + D, 0, 0);
+            }
+            if (more) {
+                constexpr int CDONE = (G::NSTEP - 1) / SP + 1;       // chunk slots visited inside the loop
+#pragma unroll
+                for (int c = CDONE; c < NCHUNK + 2; ++c) {
+                    if (c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], stage ^ 1);
+                    if (c < NCHUNK) creg[c & 1] = load_chunk(c);
+                }
+            }
+        }
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    // ---- partial slab of this workgroup: [K][NF] weights then [NF] bias
+    const long slab = (long)G::K * NF + NF;
+    float* out = part + (long)blockIdx.x * slab;
+#pragma unroll
+    for (int a = 0; a < TMW; ++a)
+#pragma unroll
+        for (int c = 0; c < TNW; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = (mt0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                int n = (nt0 + c) * 32 + i;
+                float t = acc[0][a][c][r];
+#pragma unroll
+                for (int u = 1; u < NACC; ++u) t += acc[u][a][c][r];
+                out[(long)m * NF + n] = t;
+            }
+    // bias: thread t owns columns (4t % NF .. +3); combine the NT*4/NF threads of a column in fixed order
+    float4* red = reinterpret_cast<float4*>(lds);
+    __syncthreads();
+    red[tid] = bias4;
+    __syncthreads();
+    if (tid < NF) {
+        constexpr int GROUPS = NF / 4;                 // threads t, t+GROUPS, ... share a column group
+        const int g = tid / 4, comp = tid % 4;
+        float t = 0.f;
+        for (int q = g; q < G::NT; q += GROUPS) {
+            const float4 v = red[q];
+            t += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+        }
+        out[(long)G::K * NF + tid] = t;
+    }
+}
+
+template <bool U8, int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TMW, int TNW, int NACC>
+inline hipError_t launch_imgres_wgrad(const void* x, const int32_t* srow, const float* dz, int B, float* part,
+                                      int nblocks, hipStream_t stream) {
+    using G = ImgResCfg<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW>;
+    auto kern = imgres_wgrad_kernel<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW, NACC>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVES * 64), G::LDS_BYTES, stream, x, srow, dz, B, part);
+    return hipGetLastError();
+}
+
+}  // namespace mrl

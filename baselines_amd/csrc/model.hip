@@ -10,6 +10,7 @@
 //   gather     ppo2/ppo2.py:157-165 (fused into the first-layer loaders; sf01 runner.py:69-74 eliminated)
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <string>
@@ -18,6 +19,7 @@
 #include "common.hip.h"
 #include "gemm.hip.h"
 #include "wres.hip.h"
+#include "imgres.hip.h"
 
 using namespace mrl;
 
@@ -196,16 +198,18 @@ struct Ws {
 constexpr int ADV_G = 256;
 constexpr int HEAD_MAXBLK = 512;
 constexpr int WGRAD_TARGET_WGS = 1536;
+constexpr int IMGRES_MAX_BLOCKS = 256;      // one persistent workgroup (one partial slab) per CU
 
 // ---- tile variants of the GEMM template (gemm.hip.h) and the process-wide tuning table ----------
 enum { V_128x32 = 0, V_256x32, V_128x64_W41, V_128x64_W22, V_256x64, V_128x128, V_COUNT };
 enum { V_WRES16 = 100, V_WRES8 = 101 };     // weights-resident engine (wres.hip.h), 16 / 8 waves per CU
+enum { V_IMGRES = 102 };                    // image-resident weight-gradient engine (imgres.hip.h)
 static const int kVariantBM[V_COUNT] = {128, 256, 128, 128, 256, 128};
 static const int kVariantBN[V_COUNT] = {32, 32, 64, 64, 64, 128};
 
 static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
 extern "C" int mrl_tune_set(const char* label, int variant) {
-    if (!label || (variant >= 2 * V_COUNT && variant != V_WRES16 && variant != V_WRES8)) return MRL_EINVAL;
+    if (!label || (variant >= 2 * V_COUNT && variant != V_WRES16 && variant != V_WRES8 && variant != V_IMGRES)) return MRL_EINVAL;
     if (variant < 0) tune_table().erase(label);
     else tune_table()[label] = variant;
     return 0;
@@ -258,6 +262,7 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
             nw.h.push_back((float*)take((size_t)chunk * l.out_elems * 4));
             nw.dz.push_back((float*)take((size_t)chunk * l.out_elems * 4));
             part_floats = std::max(part_floats, (size_t)max_split_floats(l.K, l.N, layer_rows(l, chunk)));
+            if (l.kind == 0) part_floats = std::max(part_floats, (size_t)IMGRES_MAX_BLOCKS * ((size_t)l.K * l.N + l.N));
         }
     };
     do_net(m->pi, ws.pi);
@@ -763,6 +768,37 @@ static int wres_dispatch(const char* lname, const char* pass, int variant, int n
     return (int)e;
 }
 
+// image-resident weight gradient: compiled for the NatureCNN geometries (imgres.hip.h is templated on
+// the layer shape so that all im2col addressing folds into instruction immediates)
+static int imgres_kind(const Layer& l, bool u8, const void* src) {
+    if (l.kind != 0 || (uintptr_t)src % 16 != 0) return 0;
+    if (u8 && l.H == 84 && l.W == 84 && l.C == 4 && l.rf == 8 && l.stride == 4 && l.NF == 32) return 1;
+    if (!u8 && l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2 && l.NF == 64) return 2;
+    if (!u8 && l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1 && l.NF == 64) return 3;
+    return 0;
+}
+static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_t* srow, const float* dz, int B,
+                           float* part, int nblocks, hipStream_t st) {
+    char label[40];
+    if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
+    ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
+    hipError_t e;
+    static int nacc = -1;              // MRL_IMGRES_NACC=1|2|4: accumulator replicas per wave (experiment knob)
+    if (nacc < 0) { const char* ev = getenv("MRL_IMGRES_NACC"); nacc = ev ? atoi(ev) : 0; }
+    if (kind == 1) {
+        if (nacc == 1) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 1>(x, srow, dz, B, part, nblocks, st);
+        else if (nacc == 2) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 2>(x, srow, dz, B, part, nblocks, st);
+        else e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 4>(x, srow, dz, B, part, nblocks, st);
+    } else if (kind == 2) {
+        if (nacc == 2) e = launch_imgres_wgrad<false, 20, 20, 32, 4, 2, 64, 8, 2, 2, 2>(x, srow, dz, B, part, nblocks, st);
+        else e = launch_imgres_wgrad<false, 20, 20, 32, 4, 2, 64, 8, 2, 2, 1>(x, srow, dz, B, part, nblocks, st);
+    } else {
+        if (nacc == 2) e = launch_imgres_wgrad<false, 9, 9, 64, 3, 1, 64, 9, 2, 2, 2>(x, srow, dz, B, part, nblocks, st);
+        else e = launch_imgres_wgrad<false, 9, 9, 64, 3, 1, 64, 9, 2, 2, 1>(x, srow, dz, B, part, nblocks, st);
+    }
+    return (int)e;
+}
+
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
                          const float* params, float* hout, int B, hipStream_t st) {
     const float* W = params + l.w_off;
@@ -833,13 +869,27 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         if (rows > 0x7fffffffL || l.b_off != l.w_off + (long)l.K * l.N) return MRL_EUNSUP;
         // ---- weight + bias gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n], db[n] = sum_rows dz[row][n]
         //      (split-K over rows; the bias column sums ride on the B operand's LDS image)
-        const int var = pick_variant(l.name, "wgrad", l.K, l.N);
-        const Split sp = pick_split(var, l.K, l.N, rows);
+        int var = pick_variant(l.name, "wgrad", l.K, l.N);
         const long slab = (long)l.K * l.N + l.N;
+        const void* asrc = first ? in.obs : (const void*)hprev;
+        const int ik = imgres_kind(l, first && m->d.ob_dtype == MRL_OB_U8, asrc);
+        int rc;
+        if (ik && (var == V_IMGRES || tune_table().find(std::string(l.name) + ".wgrad") == tune_table().end())) {
+            int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
+            nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
+            if (nblocks < 1) return MRL_ENOSPC;
+            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, B, ws.part, nblocks, st);
+            if (rc) return rc;
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st);
+            if (rc) return rc;
+        } else {
+        if (var >= V_WRES16) var = l.N <= 32 ? V_128x32 : (l.N <= 64 ? V_128x64_W41 : V_128x128);
+        // ---- weight + bias gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n], db[n] = sum_rows dz[row][n]
+        //      (split-K over rows; the bias column sums ride on the B operand's LDS image)
+        const Split sp = pick_split(var, l.K, l.N, rows);
         if ((size_t)sp.nsplit * slab > ws.part_floats) return MRL_ENOSPC;
         EpiPartial ep{ws.part, slab, l.N, (long)l.K * l.N};
         RowMC bfm{dz, l.N, l.N, (int)rows, is_vec(dz, l.N), nullptr};
-        int rc;
         if (l.kind == 0) {
             if (first) {
                 ConvPatchMC<true> af;
@@ -862,6 +912,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         if (rc) return rc;
         rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, st);
         if (rc) return rc;
+        }
         // ---- data gradient into dz[i-1] (masked by act' of layer i-1)
         if (!first) {
             const Layer& lp = net.L[i - 1];

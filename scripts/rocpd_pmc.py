@@ -13,7 +13,7 @@ def main(db, sub=''):
     acc = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
     for k, cn, v, d in rows:
-        if sub in k and 'gemm' in k or 'wres' in k:
+        if sub in k and ('gemm' in k or 'wres' in k or 'imgres' in k):
             acc[k][cn] += v
             disp[k].add(d)
     for k in acc:

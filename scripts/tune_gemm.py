@@ -17,7 +17,7 @@ from baselines_amd.common.policies import build_policy  # noqa: E402
 from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv  # noqa: E402
 from baselines_amd.ppo2 import Model, Runner  # noqa: E402
 
-VARIANTS = [('128x32', 0), ('128x64w41', 2), ('128x64w22', 3), ('128x128', 5), ('wres16', 100), ('wres8', 101)]
+VARIANTS = [('128x32', 0), ('128x64w41', 2), ('128x128', 5), ('wres16', 100), ('imgres', 102)]
 LABELS = ['c1.fwd', 'c2.fwd', 'c3.fwd', 'fc1.fwd', 'c1.wgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad', 'c2.dgrad',
           'c3.dgrad', 'fc1.dgrad']
 
