@@ -342,45 +342,50 @@ struct DgradB : DgradGeom {   // GEMM row = input channel c, KC over n;  W is HW
 };
 
 // ------------------------------------------------------------------------------------------
-// Epilogue functors:  void store(int m, int n, float acc, int z)
+// Epilogue functors, three phases so that the kernel can issue ALL auxiliary loads of a tile before the
+// first store (a load -> wait -> store chain per element serialises 16 memory round trips per tile):
+//   long  addr(m, n, z)        flat output offset, or -1 when the element has no destination
+//   float aux(o, n)            the value the store needs from memory (bias / act' source); o >= 0 always
+//   void  put(o, acc, aux)     the store
 // ------------------------------------------------------------------------------------------
 struct EpiBiasAct {       // out[m*ld + n] = act(acc + bias[n])
     static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* bias; int act;
-    __device__ __forceinline__ void store(int m, int n, float acc, int) const {
-        out[(long)m * ld + n] = act_fwd(acc + bias[n], act);
-    }
+    __device__ __forceinline__ long addr(int m, int n, int) const { return (long)m * ld + n; }
+    __device__ __forceinline__ float aux(long, int n) const { return bias[n]; }
+    __device__ __forceinline__ void put(long o, float acc, float b) const { out[o] = act_fwd(acc + b, act); }
 };
 struct EpiMaskAct {       // out[m*ld + n] = acc * act'(h[m*ld + n])      (fc data-gradient)
     static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* h; int act;
-    __device__ __forceinline__ void store(int m, int n, float acc, int) const {
-        long o = (long)m * ld + n;
-        out[o] = acc * act_bwd_from_out(h[o], act);
-    }
+    __device__ __forceinline__ long addr(int m, int n, int) const { return (long)m * ld + n; }
+    // h == nullptr: the act' mask is deferred to the consumers of `out` (store the plain product)
+    __device__ __forceinline__ float aux(long o, int) const { return h ? h[o] : 1.f; }
+    __device__ __forceinline__ void put(long o, float acc, float hv) const { out[o] = h ? acc * act_bwd_from_out(hv, act) : acc; }
 };
 struct EpiDgradConv : DgradGeom {   // scatter rows of class z back to NHWC, masked by act'(h_prev)
     static constexpr bool HAS_BIAS = false;
     float* out; const float* h; int act;
-    __device__ __forceinline__ void store(int m, int n, float acc, int z) const {
+    __device__ __forceinline__ long addr(int m, int n, int z) const {
         const int per = HY * WX;
         int b = (int)d_per.div((uint32_t)m), r = m - b * per;
         int yy = (int)d_wx.div((uint32_t)r), xx = r - yy * WX;
         int py = z / stride, px = z - py * stride;
         int iy = yy * stride + py, ix = xx * stride + px;
-        if (iy >= H || ix >= W) return;
-        long o = ((long)(b * H + iy) * W + ix) * C + n;
-        out[o] = acc * act_bwd_from_out(h[o], act);
+        if (iy >= H || ix >= W) return -1;
+        return ((long)(b * H + iy) * W + ix) * C + n;
     }
+    __device__ __forceinline__ float aux(long o, int) const { return h ? h[o] : 1.f; }
+    __device__ __forceinline__ void put(long o, float acc, float hv) const { out[o] = h ? acc * act_bwd_from_out(hv, act) : acc; }
 };
 // split-K slab of a weight-gradient GEMM: part[z][m*N + n] = acc, followed (same slab) by the bias
 // gradient part[z][M*N + n] = sum over this split's rows of dz[row][n] (the B operand's column sums).
 struct EpiPartial {
     static constexpr bool HAS_BIAS = true;
     float* part; long slab; int N; long bias_off;
-    __device__ __forceinline__ void store(int m, int n, float acc, int z) const {
-        part[(long)z * slab + (long)m * N + n] = acc;
-    }
+    __device__ __forceinline__ long addr(int m, int n, int z) const { return (long)z * slab + (long)m * N + n; }
+    __device__ __forceinline__ float aux(long, int) const { return 0.f; }
+    __device__ __forceinline__ void put(long o, float acc, float) const { part[o] = acc; }
     __device__ __forceinline__ void store_bias(int n, float acc, int z) const {
         part[(long)z * slab + bias_off + n] = acc;
     }
@@ -522,13 +527,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(AF af, BF bf, EF ef, int M, i
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + (wn * TN + b) * 32 + i;
+            const int colc = min(col, N - 1);
+            long o[16];
+            float x[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                int col = n0 + (wn * TN + b) * 32 + i;
-                if (row < M && col < N) ef.store(row, col, acc[a][b][r], z);
+                o[r] = (row < M && col < N) ? ef.addr(row, col, z) : -1;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = ef.aux(o[r] < 0 ? 0 : o[r], colc);     // all loads first, unconditional
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (o[r] >= 0) ef.put(o[r], acc[a][b][r], x[r]);
+        }
     if constexpr (EF::HAS_BIAS) {
         if (!BF::KC && mt_i == 0) {            // combine the per-part column sums in fixed order
             __syncthreads();

@@ -49,7 +49,8 @@ struct ImgResCfg {
 template <bool U8, int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TMW, int TNW, int NACC>
 __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __restrict__ x,
                                                                    const int32_t* __restrict__ srow,
-                                                                   const float* __restrict__ dz, int B,
+                                                                   const float* __restrict__ dz,
+                                                                   const float* __restrict__ hcur, int B,
                                                                    float* __restrict__ part) {
     using G = ImgResCfg<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -85,12 +86,16 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
     // register slots and written to LDS two chunk-slots later, so only 8 VGPRs are held across the MFMA
     // stream (holding the whole 79 KB stage in registers made the compiler spill and serialise the loads).
     constexpr int NCHUNK = G::NXV + G::NDV;
+    // hcur != nullptr: dz is the gradient w.r.t. this layer's OUTPUT; the ReLU mask (hcur > 0) is applied
+    // while the chunk is written to LDS (deferred activation mask, see ldsdgrad.hip.h)
     const uint4* gx = nullptr;
     const float4* gd = nullptr;
+    const float4* gh = nullptr;
     auto set_src = [&](int bb) {
         const long img = srow ? (long)srow[bb] : (long)bb;
         gx = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(x) + img * G::XBYTES);
         gd = reinterpret_cast<const float4*>(dz + (long)bb * G::NPIX * NF);
+        gh = reinterpret_cast<const float4*>(hcur + (long)bb * G::NPIX * NF);
     };
     auto load_chunk = [&](int c) -> uint4 {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -106,7 +111,19 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
         }
         return v;
     };
-    auto store_chunk = [&](int c, const uint4& v, int st) {
+    auto load_mask = [&](int c) -> float4 {          // this layer's activations for a dz chunk (mask source)
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (hcur && c >= G::NXV) {
+            const int e = tid + (c - G::NXV) * G::NT;
+            if (e < G::DZV) m = gh[e];
+        }
+        return m;
+    };
+    auto store_chunk = [&](int c, const uint4& v0, const float4& m, int st) {
+        uint4 v = v0;
+        if (hcur && c >= G::NXV) {
+            v.x = m.x > 0.f ? v.x : 0u; v.y = m.y > 0.f ? v.y : 0u; v.z = m.z > 0.f ? v.z : 0u; v.w = m.w > 0.f ? v.w : 0u;
+        }
         if (c < G::NXV) {
             const int e = tid + c * G::NT;
             if (e < G::XV) reinterpret_cast<uint4*>(lds + st * G::STAGE_BYTES)[e] = v;
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
     int b = blockIdx.x;
     if (b < B) {                                       // first image: plain copy
         set_src(b);
-        for (int c = 0; c < NCHUNK; ++c) store_chunk(c, load_chunk(c), 0);
+        for (int c = 0; c < NCHUNK; ++c) store_chunk(c, load_chunk(c), load_mask(c), 0);
     }
     __syncthreads();
     int stage = 0;
@@ -146,6 +163,7 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
         float fb[D][TNW];
         float cur[TMW];
         uint4 creg[2];
+        float4 mreg[2];
         // xo / dzo: element offsets of the current block (image row pair) -- 0 for the fully unrolled form
         auto issue = [&](int s, int slot, int xo, int dzo) {
             const int A0 = G::a_off(2 * s < G::NPIX ? 2 * s : 0);
@@ -201,8 +219,8 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
                 for (int s = 0; s < SPI; ++s) {
                     if (s == 0 || s == SPR) {                     // chunk slot boundaries: one per row
                         const int cs = s == 0 ? 0 : 1, c = 2 * q + cs;
-                        if (more && c >= 2 && c - 2 < NCHUNK) store_chunk(c - 2, creg[cs], stage ^ 1);
-                        if (more && c < NCHUNK) creg[cs] = load_chunk(c);
+                        if (more && c >= 2 && c - 2 < NCHUNK) store_chunk(c - 2, creg[cs], mreg[cs], stage ^ 1);
+                        if (more && c < NCHUNK) { creg[cs] = load_chunk(c); mreg[cs] = load_mask(c); }
                     }
                     // steps s+1 / s+D may belong to the next iteration: same code, offsets advance by 2 rows
                     const int sa = s + D;
@@ -213,8 +231,8 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
             if (more) {
 #pragma unroll
                 for (int c = G::OH; c < NCHUNK + 2; ++c) {           // chunk slots the row loop did not reach
-                    if (c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], stage ^ 1);
-                    if (c < NCHUNK) creg[c & 1] = load_chunk(c);
+                    if (c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], mreg[c & 1], stage ^ 1);
+                    if (c < NCHUNK) { creg[c & 1] = load_chunk(c); mreg[c & 1] = load_mask(c); }
                 }
             }
         } else {
@@ -228,8 +246,8 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
             for (int s = 0; s < G::NSTEP; ++s) {
                 if (s % SP == 0) {
                     const int c = s / SP;
-                    if (more && c >= 2 && c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], stage ^ 1);
-                    if (more && c < NCHUNK) creg[c & 1] = load_chunk(c);
+                    if (more && c >= 2 && c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], mreg[c & 1], stage ^ 1);
+                    if (more && c < NCHUNK) { creg[c & 1] = load_chunk(c); mreg[c & 1] = load_mask(c); }
                 }
                 step(s, s + 1 < G::NSTEP, s + D < G::NSTEP, s + D, 0, 0);
             }
@@ -237,8 +255,8 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
                 constexpr int CDONE = (G::NSTEP - 1) / SP + 1;       // chunk slots visited inside the loop
 #pragma unroll
                 for (int c = CDONE; c < NCHUNK + 2; ++c) {
-                    if (c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], stage ^ 1);
-                    if (c < NCHUNK) creg[c & 1] = load_chunk(c);
+                    if (c - 2 < NCHUNK) store_chunk(c - 2, creg[c & 1], mreg[c & 1], stage ^ 1);
+                    if (c < NCHUNK) { creg[c & 1] = load_chunk(c); mreg[c & 1] = load_mask(c); }
                 }
             }
         }
@@ -280,8 +298,8 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
 }
 
 template <bool U8, int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TMW, int TNW, int NACC>
-inline hipError_t launch_imgres_wgrad(const void* x, const int32_t* srow, const float* dz, int B, float* part,
-                                      int nblocks, hipStream_t stream) {
+inline hipError_t launch_imgres_wgrad(const void* x, const int32_t* srow, const float* dz, const float* hcur, int B,
+                                      float* part, int nblocks, hipStream_t stream) {
     using G = ImgResCfg<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW>;
     auto kern = imgres_wgrad_kernel<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW, NACC>;
     static bool raised = false;
@@ -290,7 +308,7 @@ inline hipError_t launch_imgres_wgrad(const void* x, const int32_t* srow, const 
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVES * 64), G::LDS_BYTES, stream, x, srow, dz, B, part);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVES * 64), G::LDS_BYTES, stream, x, srow, dz, hcur, B, part);
     return hipGetLastError();
 }
 

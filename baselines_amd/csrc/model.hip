@@ -20,6 +20,7 @@
 #include "gemm.hip.h"
 #include "wres.hip.h"
 #include "imgres.hip.h"
+#include "ldsdgrad.hip.h"
 
 using namespace mrl;
 
@@ -204,12 +205,13 @@ constexpr int IMGRES_MAX_BLOCKS = 256;      // one persistent workgroup (one par
 enum { V_128x32 = 0, V_256x32, V_128x64_W41, V_128x64_W22, V_256x64, V_128x128, V_COUNT };
 enum { V_WRES16 = 100, V_WRES8 = 101 };     // weights-resident engine (wres.hip.h), 16 / 8 waves per CU
 enum { V_IMGRES = 102 };                    // image-resident weight-gradient engine (imgres.hip.h)
+enum { V_LDSDGRAD = 103 };                  // LDS-resident data-gradient engine (ldsdgrad.hip.h)
 static const int kVariantBM[V_COUNT] = {128, 256, 128, 128, 256, 128};
 static const int kVariantBN[V_COUNT] = {32, 32, 64, 64, 64, 128};
 
 static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
 extern "C" int mrl_tune_set(const char* label, int variant) {
-    if (!label || (variant >= 2 * V_COUNT && variant != V_WRES16 && variant != V_WRES8 && variant != V_IMGRES)) return MRL_EINVAL;
+    if (!label || (variant >= 2 * V_COUNT && variant != V_WRES16 && variant != V_WRES8 && variant != V_IMGRES && variant != V_LDSDGRAD)) return MRL_EINVAL;
     if (variant < 0) tune_table().erase(label);
     else tune_table()[label] = variant;
     return 0;
@@ -777,8 +779,8 @@ static int imgres_kind(const Layer& l, bool u8, const void* src) {
     if (!u8 && l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1 && l.NF == 64) return 3;
     return 0;
 }
-static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_t* srow, const float* dz, int B,
-                           float* part, int nblocks, hipStream_t st) {
+static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_t* srow, const float* dz,
+                           const float* hcur, int B, float* part, int nblocks, hipStream_t st) {
     char label[40];
     if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
     ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
@@ -786,15 +788,15 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     static int nacc = -1;              // MRL_IMGRES_NACC=1|2|4: accumulator replicas per wave (experiment knob)
     if (nacc < 0) { const char* ev = getenv("MRL_IMGRES_NACC"); nacc = ev ? atoi(ev) : 0; }
     if (kind == 1) {
-        if (nacc == 1) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 1>(x, srow, dz, B, part, nblocks, st);
-        else if (nacc == 2) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 2>(x, srow, dz, B, part, nblocks, st);
-        else e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 4>(x, srow, dz, B, part, nblocks, st);
+        if (nacc == 1) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 1>(x, srow, dz, hcur, B, part, nblocks, st);
+        else if (nacc == 2) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 2>(x, srow, dz, hcur, B, part, nblocks, st);
+        else e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 4>(x, srow, dz, hcur, B, part, nblocks, st);
     } else if (kind == 2) {
-        if (nacc == 2) e = launch_imgres_wgrad<false, 20, 20, 32, 4, 2, 64, 8, 2, 2, 2>(x, srow, dz, B, part, nblocks, st);
-        else e = launch_imgres_wgrad<false, 20, 20, 32, 4, 2, 64, 8, 2, 2, 1>(x, srow, dz, B, part, nblocks, st);
+        if (nacc == 2) e = launch_imgres_wgrad<false, 20, 20, 32, 4, 2, 64, 8, 2, 2, 2>(x, srow, dz, hcur, B, part, nblocks, st);
+        else e = launch_imgres_wgrad<false, 20, 20, 32, 4, 2, 64, 8, 2, 2, 1>(x, srow, dz, hcur, B, part, nblocks, st);
     } else {
-        if (nacc == 2) e = launch_imgres_wgrad<false, 9, 9, 64, 3, 1, 64, 9, 2, 2, 2>(x, srow, dz, B, part, nblocks, st);
-        else e = launch_imgres_wgrad<false, 9, 9, 64, 3, 1, 64, 9, 2, 2, 1>(x, srow, dz, B, part, nblocks, st);
+        if (nacc == 2) e = launch_imgres_wgrad<false, 9, 9, 64, 3, 1, 64, 12, 3, 1, 2>(x, srow, dz, hcur, B, part, nblocks, st);
+        else e = launch_imgres_wgrad<false, 9, 9, 64, 3, 1, 64, 12, 3, 1, 1>(x, srow, dz, hcur, B, part, nblocks, st);
     }
     return (int)e;
 }
@@ -857,12 +859,39 @@ static int net_forward(const mrl_model* m, const Net& net, const In& in, const f
     return 0;
 }
 
+static inline const float* hprev_of(const NetWs& nw, int i) { return i ? nw.h[i - 1] : nullptr; }
+static int ldsdgrad_kind(const Layer& l, const float* dz) {
+    if (l.kind != 0 || (uintptr_t)dz % 16 != 0) return 0;
+    if (l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2 && l.NF == 64) return 1;
+    if (l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1 && l.NF == 64) return 2;
+    return 0;
+}
+static bool tuned(const Layer& l, const char* pass) {
+    return tune_table().find(std::string(l.name) + "." + pass) != tune_table().end();
+}
+
 // backward through one net; nw.dz[last] already holds dloss/d(pre-activation of the last layer)
 static int net_backward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws,
                         float* grads, int B, int accumulate, hipStream_t st) {
+    // Deferred ReLU mask (see ldsdgrad.hip.h; OFF by default, MRL_DEFER_MASK=1 enables it: measured slower
+    // because the consumers' staging is a synchronous memory phase): defer[j] == true means nw.dz[j] holds the gradient w.r.t. layer
+    // j's OUTPUT and both of its consumers (layer j's weight- and data-gradient kernels) apply (h[j] > 0)
+    // while staging it into LDS.  Only when every consumer is one of the LDS-resident engines.
+    std::vector<char> defer(net.L.size(), 0);
+    static int defer_on = -1;
+    if (defer_on < 0) { const char* ev = getenv("MRL_DEFER_MASK"); defer_on = ev ? atoi(ev) : 0; }
+    for (size_t j = 0; defer_on && j + 1 < net.L.size(); ++j) {
+        const Layer& lj = net.L[j];
+        const void* src = j == 0 ? in.obs : (const void*)nw.h[j - 1];
+        const bool wg_ok = imgres_kind(lj, j == 0 && m->d.ob_dtype == MRL_OB_U8, src) != 0 && !tuned(lj, "wgrad");
+        const bool dg_ok = j == 0 || (ldsdgrad_kind(lj, nw.dz[j]) != 0 && !tuned(lj, "dgrad"));
+        defer[j] = lj.act == ACT_RELU && wg_ok && dg_ok;
+    }
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
         const float* dz = nw.dz[i];
+        const float* hcur = defer[i] ? nw.h[i] : nullptr;            // mask-in source for this layer's consumers
+        const float* hmask = (i > 0 && defer[i - 1]) ? nullptr : hprev_of(nw, i);   // mask-out source (nullptr: deferred)
         const float* hprev = i ? nw.h[i - 1] : nullptr;
         const long rows = layer_rows(l, B);
         const bool first = (i == 0);
@@ -878,7 +907,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
             nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;
-            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, B, ws.part, nblocks, st);
+            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, hcur, B, ws.part, nblocks, st);
             if (rc) return rc;
             rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st);
             if (rc) return rc;
@@ -927,29 +956,45 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 int Md = B * g.HY * g.WX;
                 const double fl = 2.0 * B * l.OH * l.OW * (double)l.K * l.NF;
                 const bool wok = wres_dgrad_ok(l);
-                // measured (profiles/): the tiled engine is as fast or faster for the data-gradients
-                // (their A rows are gathered taps, better coalesced through the LDS staging path)
+                // LDS-resident engine for the NatureCNN geometries (ldsdgrad.hip.h is templated on the shape)
+                const int lk = ldsdgrad_kind(l, dz);
+                const bool overridden = tune_table().find(std::string(l.name) + ".dgrad") != tune_table().end();
                 int dv = pick_variant(l.name, "dgrad", Md, l.C, false);
+                if (lk && (dv == V_LDSDGRAD || !overridden)) {
+                    char label[40];
+                    if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
+                    ProfScope ps(label, fl, 0.0, st);
+                    static int prio = -1;
+                    if (prio < 0) { const char* ev = getenv("MRL_LDSDGRAD_PRIO"); prio = ev ? atoi(ev) : 0; }
+                    hipError_t e;
+                    const float* wsrc = params + l.w_off;
+                    // MRL_LDSDGRAD_PRIO (experiment knob): 0 = normal, 1 = no epilogue, 2 = no staging, 3 = neither
+                    #define MRL_LD(DBG) (lk == 1 ? launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1, DBG>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st) \
+                                                 : launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1, DBG>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st))
+                    if (prio == 3) e = MRL_LD(3); else if (prio == 2) e = MRL_LD(2); else if (prio == 1) e = MRL_LD(1); else e = MRL_LD(0);
+                    #undef MRL_LD
+                    rc = (int)e;
+                } else
                 if (dv >= V_WRES16 && wok) {
                     const int zc = l.stride * l.stride;
                     const long tpc = ((long)Md + 31) / 32;
                     WresDgradA wa; static_cast<DgradGeom&>(wa) = g; wa.dz = dz; wa.zeros = ws.zeros; wa.tiles_per_class = tpc;
                     WresDgradB wb; static_cast<DgradGeom&>(wb) = g; wb.w = params + l.w_off;
-                    WresEpiDgrad we; static_cast<DgradGeom&>(we) = g; we.out = nw.dz[i - 1]; we.hprev = hprev;
+                    WresEpiDgrad we; static_cast<DgradGeom&>(we) = g; we.out = nw.dz[i - 1]; we.hprev = hprev;   /* wres data-gradient always masks: not used when deferring */
                     we.act = lp.act; we.tiles_per_class = tpc;
                     rc = wres_dispatch(l.name, "dgrad", dv, l.C, wa, wb, we, zc, Kd, tpc * zc, fl, st);
                 } else {
                     if (dv >= V_WRES16) dv = l.C <= 32 ? V_128x32 : V_128x64_W41;
                     DgradA af; static_cast<DgradGeom&>(af) = g; af.dz = dz;
                     DgradB bf; static_cast<DgradGeom&>(bf) = g; bf.w = params + l.w_off;
-                    EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hprev; ef.act = lp.act;
+                    EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hmask; ef.act = lp.act;
                     rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, Md, l.C, Kd, l.stride * l.stride, Kd, st, fl);
                 }
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
                 const float* W = params + l.w_off;
                 RowKC bf{W, l.N, l.K, l.N, is_vec(W, l.N), nullptr};
-                EpiMaskAct ef{nw.dz[i - 1], l.K, hprev, lp.act};
+                EpiMaskAct ef{nw.dz[i - 1], l.K, hmask, lp.act};
                 int dv = pick_variant(l.name, "dgrad", B, l.K);
                 rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, B, l.K, l.N, 1, l.N, st);
             }

@@ -157,29 +157,33 @@ struct WresDgradB : DgradGeom {   // class z = (py, px); k = (tap, n'); column =
 };
 
 // ------------------------------------------------------------------------------------------
-// Epilogues: store(tile, z, row_in_tile(0..31), col, value)
+// Epilogues (three phases like gemm.hip.h: all auxiliary loads of a tile are issued before its stores):
+//   long addr(tile, z, row_in_tile, col) (-1: no destination);  float aux(o, col);  void put(o, acc, aux)
 // ------------------------------------------------------------------------------------------
 struct WresEpiBiasAct {      // out[m*ld + n] = act(acc + bias[n]),  m = tile*32 + row
     float* out; long ld; const float* bias; int act; long rows; int ncols;
-    __device__ __forceinline__ void store(long tile, int, int row, int col, float acc) const {
+    __device__ __forceinline__ long addr(long tile, int, int row, int col) const {
         long m = tile * 32 + row;
-        if (m < rows && col < ncols) out[m * ld + col] = act_fwd(acc + bias[col], act);
+        return (m < rows && col < ncols) ? m * ld + col : -1;
     }
+    __device__ __forceinline__ float aux(long, int col) const { return bias[min(col, ncols - 1)]; }
+    __device__ __forceinline__ void put(long o, float acc, float b) const { out[o] = act_fwd(acc + b, act); }
 };
 struct WresEpiDgrad : DgradGeom {   // scatter class rows back to NHWC, masked by act'(h_prev)
     float* out; const float* hprev; int act; long tiles_per_class;
-    __device__ __forceinline__ void store(long tile, int z, int row, int col, float acc) const {
+    __device__ __forceinline__ long addr(long tile, int z, int row, int col) const {
         long m = (tile - (long)z * tiles_per_class) * 32 + row;
         const int per = HY * WX;
-        if (m >= (long)B * per || col >= C) return;
+        if (m >= (long)B * per || col >= C) return -1;
         int b = (int)d_per.div((uint32_t)m), r = (int)m - b * per;
         int yy = (int)d_wx.div((uint32_t)r), xx = r - yy * WX;
         int py = z / stride, px = z - py * stride;
         int iy = yy * stride + py, ix = xx * stride + px;
-        if (iy >= H || ix >= W) return;
-        long o = ((long)(b * H + iy) * W + ix) * C + col;
-        out[o] = acc * act_bwd_from_out(hprev[o], act);
+        if (iy >= H || ix >= W) return -1;
+        return ((long)(b * H + iy) * W + ix) * C + col;
     }
+    __device__ __forceinline__ float aux(long o, int) const { return hprev[o]; }
+    __device__ __forceinline__ void put(long o, float acc, float hv) const { out[o] = acc * act_bwd_from_out(hv, act); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -270,10 +274,17 @@ __global__ __launch_bounds__(WAVES * 64) void wres_kernel(AL al, BL bl, EF ef, i
         al.template prep_group<PF>(rn);
         body(rn, wz + (NG - 1) * (2 * KL * PF), acc);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            long o[16];
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = ef.addr(tile, zcur, (r & 3) + 8 * (r >> 2) + 4 * h, nt * 32 + i);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = ef.aux(o[r] < 0 ? 0 : o[r], nt * 32 + i);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                ef.store(tile, zcur, (r & 3) + 8 * (r >> 2) + 4 * h, nt * 32 + i, acc[nt][r]);
+                if (o[r] >= 0) ef.put(o[r], acc[nt][r], x[r]);
+        }
         if (next >= total_tiles) break;
         rs = rn;
         zcur = rn.z;
