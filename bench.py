@@ -106,8 +106,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # one process per GPU over RCCL ("nccl" on ROCm).  MRL_BENCH_BACKEND=gloo lets the N>1 code path be
+        # smoke-tested on a box with fewer GPUs than ranks (ranks then share devices; not a measurement).
+        backend = os.environ.get('MRL_BENCH_BACKEND', 'nccl')
+        dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)' % (args.gpus, world)
