@@ -21,6 +21,7 @@
 #include "wres.hip.h"
 #include "imgres.hip.h"
 #include "ldsdgrad.hip.h"
+#include "mlpstep.hip.h"
 
 using namespace mrl;
 
@@ -198,8 +199,10 @@ struct Ws {
 
 constexpr int ADV_G = 256;
 constexpr int HEAD_MAXBLK = 512;
+constexpr int SPART_MAX = 2048;             // stat partials: max(HEAD_MAXBLK, MLP_MAX_TILES)
 constexpr int WGRAD_TARGET_WGS = 1536;
 constexpr int IMGRES_MAX_BLOCKS = 256;      // one persistent workgroup (one partial slab) per CU
+constexpr int MLP_MAX_TILES = 2048;         // fused MLP step: one 32-sample tile (one partial slab) per workgroup
 
 // ---- tile variants of the GEMM template (gemm.hip.h) and the process-wide tuning table ----------
 enum { V_128x32 = 0, V_256x32, V_128x64_W41, V_128x64_W22, V_256x64, V_128x128, V_COUNT };
@@ -269,13 +272,15 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     };
     do_net(m->pi, ws.pi);
     if (m->vf_copy) do_net(m->vf, ws.vf);
+    if (m->d.network == MRL_NET_MLP)
+        part_floats = std::max(part_floats, (size_t)std::min<long>(MLP_MAX_TILES, ((long)chunk + 31) / 32) * (size_t)m->P);
     ws.pdparam = (float*)take((size_t)chunk * m->d.nact * 4);
     ws.part = (float*)take(part_floats * 4);
     ws.part_floats = part_floats;
-    ws.dscratch = (double*)take((size_t)(ADV_G * 2 + HEAD_MAXBLK * 5 + 8) * 8);
+    ws.dscratch = (double*)take((size_t)(ADV_G * 2 + SPART_MAX * 5 + 8) * 8);
     ws.advstat = (float*)take(64);
     ws.srow = (int32_t*)take((size_t)chunk * 4);
-    ws.zeros = (float*)take(1024);
+    ws.zeros = (float*)take(2048);
     ws.total = off;
 }
 
@@ -1091,7 +1096,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     if (ws.total > workspace_bytes) return MRL_ENOSPC;
     double* advpart = ws.dscratch;
     double* spart = ws.dscratch + ADV_G * 2;
-    double* stats_acc = spart + HEAD_MAXBLK * 5;
+    double* stats_acc = spart + SPART_MAX * 5;
     MRL_HIP_CHECK(hipMemsetAsync(ws.zeros, 0, 1024, st));
     // minibatch advantage statistics (model.py:136-139)
     int G = std::min(ADV_G, (B + 255) / 256);
@@ -1103,6 +1108,62 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     MRL_LAUNCH_CHECK();
     const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
     const float invB = 1.f / (float)B;
+    // ---- fused whole-step kernel for the 2 x 64 tanh MLP (mlpstep.hip.h)
+    {
+        static int fused = -1;
+        if (fused < 0) { const char* ev = getenv("MRL_MLP_FUSED"); fused = ev ? atoi(ev) : 1; }
+        const mrl_model_desc& d = m->d;
+        const int ntiles = (B + 31) / 32;
+        const int K0 = (int)m->ob_elems;
+        const int nets = m->vf_copy ? 2 : 1;
+        if (fused && d.network == MRL_NET_MLP && d.num_layers == 2 && d.num_hidden == MLP_NH && d.activation == MRL_ACT_TANH &&
+            m->has_pi_head && d.nact <= 32 && K0 % 4 == 0 && B <= chunk && ntiles <= MLP_MAX_TILES &&
+            mlp_step_lds_bytes(K0, nets) <= 160 * 1024 && (size_t)ntiles * m->P <= ws.part_floats &&
+            (uintptr_t)params % 16 == 0 && (uintptr_t)obs % 16 == 0) {
+            MlpStepArgs a;
+            memset(&a, 0, sizeof a);
+            for (int n = 0; n < nets; ++n) {
+                const Net& net = n == 0 ? m->pi : m->vf;
+                a.w0[n] = net.L[0].w_off; a.b0[n] = net.L[0].b_off; a.w1[n] = net.L[1].w_off; a.b1[n] = net.L[1].b_off;
+            }
+            a.wpi = m->pi_w; a.bpi = m->pi_b; a.logstd = m->logstd; a.wvf = m->vf_w; a.bvf = m->vf_b;
+            a.K0 = K0; a.nact = d.nact; a.nets = nets; a.pd_kind = d.pd_kind; a.P = m->P;
+            a.params = params; a.obs = (const float*)obs; a.actions = actions; a.returns = returns; a.values = values;
+            a.neglogp = neglogpacs; a.advstat = ws.advstat; a.cliprange = cliprange; a.ent_coef = ent_coef;
+            a.vf_coef = vf_coef; a.invB = invB; a.B = B; a.part = ws.part; a.spart = spart;
+            {   // MRL_MLP_DBG=1: phase timestamps of workgroup 0 land in the last 64 bytes of the zero page
+                static int dbgon = -1;
+                if (dbgon < 0) { const char* ev = getenv("MRL_MLP_DBG"); dbgon = ev ? atoi(ev) : 0; }
+                a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
+            }
+            if (idx) {
+                hipLaunchKernelGGL(translate_idx_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, T, N, ws.srow);
+                MRL_LAUNCH_CHECK();
+                a.srow = ws.srow;
+            }
+            const size_t lds = mlp_step_lds_bytes(K0, nets);
+            static bool raised = false;
+            if (!raised) {
+                MRL_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised = true;
+            }
+            {
+                // algorithmic flops: fwd + bwd of both nets on B samples
+                double fl = 0.0;
+                for (int n = 0; n < nets; ++n) fl += 2.0 * B * ((double)K0 * 64 * 2 + 64.0 * 64 * 3);
+                ProfScope ps("mlp_step", fl, 0.0, st);
+                hipLaunchKernelGGL(mlp_step_kernel, dim3(ntiles), dim3(256), lds, st, a);
+            }
+            MRL_LAUNCH_CHECK();
+            int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, ntiles, stats_acc);
+            MRL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, st, stats_acc, invB, stats_out);
+            MRL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     for (int c0 = 0; c0 < B; c0 += chunk) {
         const int Bc = std::min(chunk, B - c0);
         const int accumulate = c0 > 0;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Phase timestamps (s_memtime) of workgroup 0 of the fused MLP step kernel.  MRL_MLP_DBG=1 python scripts/mlp_phases.py"""
+import os
+import sys
+os.environ['MRL_MLP_DBG'] = '1'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa
+import torch  # noqa
+from baselines_amd import ops  # noqa
+from baselines_amd.common import set_global_seeds  # noqa
+from baselines_amd.common.policies import build_policy  # noqa
+from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv  # noqa
+from baselines_amd.ppo2 import Model, Runner  # noqa
+
+N, T, M = 1024, 128, 32
+torch.cuda.set_device(0)
+set_global_seeds(0)
+env = SyntheticVecEnv('mujoco', N, seed=1)
+model = Model(policy=build_policy(env, 'mlp', value_network='copy'), ob_space=env.observation_space, ac_space=env.action_space,
+              nbatch_act=N, nbatch_train=N * T // M, nsteps=T, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5)
+runner = Runner(env=env, model=model, nsteps=T, gamma=0.99, lam=0.95, return_host=False)
+runner.run()
+ro = runner.rollout
+ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, model.value_dev(runner.obs), runner._dones_dev, 0.99, 0.95)
+inds = torch.from_numpy(np.random.permutation(N * T)).to(model.device)
+B = N * T // M
+for it in range(3):
+    model.train_indexed(3e-4, 0.2, ro, inds[it * B:(it + 1) * B])
+torch.cuda.synchronize()
+ws = model.dm.workspace
+stamps = ws[-2048 + 512:-2048 + 512 + 64].view(torch.int64).cpu().numpy()
+d = np.diff(stamps)
+names = ['P0 gather', 'P1 fc0 fwd', 'P2 fc1 fwd', 'P3 heads+loss', 'P4 head grads/dz1', 'P5 fc1 bwd', 'P6 fc0 wgrad']
+# s_memtime ticks at 100 MHz on gfx9 (constant-rate counter); report ticks and microseconds
+for n, x in zip(names, d):
+    print('%-20s %8d ticks  %7.2f us' % (n, x, x / 100.0))
+print('total %d ticks = %.2f us' % (stamps[-1] - stamps[0], (stamps[-1] - stamps[0]) / 100.0))
