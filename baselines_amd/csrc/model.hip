@@ -342,11 +342,13 @@ __global__ __launch_bounds__(256) void translate_idx_kernel(const int64_t* __res
 // advantage statistics over the minibatch (model.py:136-139), f64 accumulation
 __global__ __launch_bounds__(256) void advstat_part_kernel(const float* __restrict__ ret, const float* __restrict__ val,
                                                            const int64_t* __restrict__ idx, int B, int T, int N,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, int32_t* __restrict__ srow_out,
+                                                           int srow_cap) {
     __shared__ double sh[4];
     double s = 0.0, s2 = 0.0;
     for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
         long r = idx ? envmajor_to_row(idx[b], T, N) : b;
+        if (idx && srow_out && b < srow_cap) srow_out[b] = (int32_t)r;     // translated once, reused by the loaders
         float a = __fsub_rn(ret[r], val[r]);
         s += (double)a;
         s2 += (double)a * (double)a;
@@ -627,6 +629,15 @@ __global__ void heads_stats_reduce_kernel(const double* __restrict__ spart, int 
         double s = acc[j];
         for (int b = 0; b < nblk; ++b) s += spart[b * 5 + j];
         acc[j] = s;
+    }
+}
+// both steps in one launch: out[j] = (sum_blk spart[blk][j]) * invB
+__global__ void stats_reduce_finalize_kernel(const double* __restrict__ spart, int nblk, float invB, float* __restrict__ out) {
+    int j = threadIdx.x;
+    if (j < 5) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += spart[b * 5 + j];
+        out[j] = (float)(s * (double)invB);
     }
 }
 __global__ void stats_finalize_kernel(const double* __restrict__ acc, float invB, float* __restrict__ out) {
@@ -1097,11 +1108,10 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     double* advpart = ws.dscratch;
     double* spart = ws.dscratch + ADV_G * 2;
     double* stats_acc = spart + SPART_MAX * 5;
-    MRL_HIP_CHECK(hipMemsetAsync(ws.zeros, 0, 1024, st));
     // minibatch advantage statistics (model.py:136-139)
     int G = std::min(ADV_G, (B + 255) / 256);
     ProfScope* psadv = new ProfScope("adv_stats", 0.0, (idx ? 16.0 : 8.0) * B, st);
-    hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, B, T, N, advpart);
+    hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, B, T, N, advpart, ws.srow, chunk);
     MRL_LAUNCH_CHECK();
     hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, B, ws.advstat, stats_acc);
     delete psadv;
@@ -1136,11 +1146,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
                 if (dbgon < 0) { const char* ev = getenv("MRL_MLP_DBG"); dbgon = ev ? atoi(ev) : 0; }
                 a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
             }
-            if (idx) {
-                hipLaunchKernelGGL(translate_idx_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, T, N, ws.srow);
-                MRL_LAUNCH_CHECK();
-                a.srow = ws.srow;
-            }
+            if (idx) a.srow = ws.srow;                       // filled by advstat_part_kernel (B <= chunk here)
             const size_t lds = mlp_step_lds_bytes(K0, nets);
             static bool raised = false;
             if (!raised) {
@@ -1157,9 +1163,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
             MRL_LAUNCH_CHECK();
             int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, ntiles, stats_acc);
-            MRL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, st, stats_acc, invB, stats_out);
+            hipLaunchKernelGGL(stats_reduce_finalize_kernel, dim3(1), dim3(64), 0, st, spart, ntiles, invB, stats_out);
             MRL_LAUNCH_CHECK();
             return 0;
         }
@@ -1169,8 +1173,10 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
         const int accumulate = c0 > 0;
         In in;
         if (idx) {
-            hipLaunchKernelGGL(translate_idx_kernel, dim3((Bc + 255) / 256), dim3(256), 0, st, idx + c0, Bc, T, N, ws.srow);
-            MRL_LAUNCH_CHECK();
+            if (c0 > 0) {                                // chunk 0 was translated by advstat_part_kernel
+                hipLaunchKernelGGL(translate_idx_kernel, dim3((Bc + 255) / 256), dim3(256), 0, st, idx + c0, Bc, T, N, ws.srow);
+                MRL_LAUNCH_CHECK();
+            }
             in.obs = obs; in.srow = ws.srow;
         } else {
             in.obs = (const char*)obs + (size_t)c0 * ob_bytes; in.srow = nullptr;

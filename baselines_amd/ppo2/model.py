@@ -84,6 +84,7 @@ class Model(object):
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(torch.initial_seed()) & 0x7fffffff)
         self._train_calls = 0
+        self._fast = None
         # ---- multi-rank: total weight (mpi_adam_optimizer.py:25-27), sync_from_root (model.py:129-131) ----
         self.total_weight = 1.0
         if self.comm is not None and self.comm.Get_size() > 1:
@@ -162,12 +163,46 @@ class Model(object):
     def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None):
         """One minibatch step reading the device rollout in place: `idx_dev` (int64 device tensor) holds
         the reference's env-major flat indices (ppo2.py:160-162); the gather is fused into the
-        first-layer loaders.  Returns a device tensor [5] (no host sync)."""
+        first-layer loaders.  Returns a device tensor [5] (no host sync).
+
+        This is the per-step host path of the launch-bound MLP configs (320 steps per update), so the
+        device pointers of the long-lived buffers are cached and the two C calls are made directly."""
         stats = stats_out if stats_out is not None else torch.empty(5, dtype=torch.float32, device=self.device)
-        self.dm.grad(self.params, rollout.obs, rollout.actions, rollout.returns, rollout.values, rollout.neglogpacs,
-                     idx_dev, idx_dev.numel(), rollout.T, rollout.N, cliprange, self.ent_coef, self.vf_coef,
-                     self.grads, stats)
-        self._apply_gradients(lr)
+        c = self._fast
+        if c is None or c['ro'] is not rollout or c['obs_ptr'] != rollout.obs.data_ptr():
+            vp = _lib.c_void_p
+            lib = _lib.load()
+            c = self._fast = dict(
+                ro=rollout, obs_ptr=rollout.obs.data_ptr(), lib=lib, h=self.dm.handle, params=_lib.ptr(self.params),
+                grads=_lib.ptr(self.grads), m=_lib.ptr(self.adam_m), v=_lib.ptr(self.adam_v),
+                ws=_lib.ptr(self.dm.workspace), wsn=self.dm.workspace.numel(), chunk=self.dm.chunk,
+                obs=_lib.ptr(rollout.obs), act=_lib.ptr(rollout.actions), val=_lib.ptr(rollout.values),
+                nlp=_lib.ptr(rollout.neglogpacs), scratch=_lib.ptr(self._scratch), gnorm=_lib.ptr(self._gnorm),
+                T=int(rollout.T), N=int(rollout.N), P=self.params.numel())
+        if self.multi:
+            self.dm.grad(self.params, rollout.obs, rollout.actions, rollout.returns, rollout.values, rollout.neglogpacs,
+                         idx_dev, idx_dev.numel(), rollout.T, rollout.N, cliprange, self.ent_coef, self.vf_coef,
+                         self.grads, stats)
+            self._apply_gradients(lr)
+            return stats
+        st = _lib.stream_ptr()
+        lib = c['lib']
+        rc = lib.mrl_model_grad(c['h'], c['params'], c['obs'], c['act'], _lib.ptr(rollout.returns), c['val'], c['nlp'],
+                                _lib.ptr(idx_dev), idx_dev.numel(), c['T'], c['N'], float(cliprange), self.ent_coef,
+                                self.vf_coef, c['grads'], _lib.ptr(stats), c['ws'], c['wsn'], c['chunk'], st)
+        if rc:
+            _lib.check(rc, 'mrl_model_grad')
+        one = np.float32(1)
+        alpha = np.float32(lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
+        mgn = -1.0 if self.max_grad_norm is None else float(self.max_grad_norm)
+        rc = lib.mrl_adam_clip_step(c['params'], c['grads'], c['m'], c['v'], c['P'], float(alpha), float(self.beta1),
+                                    float(self.beta2), float(self.epsilon), mgn, float(self.total_weight), c['gnorm'],
+                                    c['scratch'], st)
+        if rc:
+            _lib.check(rc, 'mrl_adam_clip_step')
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self._train_calls += 1
         return stats
 
     def _field(self, x, dtype):
