@@ -980,15 +980,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
                     ProfScope ps(label, fl, 0.0, st);
-                    static int prio = -1;
-                    if (prio < 0) { const char* ev = getenv("MRL_LDSDGRAD_PRIO"); prio = ev ? atoi(ev) : 0; }
                     hipError_t e;
                     const float* wsrc = params + l.w_off;
-                    // MRL_LDSDGRAD_PRIO (experiment knob): 0 = normal, 1 = no epilogue, 2 = no staging, 3 = neither
-                    #define MRL_LD(DBG) (lk == 1 ? launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1, DBG>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st) \
-                                                 : launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1, DBG>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st))
-                    if (prio == 3) e = MRL_LD(3); else if (prio == 2) e = MRL_LD(2); else if (prio == 1) e = MRL_LD(1); else e = MRL_LD(0);
-                    #undef MRL_LD
+                    // 16 waves x 1 row tile, groups of 5 / 6 images (measured alternatives in profiles/README.md:
+                    // 8 waves x 2 tiles and two half-size workgroups per CU are slower)
+                    if (lk == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st);
+                    else e = launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st);
                     rc = (int)e;
                 } else
                 if (dv >= V_WRES16 && wok) {
