@@ -835,6 +835,14 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
             if (first) {
                 WresFwdA<true> wa;
                 fill_conv(wa, l, in.obs, npix, in.srow);
+                static int x3 = -1;          // MRL_U8_BF16X3=0 falls back to the fp32 MFMA path (bitwise fmaf chain)
+                if (x3 < 0) { const char* ev = getenv("MRL_U8_BF16X3"); x3 = ev ? atoi(ev) : 1; }
+                if (x3 && l.NF == 32 && l.K % 256 == 0) {
+                    char label[40];
+                    if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
+                    ProfScope ps(label, fl, 0.0, st);
+                    return (int)launch_wres_u8x3<WresEpiBiasAct, WRES_PF, 16>(wa, W, we, l.K, l.NF, tiles, num_cus(), st);
+                }
                 return wres_dispatch(l.name, "fwd", var, l.NF, wa, wb, we, 1, l.K, tiles, fl, st);
             } else {
                 WresFwdA<false> wa;
