@@ -233,6 +233,8 @@ def main():
             'config': {'workload': 'ppo2 update-only (GAE + %dx%d minibatch steps) %s-shaped %s num_envs=%d nsteps=%d'
                                    % (hp['noptepochs'], hp['nminibatches'], args.workload, hp['network'], total_envs, T),
                        'envs_per_gpu': N, 'nbatch_train_per_gpu': nbatch_train, 'chunk': model.dm.chunk,
+                       'arithmetic': 'fp32 accumulate everywhere; fp32 MFMA (bitwise fmaf chain) except the first conv '
+                                     'forward, where exact uint8 pixels meet a 3-way bf16 split of filter/255 on the bf16 pipe',
                        'parallelism': 'dp%d (envs sharded, 1 RCCL all-reduce/minibatch)' % world},
             'model_tflops': flops_per_sample_visit * total_envs * T * hp['noptepochs'] * args.steps / dt / 1e12,
             'full_iteration_env_steps_per_s': total_envs * T / (t_rollout + dt / args.steps),
