@@ -312,4 +312,196 @@ inline hipError_t launch_imgres_wgrad(const void* x, const int32_t* srow, const 
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// First-layer weight gradient on the BF16 matrix pipe ("bf16 x 3", see wres.hip.h): the A operand is raw
+// uint8 pixels (exact in bf16), dz is split into three bf16 planes (hi + mid + lo == dz exactly), so every
+// product is exact in the fp32 accumulator; 3 v_mfma_f32_32x32x16_bf16 per 16 pixels instead of 8 fp32
+// MFMAs per 16 pixels.  The reduction index of this GEMM is the PIXEL, and a bf16 MFMA fragment is 8
+// consecutive reduction elements per lane, so both operands need pixel-contiguous runs:
+//   * dz is staged fp32 row-major (coalesced), then transposed + split in LDS into dzT[plane][n][pixel]
+//     bf16 (a lane reads 8 dz column values, writes three 16-byte runs);
+//   * the image stays raw u8: lane (i = byte inside the patch row, g) gathers its 8 pixels with 8 ds_read_u8
+//     at compile-time offsets and packs them to bf16.
+// dW is accumulated on unscaled pixels and divided by 255 once at the end (models.py:19).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 ir_bf16x8 __attribute__((ext_vector_type(8)));
+struct IrU32x4 { uint32_t x, y, z, w; };
+
+template <int H, int W, int C, int RF, int STRIDE, int NF>
+struct ImgResX3Cfg {
+    static constexpr int OH = (H - RF) / STRIDE + 1, OW = (W - RF) / STRIDE + 1, NPIX = OH * OW;
+    static constexpr int ROWK = RF * C, K = RF * RF * C, MT = K / 32;
+    static constexpr int WAVES = MT, NT = WAVES * 64;
+    static constexpr int XBYTES = H * W * C, XV = XBYTES / 16;
+    static constexpr int DZV = NPIX * NF / 4;
+    static constexpr int NPIXP = NPIX + 8;                          // bf16 elements per dzT row
+    static constexpr int PLANE = NF * NPIXP;                        // bf16 elements per plane
+    static constexpr int OFF_DZF = XBYTES;                          // fp32 staging of dz [NPIX][NF]
+    static constexpr int OFF_DZT = OFF_DZF + NPIX * NF * 4;         // 3 bf16 planes
+    static constexpr size_t LDS_BYTES = (size_t)OFF_DZT + 3 * (size_t)PLANE * 2;
+    static_assert(ROWK == 32 && NF == 32 && NPIX % 16 == 0 && XBYTES % 16 == 0 && MT == RF && NT == 512, "c1-shaped layers only");
+    static_assert(LDS_BYTES <= 160 * 1024, "image + dz staging + planes must fit the CU's LDS");
+    static constexpr int a_off(int p) { return ((p / OW) * STRIDE * W + (p % OW) * STRIDE) * C; }
+};
+
+__device__ __forceinline__ uint32_t ir_bf16_rn_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int H, int W, int C, int RF, int STRIDE, int NF>
+__global__ __launch_bounds__(512) void imgres_u8x3_wgrad_kernel(
+    const void* __restrict__ x, const int32_t* __restrict__ srow, const float* __restrict__ dz, int B,
+    float* __restrict__ part) {
+    using G = ImgResX3Cfg<H, W, C, RF, STRIDE, NF>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* xs = lds;
+    float* dzf = reinterpret_cast<float*>(lds + G::OFF_DZF);
+    uint16_t* dzt = reinterpret_cast<uint16_t*>(lds + G::OFF_DZT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 bias4 = f4zero();
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        // ---- stage: image bytes and fp32 dz, coalesced 16-byte vectors, loads batched before the LDS writes
+        __syncthreads();                                     // previous image fully consumed
+        {
+            const long img = srow ? (long)srow[b] : (long)b;
+            const uint4* gx = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(x) + img * G::XBYTES);
+            const float4* gd = reinterpret_cast<const float4*>(dz + (long)b * G::NPIX * NF);
+            constexpr int NXV = (G::XV + G::NT - 1) / G::NT, NDV = (G::DZV + G::NT - 1) / G::NT;
+            uint4 vx[NXV];
+            float4 vd[NDV];
+#pragma unroll
+            for (int q = 0; q < NXV; ++q) { const int e = tid + q * G::NT; vx[q] = gx[min(e, G::XV - 1)]; }
+#pragma unroll
+            for (int q = 0; q < NDV; ++q) { const int e = tid + q * G::NT; vd[q] = gd[min(e, G::DZV - 1)]; }
+#pragma unroll
+            for (int q = 0; q < NXV; ++q) { const int e = tid + q * G::NT; if (e < G::XV) reinterpret_cast<uint4*>(xs)[e] = vx[q]; }
+#pragma unroll
+            for (int q = 0; q < NDV; ++q) {
+                const int e = tid + q * G::NT;
+                if (e < G::DZV) {
+                    reinterpret_cast<float4*>(dzf)[e] = vd[q];
+                    bias4.x += vd[q].x; bias4.y += vd[q].y; bias4.z += vd[q].z; bias4.w += vd[q].w;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- transpose + 3-way bf16 split: unit = (column n, run of 8 pixels)
+        for (int u = tid; u < NF * (G::NPIX / 8); u += G::NT) {
+            const int n = u % NF, grp = u / NF;              // consecutive lanes -> consecutive n: conflict-free reads
+            uint32_t pk[3][4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                uint32_t hb[3][2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float v = dzf[(grp * 8 + e2 * 2 + hh) * NF + n];
+                    const uint32_t h0 = ir_bf16_rn_bits(v);
+                    const float r1 = v - __uint_as_float(h0 << 16);
+                    const uint32_t h1 = ir_bf16_rn_bits(r1);
+                    const float r2 = r1 - __uint_as_float(h1 << 16);
+                    const uint32_t h2 = ir_bf16_rn_bits(r2);
+                    hb[0][hh] = h0; hb[1][hh] = h1; hb[2][hh] = h2;
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pk[pl][e2] = (hb[pl][0] & 0xffffu) | (hb[pl][1] << 16);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint4*>(dzt + (long)pl * G::PLANE + (long)n * G::NPIXP + grp * 8) =
+                    make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+        }
+        __syncthreads();
+        // ---- MFMA stream: wave = patch row ky; block = 16 pixels (lane half g takes pixels 8g .. 8g+7)
+        // launder the lane constant: otherwise all 200 `g ? o1 : o0` offsets are loop-invariant across images
+        // and get hoisted out of the image loop (200 live VGPRs -> spills)
+        int gq = g;
+        asm volatile("" : "+v"(gq));
+        const uint8_t* xrow = xs + wave * W * C + i;
+        const uint16_t* brow = dzt + (long)i * G::NPIXP + 8 * gq;
+        // bytes of block blk+1 are read before the MFMAs of block blk; sched_barrier keeps the compiler from
+        // hoisting all 200 byte reads of the unrolled loop (it does, and spills)
+        auto rdbytes = [&](int blk, uint32_t (&by)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int o0 = G::a_off(16 * blk + e), o1 = G::a_off(16 * blk + 8 + e);
+                by[e] = xrow[gq ? o1 : o0];
+            }
+        };
+        uint32_t by[8], nb[8];
+        rdbytes(0, by);
+#pragma unroll
+        for (int blk = 0; blk < G::NPIX / 16; ++blk) {
+            if (blk + 1 < G::NPIX / 16) rdbytes(blk + 1, nb);
+            IrU32x4 a;
+            {
+                const uint32_t f0 = __float_as_uint((float)by[0]), f1 = __float_as_uint((float)by[1]);
+                const uint32_t f2 = __float_as_uint((float)by[2]), f3 = __float_as_uint((float)by[3]);
+                const uint32_t f4 = __float_as_uint((float)by[4]), f5 = __float_as_uint((float)by[5]);
+                const uint32_t f6 = __float_as_uint((float)by[6]), f7 = __float_as_uint((float)by[7]);
+                a.x = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+                a.y = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+                a.z = __builtin_amdgcn_perm(f5, f4, 0x07060302u);
+                a.w = __builtin_amdgcn_perm(f7, f6, 0x07060302u);
+            }
+            const ir_bf16x8 av = __builtin_bit_cast(ir_bf16x8, a);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const ir_bf16x8 bv = *reinterpret_cast<const ir_bf16x8*>(brow + (long)pl * G::PLANE + 16 * blk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+            }
+            if (blk + 1 < G::NPIX / 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) by[e] = nb[e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- partial slab of this workgroup: [K][NF] weights (scaled by 1/255) then [NF] bias
+    const long slab = (long)G::K * NF + NF;
+    float* out = part + (long)blockIdx.x * slab;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        out[(long)m * NF + i] = acc[r] / 255.f;
+    }
+    float4* red = reinterpret_cast<float4*>(lds);
+    __syncthreads();
+    red[tid] = bias4;
+    __syncthreads();
+    if (tid < NF) {
+        constexpr int GROUPS = NF / 4;
+        const int gq = tid / 4, comp = tid % 4;
+        float t = 0.f;
+        for (int q = gq; q < G::NT; q += GROUPS) {
+            const float4 v = red[q];
+            t += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+        }
+        out[(long)G::K * NF + tid] = t;
+    }
+}
+
+template <int H, int W, int C, int RF, int STRIDE, int NF>
+inline hipError_t launch_imgres_u8x3_wgrad(const void* x, const int32_t* srow, const float* dz, int B, float* part,
+                                           int nblocks, hipStream_t stream) {
+    using G = ImgResX3Cfg<H, W, C, RF, STRIDE, NF>;
+    auto kern = imgres_u8x3_wgrad_kernel<H, W, C, RF, STRIDE, NF>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, srow, dz, B, part);
+    return hipGetLastError();
+}
+
 }  // namespace mrl

@@ -803,7 +803,11 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     hipError_t e;
     static int nacc = -1;              // MRL_IMGRES_NACC=1|2|4: accumulator replicas per wave (experiment knob)
     if (nacc < 0) { const char* ev = getenv("MRL_IMGRES_NACC"); nacc = ev ? atoi(ev) : 0; }
-    if (kind == 1) {
+    static int x3 = -1;                // MRL_U8_BF16X3=0: fp32 MFMA path for the u8 layer
+    if (x3 < 0) { const char* ev = getenv("MRL_U8_BF16X3"); x3 = ev ? atoi(ev) : 1; }
+    if (kind == 1 && x3 && !hcur) {
+        e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
+    } else if (kind == 1) {
         if (nacc == 1) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 1>(x, srow, dz, hcur, B, part, nblocks, st);
         else if (nacc == 2) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 2>(x, srow, dz, hcur, B, part, nblocks, st);
         else e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 4>(x, srow, dz, hcur, B, part, nblocks, st);
