@@ -234,7 +234,8 @@ def main():
                                    % (hp['noptepochs'], hp['nminibatches'], args.workload, hp['network'], total_envs, T),
                        'envs_per_gpu': N, 'nbatch_train_per_gpu': nbatch_train, 'chunk': model.dm.chunk,
                        'arithmetic': 'fp32 accumulate everywhere; fp32 MFMA (bitwise fmaf chain) except the first conv '
-                                     'forward, where exact uint8 pixels meet a 3-way bf16 split of filter/255 on the bf16 pipe',
+                                     'layer (forward and weight gradient), where exact uint8 pixels meet a 3-way bf16 split of '
+                                     'the other operand on the bf16 pipe',
                        'parallelism': 'dp%d (envs sharded, 1 RCCL all-reduce/minibatch)' % world},
             'model_tflops': flops_per_sample_visit * total_envs * T * hp['noptepochs'] * args.steps / dt / 1e12,
             'full_iteration_env_steps_per_s': total_envs * T / (t_rollout + dt / args.steps),
