@@ -65,6 +65,7 @@ SIGNATURES = {
     'mrl_dqn_td_scratch_bytes': (c_size_t, [c_int]),
     'mrl_dqn_td': (c_int, [c_void_p] * 7 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     'mrl_tune_set': (c_int, [c_char_p, c_int]),
+    'mrl_set_option': (c_int, [c_char_p, c_int]),
     'mrl_prof_enable': (c_int, [c_int]),
     'mrl_prof_num_labels': (c_int, []),
     'mrl_prof_get': (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_double),
@@ -162,3 +163,8 @@ def prof_report():
 def tune_set(label, variant):
     """Override the GEMM tile variant of one launch site ("c1.fwd", ...); variant < 0 restores the default."""
     check(load().mrl_tune_set(label.encode(), int(variant)), 'mrl_tune_set')
+
+
+def set_option(name, value):
+    """Engine option (include/mrl.h: "u8_bf16x3", "mlp_fused", ...)."""
+    check(load().mrl_set_option(name.encode(), int(value)), 'mrl_set_option')

@@ -213,6 +213,25 @@ static const int kVariantBM[V_COUNT] = {128, 256, 128, 128, 256, 128};
 static const int kVariantBN[V_COUNT] = {32, 32, 64, 64, 64, 128};
 
 static std::map<std::string, int>& tune_table() { static std::map<std::string, int> t; return t; }
+
+// ---- process-wide options (engine selection knobs; defaults from the environment on first use) --------
+static std::map<std::string, int>& option_table() { static std::map<std::string, int> t; return t; }
+static int get_option(const char* name, const char* env, int dflt) {
+    auto& t = option_table();
+    auto it = t.find(name);
+    if (it != t.end()) return it->second;
+    const char* ev = getenv(env);
+    int v = ev ? atoi(ev) : dflt;
+    t[name] = v;
+    return v;
+}
+extern "C" int mrl_set_option(const char* name, int value) {
+    if (!name) return MRL_EINVAL;
+    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg"};
+    for (const char* k : known)
+        if (!strcmp(k, name)) { option_table()[name] = value; return 0; }
+    return MRL_EINVAL;
+}
 extern "C" int mrl_tune_set(const char* label, int variant) {
     if (!label || (variant >= 2 * V_COUNT && variant != V_WRES16 && variant != V_WRES8 && variant != V_IMGRES && variant != V_LDSDGRAD)) return MRL_EINVAL;
     if (variant < 0) tune_table().erase(label);
@@ -801,10 +820,8 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
     ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
     hipError_t e;
-    static int nacc = -1;              // MRL_IMGRES_NACC=1|2|4: accumulator replicas per wave (experiment knob)
-    if (nacc < 0) { const char* ev = getenv("MRL_IMGRES_NACC"); nacc = ev ? atoi(ev) : 0; }
-    static int x3 = -1;                // MRL_U8_BF16X3=0: fp32 MFMA path for the u8 layer
-    if (x3 < 0) { const char* ev = getenv("MRL_U8_BF16X3"); x3 = ev ? atoi(ev) : 1; }
+    const int nacc = get_option("imgres_nacc", "MRL_IMGRES_NACC", 0);   // accumulator replicas per wave (experiment knob)
+    const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);          // 0: fp32 MFMA path for the u8 layer
     if (kind == 1 && x3 && !hcur) {
         e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
     } else if (kind == 1) {
@@ -839,8 +856,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
             if (first) {
                 WresFwdA<true> wa;
                 fill_conv(wa, l, in.obs, npix, in.srow);
-                static int x3 = -1;          // MRL_U8_BF16X3=0 falls back to the fp32 MFMA path (bitwise fmaf chain)
-                if (x3 < 0) { const char* ev = getenv("MRL_U8_BF16X3"); x3 = ev ? atoi(ev) : 1; }
+                const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);   // 0: fp32 MFMA path (bitwise fmaf chain)
                 if (x3 && l.NF == 32 && l.K % 256 == 0) {
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
@@ -906,8 +922,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
     // j's OUTPUT and both of its consumers (layer j's weight- and data-gradient kernels) apply (h[j] > 0)
     // while staging it into LDS.  Only when every consumer is one of the LDS-resident engines.
     std::vector<char> defer(net.L.size(), 0);
-    static int defer_on = -1;
-    if (defer_on < 0) { const char* ev = getenv("MRL_DEFER_MASK"); defer_on = ev ? atoi(ev) : 0; }
+    const int defer_on = get_option("defer_mask", "MRL_DEFER_MASK", 0);
     for (size_t j = 0; defer_on && j + 1 < net.L.size(); ++j) {
         const Layer& lj = net.L[j];
         const void* src = j == 0 ? in.obs : (const void*)nw.h[j - 1];
@@ -1129,8 +1144,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     const float invB = 1.f / (float)B;
     // ---- fused whole-step kernel for the 2 x 64 tanh MLP (mlpstep.hip.h)
     {
-        static int fused = -1;
-        if (fused < 0) { const char* ev = getenv("MRL_MLP_FUSED"); fused = ev ? atoi(ev) : 1; }
+        const int fused = get_option("mlp_fused", "MRL_MLP_FUSED", 1);
         const mrl_model_desc& d = m->d;
         const int ntiles = (B + 31) / 32;
         const int K0 = (int)m->ob_elems;
@@ -1151,8 +1165,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
             a.neglogp = neglogpacs; a.advstat = ws.advstat; a.cliprange = cliprange; a.ent_coef = ent_coef;
             a.vf_coef = vf_coef; a.invB = invB; a.B = B; a.part = ws.part; a.spart = spart;
             {   // MRL_MLP_DBG=1: phase timestamps of workgroup 0 land in the last 64 bytes of the zero page
-                static int dbgon = -1;
-                if (dbgon < 0) { const char* ev = getenv("MRL_MLP_DBG"); dbgon = ev ? atoi(ev) : 0; }
+                const int dbgon = get_option("mlp_dbg", "MRL_MLP_DBG", 0);
                 a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
             }
             if (idx) a.srow = ws.srow;                       // filled by advstat_part_kernel (B <= chunk here)

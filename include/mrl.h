@@ -195,6 +195,13 @@ int mrl_prof_get(int i, char* name, int name_cap, long* count, double* total_ms,
  * (e.g. "c1.fwd"); variant < 0 restores the built-in choice.  Results are identical for every
  * variant of the forward / data-gradient GEMMs; weight-gradient split-K changes summation order. */
 int mrl_tune_set(const char* label, int variant);
+/* Engine options (process-wide; defaults also settable through the environment variable in brackets):
+ *   "u8_bf16x3"  [MRL_U8_BF16X3, 1]  first conv layer (uint8 pixels) on the bf16 pipe with an exact 3-way
+ *                  bf16 split of the other operand; 0 = fp32 MFMA (bitwise fmaf chain)
+ *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
+ *   "defer_mask" [MRL_DEFER_MASK, 0], "imgres_nacc", "mlp_dbg": experiment knobs
+ * Returns MRL_EINVAL for unknown names. */
+int mrl_set_option(const char* name, int value);
 
 #ifdef __cplusplus
 }

@@ -249,3 +249,48 @@ def test_adam_clip_matches_oracle_many_steps():
     np.testing.assert_allclose(params.cpu().numpy(), om.p['x'].numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(m.cpu().numpy(), om.m['x'].numpy(), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(v.cpu().numpy(), om.v['x'].numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_engine_options_agree():
+    """The fast engines against their plain counterparts on the same minibatch:
+       * first conv layer on the bf16 pipe (exact u8 x 3-way bf16 split) vs the fp32 MFMA path,
+       * fused whole-step MLP kernel vs layer-wise launches.
+    Gradients agree to fp32 round-off (the split products are exact; only the summation order and the
+    folded 1/255 scale differ), well inside the 1e-5 loss-parity bar."""
+    from baselines_amd import _lib as L
+    from baselines_amd import ops
+    rng = np.random.RandomState(0)
+
+    def grads(network, ob_shape, ob_dtype, pd_kind, nact, value_copy, B, opt, val):
+        L.set_option(opt, val)
+        dm = ops.DeviceModel(network=network, ob_shape=ob_shape, ob_dtype=ob_dtype, pd_kind=pd_kind, nact=nact,
+                             value_copy=value_copy, chunk=B)
+        r = np.random.RandomState(1)
+        params = torch.from_numpy((r.randn(dm.P) * 0.05).astype(np.float32)).cuda()
+        if ob_dtype == np.uint8:
+            obs = torch.from_numpy(r.randint(0, 256, (B,) + ob_shape).astype(np.uint8)).cuda()
+        else:
+            obs = torch.from_numpy(r.randn(B, *ob_shape).astype(np.float32)).cuda()
+        if pd_kind == 'categorical':
+            act = torch.from_numpy(r.randint(0, nact, B).astype(np.int32)).cuda()
+        else:
+            act = torch.from_numpy(r.randn(B, nact).astype(np.float32)).cuda()
+        ret, val_, nlp = (torch.from_numpy(r.randn(B).astype(np.float32)).cuda() for _ in range(3))
+        nlp = nlp.abs() + 1.0
+        g = torch.empty(dm.P, dtype=torch.float32, device='cuda')
+        st = torch.empty(5, dtype=torch.float32, device='cuda')
+        dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
+        return g.cpu().numpy(), st.cpu().numpy()
+
+    try:
+        for net, shp, dt, pd, na, vc, B, opt in [('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False, 160, 'u8_bf16x3'),
+                                                 ('mlp', (376,), np.float32, 'gaussian', 17, True, 200, 'mlp_fused'),
+                                                 ('mlp', (4,), np.float32, 'categorical', 2, False, 96, 'mlp_fused')]:
+            g1, s1 = grads(net, shp, dt, pd, na, vc, B, opt, 1)
+            g0, s0 = grads(net, shp, dt, pd, na, vc, B, opt, 0)
+            scale = np.abs(g0).max()
+            assert np.abs(g1 - g0).max() <= 2e-6 * scale + 1e-9, (opt, np.abs(g1 - g0).max(), scale)
+            np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
+    finally:
+        L.set_option('u8_bf16x3', 1)
+        L.set_option('mlp_fused', 1)
