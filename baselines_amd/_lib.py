@@ -64,6 +64,11 @@ SIGNATURES = {
                                c_void_p, c_void_p]),
     'mrl_dqn_td_scratch_bytes': (c_size_t, [c_int]),
     'mrl_dqn_td': (c_int, [c_void_p] * 7 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
+    'mrl_framestack_step': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    'mrl_vecnorm_ob': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p,
+                               c_void_p, c_void_p]),
+    'mrl_vecnorm_rew': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double, c_double, c_double, c_double,
+                                c_void_p, c_void_p, c_void_p]),
     'mrl_tune_set': (c_int, [c_char_p, c_int]),
     'mrl_set_option': (c_int, [c_char_p, c_int]),
     'mrl_prof_enable': (c_int, [c_int]),

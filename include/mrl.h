@@ -180,6 +180,25 @@ int mrl_synth_env_step(uint32_t seed, int ob_elems, int ob_u8, int discrete, int
                        const int32_t* actions, void* obs_out, float* rew_out, uint8_t* done_out,
                        float* fin_r_out, int32_t* fin_l_out, void* stream);
 
+/* ---- actor-side wrappers on the device -----------------------------------
+ * K11 VecFrameStack.step_wait / reset --- common/vec_env/vec_frame_stack.py:17-30.  stacked [N][pix][S],
+ * obs [N][pix][C], elements of `esize` bytes (1 or 4); in place.  Reference semantics: the stack axis is
+ * rolled left by ONE element per step (np.roll shift=-1: a frame shift when C == 1), envs with news != 0
+ * are zeroed (reset != 0: all of them), the last C elements become the new observation. */
+int mrl_framestack_step(void* stacked, const void* obs, const uint8_t* news, int N, long pix, int S, int C,
+                        int esize, int reset, void* stream);
+/* K12 VecNormalize --- common/vec_env/vec_normalize.py:26-47, common/running_mean_std.py:12-33.
+ * ob: batch mean/var per column in float32, row after row (== np.mean/np.var(axis=0), bit-exact), merged
+ * into the float64 running mean[D] / var[D] (count = samples seen BEFORE this batch, host-tracked), then
+ * out = clip((obs - mean) / sqrt(var + epsilon), +-clipob) computed in float64; out_f64 may be NULL.
+ * rew: ret[N] (f64 state) = ret*gamma + rews; rms[2] = {mean, var} of ret updated the same way;
+ * out = clip(rews / sqrt(var + epsilon), +-cliprew); ret[news] = 0. */
+int mrl_vecnorm_ob(const float* obs, int N, int D, double* mean, double* var, double count, double epsilon,
+                   double clipob, float* out_f32, double* out_f64, void* stream);
+int mrl_vecnorm_rew(const float* rews, const uint8_t* news, int N, double* ret, double* rms, double count,
+                    double gamma, double epsilon, double cliprew, float* out_f32, double* out_f64,
+                    void* stream);
+
 /* ---- optional HIP-event profiler ------------------------------------------------------------
  * When enabled every kernel launch of the library is bracketed by hipEvents recorded on the launch
  * stream, accumulated per label ("c1.fwd", "c2.wgrad", "heads", "clip+adam", ...) together with

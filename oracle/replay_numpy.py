@@ -207,3 +207,71 @@ def dqn_td(q_t, q_tp1_target, q_tp1_online, actions, rewards, dones, weights, ga
     dq = np.zeros_like(q_t)
     dq[ar, actions] = w * dtd / np.float32(B)
     return td, weighted, dq
+
+
+# ---------------------------------------------------------------------------------------------
+# actor-side wrappers: CPU restatement of
+#   baselines/common/vec_env/vec_frame_stack.py:6-30, vec_normalize.py:4-47,
+#   baselines/common/running_mean_std.py:5-33
+# pinned by tests/golden/wrappers.npz (reference classes run verbatim, oracle/make_golden_wrappers.py)
+# ---------------------------------------------------------------------------------------------
+def framestack_reset(obs, nstack):
+    """vec_frame_stack.py:26-30"""
+    stacked = np.zeros(obs.shape[:-1] + (obs.shape[-1] * nstack,), obs.dtype)
+    stacked[..., -obs.shape[-1]:] = obs
+    return stacked
+
+
+def framestack_step(stacked, obs, news):
+    """vec_frame_stack.py:17-24.  NOTE the reference rolls the channel axis by ONE ELEMENT
+    (`np.roll(..., shift=-1, axis=-1)`), not by one frame: identical for single-channel frames (the Atari
+    case), but for C > 1 the history slides by a single channel per step.  Restated as is."""
+    c = obs.shape[-1]
+    out = np.empty_like(stacked)
+    out[..., :-1] = stacked[..., 1:]
+    out[..., -1] = stacked[..., 0]           # wrapped element (overwritten below since c >= 1)
+    out[np.asarray(news, bool)] = 0
+    out[..., -c:] = obs
+    return out
+
+
+class RunningMeanStdOracle(object):
+    """running_mean_std.py:5-33 (float64 state, count starts at 1e-4, var at 1)"""
+
+    def __init__(self, shape=(), epsilon=1e-4):
+        self.mean = np.zeros(shape, np.float64)
+        self.var = np.ones(shape, np.float64)
+        self.count = epsilon
+
+    def update(self, x):
+        bm, bv, bc = np.mean(x, axis=0), np.var(x, axis=0), x.shape[0]
+        delta = bm - self.mean
+        tot = self.count + bc
+        new_mean = self.mean + delta * bc / tot
+        m2 = self.var * self.count + bv * bc + np.square(delta) * self.count * bc / tot
+        self.mean, self.var, self.count = new_mean, m2 / tot, tot
+
+
+class VecNormalizeOracle(object):
+    """vec_normalize.py:4-47 with ob=True, ret=True, use_tf=False"""
+
+    def __init__(self, num_envs, ob_shape, clipob=10., cliprew=10., gamma=0.99, epsilon=1e-8):
+        self.ob_rms, self.ret_rms = RunningMeanStdOracle(ob_shape), RunningMeanStdOracle(())
+        self.clipob, self.cliprew, self.gamma, self.epsilon = clipob, cliprew, gamma, epsilon
+        self.ret = np.zeros(num_envs)
+
+    def obfilt(self, obs):
+        self.ob_rms.update(obs)
+        return np.clip((obs - self.ob_rms.mean) / np.sqrt(self.ob_rms.var + self.epsilon), -self.clipob, self.clipob)
+
+    def reset(self, obs):
+        self.ret = np.zeros_like(self.ret)
+        return self.obfilt(obs)
+
+    def step(self, obs, rews, news):
+        self.ret = self.ret * self.gamma + rews
+        obs = self.obfilt(obs)
+        self.ret_rms.update(self.ret)
+        rews = np.clip(rews / np.sqrt(self.ret_rms.var + self.epsilon), -self.cliprew, self.cliprew)
+        self.ret[np.asarray(news, bool)] = 0.
+        return obs, rews

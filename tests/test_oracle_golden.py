@@ -137,3 +137,31 @@ def test_dqn_td_against_torch_autograd():
     np.testing.assert_allclose(td, tdt.detach().numpy(), atol=1e-6)
     np.testing.assert_allclose(loss, float(lt), rtol=1e-6)
     np.testing.assert_allclose(dq, tq.grad.numpy(), atol=1e-7)
+
+
+# ---------------------------------------------------------------- actor-side wrappers (8 f2)
+@pytest.mark.parametrize('tag', ['fs_atari', 'fs_small'])
+def test_framestack_oracle_matches_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, 'wrappers.npz'))
+    obs, dones, nstack, want = g[tag + '_in_obs'], g[tag + '_in_dones'], int(g[tag + '_nstack']), g[tag + '_out']
+    st = R.framestack_reset(obs[0], nstack)
+    np.testing.assert_array_equal(st, want[0])
+    for t in range(1, len(obs)):
+        st = R.framestack_step(st, obs[t], dones[t])
+        np.testing.assert_array_equal(st, want[t])
+
+
+@pytest.mark.parametrize('tag', ['vn_mujoco', 'vn_small'])
+def test_vecnormalize_oracle_matches_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, 'wrappers.npz'))
+    obs, rews, dones = g[tag + '_in_obs'], g[tag + '_in_rews'], g[tag + '_in_dones']
+    vn = R.VecNormalizeOracle(obs.shape[1], obs.shape[2:])
+    np.testing.assert_array_equal(vn.reset(obs[0]), g[tag + '_out_obs'][0])
+    for t in range(1, len(obs)):
+        o, r = vn.step(obs[t], rews[t], dones[t])
+        np.testing.assert_array_equal(o, g[tag + '_out_obs'][t])          # float64, bit-exact
+        np.testing.assert_array_equal(r, g[tag + '_out_rews'][t - 1])
+    np.testing.assert_array_equal(vn.ob_rms.mean, g[tag + '_ob_mean'])
+    np.testing.assert_array_equal(vn.ob_rms.var, g[tag + '_ob_var'])
+    assert vn.ob_rms.count == float(g[tag + '_ob_count']) and vn.ret_rms.var == float(g[tag + '_ret_var'])
+    np.testing.assert_array_equal(vn.ret, g[tag + '_ret'])
