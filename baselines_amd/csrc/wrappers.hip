@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64) void vecnorm_stats_kernel(const float* __restri
     const double delta = (double)m32 - mean[c];
     const double tot = count + bc;
     const double new_mean = mean[c] + delta * bc / tot;
-    const double m_a = var[c] * count, m_b = (double)v32 * bc;
+    // batch_var (float32 array) * batch_count (Python int) stays float32 in NumPy before it meets the float64 state
+    const double m_a = var[c] * count, m_b = (double)__fmul_rn(v32, (float)N);
     const double M2 = m_a + m_b + delta * delta * count * bc / tot;
     mean[c] = new_mean;
     var[c] = M2 / tot;
