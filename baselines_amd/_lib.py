@@ -46,6 +46,10 @@ SIGNATURES = {
     'mrl_model_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                c_size_t, c_int, c_void_p]),
+    'mrl_model_grad_micro': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_clip_accumulate': (c_int, [c_void_p, c_void_p, c_long, c_float, c_float, c_int, c_void_p, c_void_p]),
     'mrl_adam_scratch_bytes': (c_size_t, [c_long]),
     'mrl_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),

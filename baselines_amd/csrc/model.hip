@@ -1115,17 +1115,22 @@ extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void
     return 0;
 }
 
-extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const void* obs, const void* actions,
-                              const float* returns, const float* values, const float* neglogpacs,
-                              const int64_t* idx, int B, int T, int N, float cliprange, float ent_coef,
-                              float vf_coef, float* grads_out, float* stats_out, void* workspace,
-                              size_t workspace_bytes, int chunk, void* stream) {
+// Gradient of the loss over samples [mb0, mb0+mbn) of a minibatch of Bstat samples whose advantage statistics
+// span the WHOLE minibatch: mb0 = 0, mbn = Bstat is Model.train (model.py:133-158); a proper sub-range is one
+// MicrobatchedModel step (microbatched_model.py:40-60: normalise once, then per-slice losses with means over the slice).
+static int model_grad_range(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                            const float* returns, const float* values, const float* neglogpacs,
+                            const int64_t* idx, int Bstat, int mb0, int mbn, int T, int N, float cliprange, float ent_coef,
+                            float vf_coef, float* grads_out, float* stats_out, void* workspace,
+                            size_t workspace_bytes, int chunk, void* stream) {
     if (!m || !params || !obs || !actions || !returns || !values || !neglogpacs || !grads_out || !stats_out ||
-        !workspace || B <= 0 || chunk <= 0)
+        !workspace || Bstat <= 0 || chunk <= 0 || mb0 < 0 || mbn <= 0 || mb0 + mbn > Bstat)
         return MRL_EINVAL;
     if (idx && (T <= 0 || N <= 0)) return MRL_EINVAL;
     if (idx && (long)T * N > 0x7fffffffL) return MRL_EUNSUP;
     hipStream_t st = (hipStream_t)stream;
+    const bool whole = mb0 == 0 && mbn == Bstat;
+    const int B = mbn;
     Ws ws;
     carve(m, chunk, (char*)workspace, ws);
     if (ws.total > workspace_bytes) return MRL_ENOSPC;
@@ -1133,14 +1138,25 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     double* spart = ws.dscratch + ADV_G * 2;
     double* stats_acc = spart + SPART_MAX * 5;
     // minibatch advantage statistics (model.py:136-139)
-    int G = std::min(ADV_G, (B + 255) / 256);
-    ProfScope* psadv = new ProfScope("adv_stats", 0.0, (idx ? 16.0 : 8.0) * B, st);
-    hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, B, T, N, advpart, ws.srow, chunk);
+    int G = std::min(ADV_G, (Bstat + 255) / 256);
+    ProfScope* psadv = new ProfScope("adv_stats", 0.0, (idx ? 16.0 : 8.0) * Bstat, st);
+    hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, Bstat, T, N, advpart,
+                       whole ? ws.srow : nullptr, chunk);
     MRL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, B, ws.advstat, stats_acc);
+    hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, Bstat, ws.advstat, stats_acc);
     delete psadv;
     MRL_LAUNCH_CHECK();
     const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
+    if (!whole) {                                   // the slice starts at sample mb0 of the minibatch
+        if (idx) {
+            idx += mb0;
+        } else {
+            const size_t act_bytes = m->d.pd_kind == MRL_PD_CATEGORICAL ? 4 : 4 * (size_t)m->d.nact;
+            obs = (const char*)obs + (size_t)mb0 * ob_bytes;
+            actions = (const char*)actions + (size_t)mb0 * act_bytes;
+            returns += mb0; values += mb0; neglogpacs += mb0;
+        }
+    }
     const float invB = 1.f / (float)B;
     // ---- fused whole-step kernel for the 2 x 64 tanh MLP (mlpstep.hip.h)
     {
@@ -1168,7 +1184,13 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
                 const int dbgon = get_option("mlp_dbg", "MRL_MLP_DBG", 0);
                 a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
             }
-            if (idx) a.srow = ws.srow;                       // filled by advstat_part_kernel (B <= chunk here)
+            if (idx) {
+                if (!whole) {
+                    hipLaunchKernelGGL(translate_idx_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, T, N, ws.srow);
+                    MRL_LAUNCH_CHECK();
+                }
+                a.srow = ws.srow;                            // else filled by advstat_part_kernel (B <= chunk here)
+            }
             const size_t lds = mlp_step_lds_bytes(K0, nets);
             static bool raised = false;
             if (!raised) {
@@ -1195,7 +1217,7 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
         const int accumulate = c0 > 0;
         In in;
         if (idx) {
-            if (c0 > 0) {                                // chunk 0 was translated by advstat_part_kernel
+            if (c0 > 0 || !whole) {                      // chunk 0 of a whole minibatch was translated by advstat_part_kernel
                 hipLaunchKernelGGL(translate_idx_kernel, dim3((Bc + 255) / 256), dim3(256), 0, st, idx + c0, Bc, T, N, ws.srow);
                 MRL_LAUNCH_CHECK();
             }
@@ -1241,4 +1263,22 @@ extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const voi
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, st, stats_acc, invB, stats_out);
     MRL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mrl_model_grad(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                              const float* returns, const float* values, const float* neglogpacs,
+                              const int64_t* idx, int B, int T, int N, float cliprange, float ent_coef,
+                              float vf_coef, float* grads_out, float* stats_out, void* workspace,
+                              size_t workspace_bytes, int chunk, void* stream) {
+    return model_grad_range(m, params, obs, actions, returns, values, neglogpacs, idx, B, 0, B, T, N, cliprange, ent_coef,
+                            vf_coef, grads_out, stats_out, workspace, workspace_bytes, chunk, stream);
+}
+
+extern "C" int mrl_model_grad_micro(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                                    const float* returns, const float* values, const float* neglogpacs,
+                                    const int64_t* idx, int B, int mb0, int mbn, int T, int N, float cliprange,
+                                    float ent_coef, float vf_coef, float* grads_out, float* stats_out, void* workspace,
+                                    size_t workspace_bytes, int chunk, void* stream) {
+    return model_grad_range(m, params, obs, actions, returns, values, neglogpacs, idx, B, mb0, mbn, T, N, cliprange,
+                            ent_coef, vf_coef, grads_out, stats_out, workspace, workspace_bytes, chunk, stream);
 }

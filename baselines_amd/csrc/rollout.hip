@@ -289,6 +289,49 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// MicrobatchedModel (microbatched_model.py:57-66): every microbatch gradient is averaged over ranks and clipped by
+// ITS OWN global norm (the reference sums `self.grads`, which model.py:105-112 defines post-clip), then summed.
+__global__ __launch_bounds__(256) void clip_accumulate_kernel(const float* __restrict__ g, float* __restrict__ acc, long P,
+                                                              float max_grad_norm, float total_weight, int first,
+                                                              const double* __restrict__ part, int npart) {
+    __shared__ double sh[4];
+    __shared__ float s_scale;
+    float scale = 1.f;
+    if (max_grad_norm >= 0.f) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < npart; i += 256) s += part[i];
+        double tot = block_sum_256(s, sh);
+        if (threadIdx.x == 0) {
+            float gn = (float)sqrt(tot);
+            s_scale = max_grad_norm * fminf(1.f / gn, 1.f / max_grad_norm);
+        }
+        __syncthreads();
+        scale = s_scale;
+    }
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < P; i += (long)gridDim.x * 256L) {
+        float x = g[i];
+        if (total_weight != 1.f) x = x / total_weight;
+        x = x * scale;
+        acc[i] = first ? x : acc[i] + x;
+    }
+}
+
+extern "C" int mrl_clip_accumulate(const float* grads, float* acc, long P, float max_grad_norm, float total_weight,
+                                   int first, void* scratch, void* stream) {
+    if (!grads || !acc || P <= 0 || !scratch || total_weight <= 0.f) return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (int)min((P + 1023) / 1024, (long)ADAM_MAX_PART);
+    ProfScope ps("clip+accumulate", 0.0, (max_grad_norm >= 0.f ? 16.0 : 12.0) * P, st);
+    if (max_grad_norm >= 0.f) {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grads, P, total_weight, (double*)scratch);
+        MRL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(clip_accumulate_kernel, dim3(blocks), dim3(256), 0, st, grads, acc, P, max_grad_norm, total_weight,
+                       first, (const double*)scratch, blocks);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t mrl_adam_scratch_bytes(long P) {
     (void)P;
     return ADAM_MAX_PART * sizeof(double);

@@ -70,6 +70,14 @@ def adam_clip_step(params, grads, m, v, alpha, beta1, beta2, eps, max_grad_norm,
                                          ptr(scratch), stream_ptr()), 'mrl_adam_clip_step')
 
 
+def clip_accumulate(grads, acc, max_grad_norm, total_weight, first, scratch):
+    """acc (+)= clip_by_global_norm(grads / total_weight): one MicrobatchedModel slice (microbatched_model.py:57-64)."""
+    _lib.require_gpu()
+    mgn = -1.0 if max_grad_norm is None else float(max_grad_norm)
+    check(_lib.load().mrl_clip_accumulate(ptr(grads), ptr(acc), grads.numel(), mgn, float(total_weight), int(bool(first)),
+                                          ptr(scratch), stream_ptr()), 'mrl_clip_accumulate')
+
+
 class DeviceModel(object):
     """Handle on an `mrl_model` layout object + the device buffers it works on."""
 
@@ -169,3 +177,12 @@ class DeviceModel(object):
                                       float(ent_coef), float(vf_coef), ptr(grads_out), ptr(stats_out),
                                       ptr(self.workspace), self.workspace.numel(), self.chunk, stream_ptr()),
               'mrl_model_grad')
+
+    def grad_micro(self, params, obs, actions, returns, values, neglogpacs, idx, B, mb0, mbn, T, N, cliprange, ent_coef,
+                   vf_coef, grads_out, stats_out):
+        """one MicrobatchedModel slice: advantage statistics over all B samples, loss/gradient over [mb0, mb0+mbn)."""
+        check(self.lib.mrl_model_grad_micro(self.handle, ptr(params), ptr(obs), ptr(actions), ptr(returns), ptr(values),
+                                            ptr(neglogpacs), ptr(idx), int(B), int(mb0), int(mbn), int(T), int(N),
+                                            float(cliprange), float(ent_coef), float(vf_coef), ptr(grads_out),
+                                            ptr(stats_out), ptr(self.workspace), self.workspace.numel(), self.chunk,
+                                            stream_ptr()), 'mrl_model_grad_micro')

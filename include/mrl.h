@@ -107,6 +107,22 @@ int mrl_model_grad(const mrl_model* m, const float* params, const void* obs, con
                    float vf_coef, float* grads_out, float* stats_out, void* workspace,
                    size_t workspace_bytes, int chunk, void* stream);
 
+/* ---- MicrobatchedModel step --- ppo2/microbatched_model.py:36-60 ----------
+ * As mrl_model_grad, but the advantage statistics span all B samples of the minibatch while the
+ * loss / gradient / stats cover only samples [mb0, mb0+mbn) (means over mbn, like the reference's
+ * microbatch-sized graph). */
+int mrl_model_grad_micro(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                         const float* returns, const float* values, const float* neglogpacs,
+                         const int64_t* idx, int B, int mb0, int mbn, int T, int N, float cliprange,
+                         float ent_coef, float vf_coef, float* grads_out, float* stats_out,
+                         void* workspace, size_t workspace_bytes, int chunk, void* stream);
+/* acc := (first ? 0 : acc) + clip_by_global_norm(grads / total_weight): the reference sums its
+ * post-clip `self.grads` per microbatch (microbatched_model.py:57-64, model.py:105-112); the
+ * average and the un-clipped Adam apply are mrl_adam_clip_step(acc, max_grad_norm < 0,
+ * total_weight = nmicrobatches).  scratch: >= mrl_adam_scratch_bytes(P). */
+int mrl_clip_accumulate(const float* grads, float* acc, long P, float max_grad_norm, float total_weight,
+                        int first, void* scratch, void* stream);
+
 /* ---- K8+K9: [rank average] -> clip_by_global_norm -> Adam --- ppo2/model.py:97-114,
  * common/mpi_adam_optimizer.py:39-40.  grads := grads / total_weight (if != 1) BEFORE the norm,
  * scale = c*min(1/gn, 1/c) (max_grad_norm < 0: no clipping), TF-1 ApplyAdam update with

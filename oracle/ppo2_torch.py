@@ -215,17 +215,21 @@ class OracleModel(object):
         loss = pg_loss - entropy * self.ent_coef + vf_loss * self.vf_coef
         return loss, [pg_loss, vf_loss, entropy, approxkl, clipfrac]
 
-    def compute_grads(self, cliprange, obs, returns, actions, values, neglogpacs):
-        """model.py:136-139 + graph gradients.  Returns (stats, flat unclipped grad ndarray)."""
+    def _normalised_advs(self, returns, values):
         returns = np.asarray(returns)
         values = np.asarray(values)
         if self.dtype == torch.float64:
-            returns64, values64 = returns.astype(np.float64), values.astype(np.float64)
-            advs = returns64 - values64
-            advs = (advs - advs.mean()) / (advs.std() + 1e-8)
-        else:
-            advs = returns - values
-            advs = (advs - advs.mean()) / (advs.std() + 1e-8)
+            returns, values = returns.astype(np.float64), values.astype(np.float64)
+        advs = returns - values
+        return (advs - advs.mean()) / (advs.std() + 1e-8)
+
+    def compute_grads(self, cliprange, obs, returns, actions, values, neglogpacs, advs=None):
+        """model.py:136-139 + graph gradients.  Returns (stats, flat unclipped grad ndarray).
+        `advs` given: already normalised (the MicrobatchedModel slices, microbatched_model.py:40-56)."""
+        returns = np.asarray(returns)
+        values = np.asarray(values)
+        if advs is None:
+            advs = self._normalised_advs(returns, values)
         for t in self.p.values():
             t.grad = None
         loss, stats = self.loss_and_stats(obs, returns, actions, values, neglogpacs, cliprange, advs)
@@ -237,8 +241,8 @@ class OracleModel(object):
         flat = torch.cat([g.reshape(-1) for g in grads])
         return [float(s.detach()) for s in stats], flat
 
-    def apply_flat_grad(self, lr, flat):
-        """[MPI average] -> clip_by_global_norm -> TF-1 Adam.  flat: torch 1-D."""
+    def average_and_clip(self, flat):
+        """`self.grads` of model.py:105-112: [MPI average] -> clip_by_global_norm.  flat: torch 1-D."""
         if self.allreduce is not None:
             # mpi_adam_optimizer.py:21,39-40
             flat = self.allreduce(flat * self.rank_weight) / self.total_weight
@@ -249,6 +253,12 @@ class OracleModel(object):
             scale = c * torch.minimum(1.0 / gn, 1.0 / c)
             flat = flat * scale
             self.last_gnorm = float(gn)
+        return flat
+
+    def apply_flat_grad(self, lr, flat, clipped=False):
+        """[MPI average] -> clip_by_global_norm -> TF-1 Adam.  flat: torch 1-D."""
+        if not clipped:
+            flat = self.average_and_clip(flat)
         self.last_grads = flat.clone()
         lr = self.npdt(lr)
         one = self.npdt(1)
@@ -269,6 +279,26 @@ class OracleModel(object):
         stats, flat = self.compute_grads(cliprange, obs, returns, actions, values, neglogpacs)
         self.apply_flat_grad(lr, flat)
         return stats
+
+    def train_micro(self, microbatch_size, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
+        """MicrobatchedModel.train (microbatched_model.py:36-75): advantages normalised over the whole minibatch,
+        per-slice post-clip gradients summed, divided by the number of microbatches, applied without a second
+        clip; stats = np.mean over the microbatches."""
+        assert states is None
+        n = len(np.asarray(returns))
+        assert n % microbatch_size == 0
+        nmicro = n // microbatch_size
+        advs = self._normalised_advs(returns, values)
+        total, stats_all = None, []
+        for k in range(nmicro):
+            sl = slice(k * microbatch_size, (k + 1) * microbatch_size)
+            stats, flat = self.compute_grads(cliprange, np.asarray(obs)[sl], np.asarray(returns)[sl], np.asarray(actions)[sl],
+                                             np.asarray(values)[sl], np.asarray(neglogpacs)[sl], advs=advs[sl])
+            flat = self.average_and_clip(flat)
+            total = flat if total is None else total + flat
+            stats_all.append(stats)
+        self.apply_flat_grad(lr, total / nmicro, clipped=True)
+        return np.mean(np.array(stats_all, dtype=np.float32), axis=0).tolist()
 
     # ---- helpers --------------------------------------------------------------
     def flat_params(self):

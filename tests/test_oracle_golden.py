@@ -165,3 +165,30 @@ def test_vecnormalize_oracle_matches_reference(golden_dir, tag):
     np.testing.assert_array_equal(vn.ob_rms.var, g[tag + '_ob_var'])
     assert vn.ob_rms.count == float(g[tag + '_ob_count']) and vn.ret_rms.var == float(g[tag + '_ret_var'])
     np.testing.assert_array_equal(vn.ret, g[tag + '_ret'])
+
+
+def test_oracle_microbatched_restatement_consistency():
+    """microbatched_model.py:36-75 restated in OracleModel.train_micro: one microbatch == plain train when the clip is
+    inactive twice-over is impossible (the slice gradient is clipped BEFORE the apply), so check the two facts the
+    reference's own test relies on (test_microbatches.py:11-32): a single full-size microbatch reproduces train()
+    exactly, and small microbatches stay within its 3e-3 of it."""
+    from oracle.ppo2_torch import OracleModel
+    rng = np.random.RandomState(0)
+    B = 32
+    obs = rng.randn(B, 4).astype(np.float32)
+    ret, val, nlp = (rng.randn(B).astype(np.float32) for _ in range(3))
+    nlp = np.abs(nlp)
+    act = rng.randint(0, 2, B)
+
+    def mk():
+        np.random.seed(3)
+        return OracleModel(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind='categorical', nact=2,
+                           ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+    a, b, c = mk(), mk(), mk()
+    sa = a.train(1e-3, 0.2, obs, ret, None, act, val, nlp)
+    sb = b.train_micro(B, 1e-3, 0.2, obs, ret, None, act, val, nlp)
+    np.testing.assert_allclose(sa, sb, rtol=1e-6)
+    np.testing.assert_array_equal(a.flat_params(), b.flat_params())
+    c.train_micro(2, 1e-3, 0.2, obs, ret, None, act, val, nlp)
+    assert not np.array_equal(a.flat_params(), c.flat_params())
+    np.testing.assert_allclose(a.flat_params(), c.flat_params(), atol=3e-3)
