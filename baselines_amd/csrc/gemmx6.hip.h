@@ -1,0 +1,232 @@
+// Tiled "bf16 x 6" GEMM for gfx950 (MI355X): fp32-class products on the BF16 matrix pipe, fifth GEMM engine of libmrl.
+// Used for the fully connected layer of NatureCNN (common/models.py:24-26 `fc(h, 'fc1', nh=512)` via a2c/utils.py:58-63),
+// forward and data-gradient:   C[M][N] = A[M][K] * B[N][K]^T   with A fp32 row-major (K contiguous).
+//
+// Both operands are split EXACTLY into three bf16 planes, x = x0 + x1 + x2 (8 + 8 + 8 significant bits, truncation
+// split, every residual exact), and the six products down to 2^-16 relative are accumulated in fp32:
+//   x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0);   dropped: x1w2, x2w1, x2w2 <= 2^-23 of the product,
+// i.e. below the rounding of one fp32 multiply.  6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace
+// 8 v_mfma_f32_32x32x2_f32 (64 cycles): 2.7x less matrix time.  Not the bitwise fmaf chain of the fp32 MFMA engines
+// (gemm.hip.h stays the reference path, MRL_F32_BF16X6=0 selects it); parity tests hold unchanged.
+//
+//   * B (the weight matrix, 1.6 M elements) is split and laid out [plane][n][k] ONCE per call by split_planes_kernel
+//     -- its staging is then a plain 16-byte copy;
+//   * A (activations / incoming gradients) is split while it is staged: a tile element is split once and used by the
+//     4 column blocks of the 128-wide tile, so the VALU work is ~1/4 of a per-fragment split;
+//   * 128 x 128 x 32 tiles, 4 waves x (64 x 64), LDS rows padded to 40 bf16 (conflict-free ds_read_b128 fragments),
+//     60 KB LDS and ~180 VGPRs per workgroup: two workgroups per CU cover each other's barriers;
+//   * XCD-aware tile order and three-phase epilogues as in gemm.hip.h (same epilogue functors).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+#include "wres.hip.h"      // bf16x8, U32x4, split2_bf16x3
+
+namespace mrl {
+
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+constexpr int X6_BM = 128, X6_BN = 128, X6_BK = 32, X6_LDK = 40;
+
+// out[plane][n][k] (bf16 bits) from src[R][Cn] fp32:  transpose ? (n, k) = (col, row) : (n, k) = (row, col)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int Cn, int transpose,
+                                                           uint16_t* __restrict__ out) {
+    const long total = (long)R * Cn;
+    const long Nn = transpose ? Cn : R, Kd = transpose ? R : Cn;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+        const long r = e / Cn, c = e - r * Cn;
+        const long n = transpose ? c : r, k = transpose ? r : c;
+        const float v = src[e];
+        const uint32_t u = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u & 0xffff0000u);
+        const uint32_t u1 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        out[(0 * Nn + n) * Kd + k] = (uint16_t)(u >> 16);
+        out[(1 * Nn + n) * Kd + k] = (uint16_t)(u1 >> 16);
+        out[(2 * Nn + n) * Kd + k] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+}
+
+// A-row descriptions: element (m, k) of the A operand lives at p[row_base(m) + koff(k)], k in chunks of X6_BK
+struct X6DenseA {            // A[M][lda] row-major
+    const float* p; long lda;
+    __device__ __forceinline__ long row_base(int m) const { return (long)m * lda; }
+    __device__ __forceinline__ long koff(int k0) const { return k0; }
+};
+struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k = (ky, kx, c); X6_BK divides rf*C
+    __device__ __forceinline__ long row_base(int m) const {
+        const int ohw = OH * OW;
+        int b = (int)d_ohw.div((uint32_t)m), r = m - b * ohw;
+        int oy = (int)d_ow.div((uint32_t)r), ox = r - oy * OW;
+        long img = srow ? (long)srow[b] : (long)b;
+        return ((img * H + oy * stride) * W + ox * stride) * C;
+    }
+    __device__ __forceinline__ long koff(int k0) const {
+        const int ky = (int)d_rowk.div((uint32_t)k0);
+        return (long)ky * W * C + (k0 - ky * rowk);
+    }
+};
+
+// 128 x (TN*64) x 32 tiles, 4 waves as 2 x 2, each wave 64 x (TN*32)
+template <class AF, class EF, int TN>
+__global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
+                                                      int mtiles, int ntiles) {
+    constexpr int BN = TN * 64;
+    constexpr int NQ = BN / 64;                            // 16-byte B chunks per thread and plane
+    extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
+    uint16_t* As = x6s;                                   // [3][128][LDK]
+    uint16_t* Bs = x6s + 3 * 128 * X6_LDK;                // [3][BN][LDK]
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt_i = slot % ntiles;
+    const long panel = (long)(slot / ntiles) * 8 + xcd;
+    if (panel >= (long)mtiles) return;
+    const int mt_i = (int)panel;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt_i * X6_BM, n0 = nt_i * BN;
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // staging addresses: A rows p*32 + tid/8, 4 floats at k = (tid&7)*4;  B rows (q*256 + tid)/4, 8 bf16 at ((..)&3)*8
+    const float* ap[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        ap[p] = static_cast<const float*>(af.p) + af.row_base(min(m0 + p * 32 + (tid >> 3), M - 1)) + (tid & 7) * 4;
+    const uint16_t* bp[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = q * 256 + tid;
+        bp[q] = Bp + (long)min(n0 + (c >> 2), N - 1) * K + (c & 3) * 8;
+    }
+    const long bplane = (long)N * K;
+    // ONE register stage: a second one (loads issued two tiles ahead) needs 40 more VGPRs, which pushes the kernel
+    // past 256 registers at 2 waves per SIMD -- measured 18 % slower with the spills than the exposed latency costs
+    float4 ra0[4];
+    u32x4v rb0[3 * NQ];         // clang vector type: HIP's uint4 struct in an array is left in scratch memory by SROA
+    auto fetch = [&](float4 (&ra)[4], u32x4v (&rb)[3 * NQ], int k0) {
+        const long ko = af.koff(k0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + k0);
+    };
+    auto swrite = [&](const float4 (&ra)[4], const u32x4v (&rb)[3 * NQ]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+            split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
+            split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
+            uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+            *reinterpret_cast<uint2*>(d + 128 * X6_LDK) = make_uint2(a1x, a1y);
+            *reinterpret_cast<uint2*>(d + 2 * 128 * X6_LDK) = make_uint2(a2x, a2y);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = q * 256 + tid;
+                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
+            }
+    };
+    auto mfma_block = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < X6_BK / 16; ++kb) {
+            bf16x8 fa[2][3], fb[TN][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * 128 + (wm * 2 + a) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[b][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * TN + b) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {      // small terms first
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+
+    const int ntile = K / X6_BK;
+    fetch(ra0, rb0, 0);
+    for (int t = 0; t < ntile; ++t) {
+        __syncthreads();                       // previous tile's fragment reads are done
+        swrite(ra0, rb0);
+        __syncthreads();
+        if (t + 1 < ntile) fetch(ra0, rb0, (t + 1) * X6_BK);   // next tile in flight during the MFMA block
+        // fences: without them the compiler hoists the split arithmetic of swrite() up to the loads and waits for
+        // them BEFORE the MFMA block (the full memory latency exposed once per tile)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + (wn * TN + b) * 32 + i;
+            const int colc = min(col, N - 1);
+            long o[16];
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[r] = (row < M && col < N) ? ef.addr(row, col, 0) : -1;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = ef.aux(o[r] < 0 ? 0 : o[r], colc);     // all loads first, unconditional
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (o[r] >= 0) ef.put(o[r], acc[a][b][r], x[r]);
+        }
+}
+
+inline bool gemm_x6_ok(const void* A, long lda, int K) {
+    return K % X6_BK == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;
+}
+inline size_t gemm_x6_plane_bytes(long N, long K) { return (size_t)3 * N * K * sizeof(uint16_t); }
+
+inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool transpose, uint16_t* out, hipStream_t stream) {
+    const long total = (long)R * Cn;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out);
+    return hipGetLastError();
+}
+
+template <class AF, class EF>
+inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const bool narrow = N <= 64;                                       // 128 x 64 tiles for the 64-filter conv layers
+    const int bn = narrow ? 64 : 128;
+    const int mtiles = (M + X6_BM - 1) / X6_BM, ntiles = (N + bn - 1) / bn;
+    const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)3 * (128 + bn) * X6_LDK * sizeof(uint16_t);
+    if (narrow)
+        hipLaunchKernelGGL((gemm_x6_kernel<AF, EF, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles);
+    else
+        hipLaunchKernelGGL((gemm_x6_kernel<AF, EF, 2>), dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles);
+    return hipGetLastError();
+}
+
+}  // namespace mrl

@@ -44,23 +44,36 @@ struct LdsDgradCfg {
     static constexpr int NDV = (DZV + NT - 1) / NT;
     static_assert(C % 32 == 0 && NF % 8 == 0 && KD % 64 == 0, "tile shapes");
     static_assert(ROWS <= TILES * 32, "an image group must fit the workgroup's 16 row tiles");
+    static_assert(27 / WX + 1 < 2 * HY, "epilogue carry arithmetic: a 32-row tile spans at most 3 images");
     static_assert(LDS_BYTES <= 160 * 1024, "filter slice + image group must fit the CU's LDS");
 };
 
 template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW, int DBG>
 __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ hcur,
                                                                 const float* __restrict__ w, const float* __restrict__ hprev,
-                                                                float* __restrict__ out, int act, int B) {
+                                                                float* __restrict__ out, int act, int B, int stagger, long long* dbg) {
     using K = LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wt = smem;                                   // [32][KP]   wt[c][tap*NF + n]
     float* dzs = smem + K::W_FLOATS;                    // [G*NPIX + 1][NFP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int role = blockIdx.x % K::ROLES, z = role / K::NSPL, cs = role % K::NSPL;
+    // All ROLES workgroups that work on the same image groups (same wg) read the same dz bytes at the same time.
+    // Consecutive block ids land on consecutive XCDs (8 of them, private L2 each), so the block id is decoded as
+    // (xcd, role, slot): the ROLES readers of a group share one XCD's L2 and dz leaves HBM once, not ROLES times.
+    const int nwg = gridDim.x / K::ROLES;                                 // host launches a multiple of 8*ROLES
+    const int xcd = blockIdx.x % 8, rest = blockIdx.x / 8;
+    const int role = rest % K::ROLES, wg = (rest / K::ROLES) * 8 + xcd;
+    const int z = role / K::NSPL, cs = role % K::NSPL;
     const int py = z / STRIDE, px = z % STRIDE;
-    const int wg = blockIdx.x / K::ROLES, nwg = gridDim.x / K::ROLES;     // host launches a multiple of ROLES
     const int ngroups = (B + G - 1) / G;
+    // De-phasing: every workgroup runs the same stage -> MFMA -> store cycle; started together they hit HBM in
+    // bursts (all stores at once, then silence).  A one-time start delay spreads the phases of the workgroups
+    // over one cycle so the memory phases of some overlap the MFMA phases of the others.
+    if (stagger > 0) {
+        const long long wait = (long long)(wg % 16) * stagger / 16, t0 = clock64();
+        while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     // DBG (timing experiments only): 1 = skip the epilogue, 2 = skip the per-group staging, 3 = both
     // ---- filter slice -> LDS (once): wt[c][ (a*TAPS + b2)*NF + n ] = W[py + s*a][px + s*b2][cs*32 + c][n]
     for (int e = tid; e < 32 * K::KD; e += K::NT) {
@@ -112,10 +125,20 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
         }
     };
 
-    for (int grp = wg; grp < ngroups; grp += nwg) {
+    // dbg != nullptr (timing experiments): wave `dbgw` of workgroup 0 stamps the phase boundaries of its first 6 groups
+    int it = 0;
+    auto stamp = [&](int k) {
+        if (dbg && wg == 0 && role == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1) && it < 6)
+            dbg[((wave ? 1 : 0) * 6 + it) * 8 + k] = (long long)__builtin_readcyclecounter();
+    };
+    for (int grp = wg; grp < ngroups; grp += nwg, ++it) {
+        stamp(0);
         __syncthreads();                                 // everyone is done reading the previous group
+        stamp(1);
         if (!(DBG & 2) || grp == wg) stage_group(grp);
+        stamp(2);
         __syncthreads();
+        stamp(3);
         const int b0 = grp * G;
 
         // ---- this wave's two row tiles; lane row -> (image g, yy, xx) of class z
@@ -176,6 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        stamp(4);
         // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*h
         // all act'-mask loads of both tiles are issued before the first store (a load -> wait -> store
         // chain per element costs 32 serial memory round trips per group)
@@ -189,18 +213,38 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
             continue;
         }
         float hv[K::TMW][16];
-        // the row -> (image, iy, ix) part of these offsets is invariant across groups; left alone the compiler
-        // hoists all 32 of them out of the group loop (64+ VGPRs live across the MFMA stream -> spills that
-        // serialise the prefetch).  Laundering the lane constants keeps the arithmetic in the epilogue.
+        // Destination offsets.  The row -> (image, iy, ix) map is invariant across groups: left alone the compiler
+        // hoists all 32 offsets out of the group loop (64+ VGPRs live across the MFMA stream -> spills that
+        // serialise the prefetch), so the lane constants are laundered and the math stays here -- but it has to
+        // be cheap, 4 waves of a SIMD run it back to back while the matrix pipe idles: 32-bit element offsets
+        // relative to the group's first image (a group is < 2^31 elements), one div/mod chain per tile and
+        // carry arithmetic for its 16 rows (row r of the C/D layout is base + (r&3) + 8*(r>>2)).
         int hq = h, wq = wave;
         asm volatile("" : "+v"(hq), "+v"(wq));
-        auto off = [&](int t, int r) -> long {
-            const int m = (wq * K::TMW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;
-            const int g = m / K::PER, rr = m % K::PER;
-            const int iy = (rr / K::WX) * STRIDE + py, ix = (rr % K::WX) * STRIDE + px;
-            const bool ok = m < K::ROWS && b0 + g < B && iy < H && ix < W;
-            return ok ? ((long)((b0 + g) * H + iy) * W + ix) * C + cs * 32 + i : -1;
-        };
+        const long gbase = (long)b0 * (H * W * C) + cs * 32 + i;
+        const int gleft = B - b0;                                      // images of this group that exist
+        int goff[K::TMW][16];
+#pragma unroll
+        for (int t = 0; t < K::TMW; ++t) {
+            const int m0 = (wq * K::TMW + t) * 32 + 4 * hq;
+            const int g0 = m0 / K::PER, r0 = m0 % K::PER;
+            const int yy0 = r0 / K::WX, xx0 = r0 % K::WX;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2);                  // <= 27
+                int xx1 = xx0 + d, yy1 = yy0, g1 = g0;
+                // d / WX and d % WX are compile-time constants; at most one extra carry from the remainders
+                yy1 += d / K::WX;
+                xx1 = xx0 + d % K::WX;
+                if (xx1 >= K::WX) { xx1 -= K::WX; ++yy1; }
+                if (yy1 >= 2 * K::HY) { yy1 -= 2 * K::HY; g1 += 2; }
+                if (yy1 >= K::HY) { yy1 -= K::HY; ++g1; }
+                const int iy = yy1 * STRIDE + py, ix = xx1 * STRIDE + px;
+                const bool ok = g1 < G && g1 < gleft && iy < H && ix < W;
+                goff[t][r] = ok ? ((g1 * H + iy) * W + ix) * C : -1;
+            }
+        }
+        auto off = [&](int t, int r) -> long { return goff[t][r] < 0 ? -1 : gbase + goff[t][r]; };
         if (hprev) {
 #pragma unroll
             for (int t = 0; t < K::TMW; ++t)
@@ -209,6 +253,7 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
                     const long o = off(t, r);
                     hv[t][r] = hprev[o < 0 ? 0 : o];
                 }
+            stamp(5);
 #pragma unroll
             for (int t = 0; t < K::TMW; ++t)
 #pragma unroll
@@ -216,6 +261,7 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
                     const long o = off(t, r);
                     if (o >= 0) out[o] = acc[t][r] * act_bwd_from_out(hv[t][r], act);
                 }
+            stamp(6);
         } else {                                   // mask deferred to the consumers: fire-and-forget stores
 #pragma unroll
             for (int t = 0; t < K::TMW; ++t)
@@ -230,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
 
 template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW, int DBG>
 inline hipError_t launch_lds_dgrad(const float* dz, const float* hcur, const float* w, const float* hprev, float* out,
-                                   int act, int B, int num_cus, hipStream_t stream) {
+                                   int act, int B, int num_cus, int stagger, long long* dbg, hipStream_t stream) {
     using K = LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
     auto kern = lds_dgrad_kernel<H, W, C, RF, STRIDE, NF, G, WAVES, TMW, DBG>;
     static bool raised = false;
@@ -240,8 +286,8 @@ inline hipError_t launch_lds_dgrad(const float* dz, const float* hcur, const flo
         raised = true;
     }
     const int ngroups = (B + G - 1) / G;
-    int per_role = std::max(1, std::min(num_cus / K::ROLES, ngroups));
-    hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, hcur, w, hprev, out, act, B);
+    int per_role = std::max(8, std::min(num_cus / K::ROLES, (ngroups + 7) / 8 * 8) / 8 * 8);   // multiple of 8 (XCD decode)
+    hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, hcur, w, hprev, out, act, B, stagger, dbg);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@
 #include "wres.hip.h"
 #include "imgres.hip.h"
 #include "ldsdgrad.hip.h"
+#include "gemmx6.hip.h"
 #include "mlpstep.hip.h"
 
 using namespace mrl;
@@ -184,6 +185,7 @@ extern "C" int mrl_model_tensor_info(const mrl_model* m, int i, char* name, int 
 // ---- workspace carving ------------------------------------------------------------------
 struct NetWs {
     std::vector<float*> h, dz;
+    uint16_t* planes;    // bf16 x 3 image of one fc weight matrix (gemmx6.hip.h), shared by both nets
 };
 struct Ws {
     NetWs pi, vf;
@@ -227,7 +229,7 @@ static int get_option(const char* name, const char* env, int dflt) {
 }
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
-    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg"};
+    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg", "dgrad_stagger", "dgrad_dbg", "dgrad_cfg", "f32_bf16x6", "x6_cfg"};
     for (const char* k : known)
         if (!strcmp(k, name)) { option_table()[name] = value; return 0; }
     return MRL_EINVAL;
@@ -291,6 +293,12 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     };
     do_net(m->pi, ws.pi);
     if (m->vf_copy) do_net(m->vf, ws.vf);
+    {   // scratch for the split weight planes of the largest hidden layer (first layers read observations: own engines)
+        size_t pb = 0;
+        for (const Net* net : {&m->pi, &m->vf})
+            for (size_t i = 1; i < net->L.size(); ++i) pb = std::max(pb, gemm_x6_plane_bytes(net->L[i].N, net->L[i].K));
+        ws.pi.planes = ws.vf.planes = pb ? (uint16_t*)take(pb) : nullptr;
+    }
     if (m->d.network == MRL_NET_MLP)
         part_floats = std::max(part_floats, (size_t)std::min<long>(MLP_MAX_TILES, ((long)chunk + 31) / 32) * (size_t)m->P);
     ws.pdparam = (float*)take((size_t)chunk * m->d.nact * 4);
@@ -838,8 +846,9 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     return (int)e;
 }
 
+static bool tuned(const Layer& l, const char* pass);
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
-                         const float* params, float* hout, int B, hipStream_t st) {
+                         const float* params, float* hout, uint16_t* planes, int B, hipStream_t st) {
     const float* W = params + l.w_off;
     const float* bias = params + l.b_off;
     RowMC bf{W, l.N, l.N, l.K, is_vec(W, l.N), nullptr};
@@ -865,6 +874,35 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 }
                 return wres_dispatch(l.name, "fwd", var, l.NF, wa, wb, we, 1, l.K, tiles, fl, st);
             } else {
+                // fp32 activations: bf16 x 6 split engine (wres.hip.h) unless MRL_F32_BF16X6=0 asks for the fmaf chain
+                // group = PF blocks of 16 k inside one patch row; the deeper the group the more time its prefetch has
+                const int x6 = get_option("f32_bf16x6", "MRL_F32_BF16X6", 1);
+                const int rowk = l.rf * l.C;
+                const int pf = rowk % 128 == 0 ? 8 : rowk % 96 == 0 ? 6 : rowk % 64 == 0 ? 4 : 0;
+                if (x6 && planes && get_option("x6_cfg", "MRL_X6_CFG", 0) == 0 && rowk % X6_BK == 0 && l.C % 4 == 0 &&
+                    (uintptr_t)hprev % 16 == 0) {
+                    // tiled engine with the im2col row map: the split of an activation is shared by both 32-column blocks
+                    X6ConvA ca;
+                    fill_conv(ca, l, hprev, npix, nullptr);
+                    char label[40];
+                    if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
+                    ProfScope ps(label, fl, 0.0, st);
+                    hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st);
+                    if (e != hipSuccess) return (int)e;
+                    EpiBiasAct efx{hout, l.NF, bias, l.act};
+                    return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st);
+                }
+                if (x6 && pf && l.C % 4 == 0 && wres_f32x6_lds_bytes(l.K) <= 160 * 1024) {
+                    WresFwdA8 wa8;
+                    fill_conv(wa8, l, hprev, npix, nullptr);
+                    char label[40];
+                    if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
+                    ProfScope ps(label, fl, 0.0, st);
+                    if (get_option("x6_cfg", "MRL_X6_CFG", 0) == 1) return (int)launch_wres_f32x6<WresEpiBiasAct, 4, 12>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
+                    if (pf == 8) return (int)launch_wres_f32x6<WresEpiBiasAct, 8, 8>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
+                    if (pf == 6) return (int)launch_wres_f32x6<WresEpiBiasAct, 6, 8>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
+                    return (int)launch_wres_f32x6<WresEpiBiasAct, 4, 8>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
+                }
                 WresFwdA<false> wa;
                 fill_conv(wa, l, hprev, npix, nullptr);
                 return wres_dispatch(l.name, "fwd", var, l.NF, wa, wb, we, 1, l.K, tiles, fl, st);
@@ -888,6 +926,16 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
             RowKC af{(const float*)in.obs, l.K, B, l.K, is_vec(in.obs, l.K), in.srow};
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
         } else {
+            // hidden fc layer: bf16 x 6 tiled engine (gemmx6.hip.h) on large batches unless MRL_F32_BF16X6=0
+            if (planes && B >= 1024 && l.N >= 128 && gemm_x6_ok(hprev, l.K, l.K) && !tuned(l, "fwd") &&
+                get_option("f32_bf16x6", "MRL_F32_BF16X6", 1)) {
+                char label[40];
+                if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
+                ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
+                hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st);        // B[n][k] = W[k][n]
+                if (e != hipSuccess) return (int)e;
+                return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st);
+            }
             RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K), nullptr};
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
         }
@@ -897,7 +945,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
 static int net_forward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, int B,
                        hipStream_t st) {
     for (size_t i = 0; i < net.L.size(); ++i) {
-        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], B, st);
+        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, B, st);
         if (rc) return rc;
     }
     return 0;
@@ -1009,10 +1057,17 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     ProfScope ps(label, fl, 0.0, st);
                     hipError_t e;
                     const float* wsrc = params + l.w_off;
+                    const int stg = get_option("dgrad_stagger", "MRL_DGRAD_STAGGER", 0);   // start-phase spread (cycles)
+                    // MRL_DGRAD_DBG=<layer index>: phase timestamps of workgroup 0 land behind the zero page
+                    long long* dbgp = get_option("dgrad_dbg", "MRL_DGRAD_DBG", 0) == i ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
                     // 16 waves x 1 row tile, groups of 5 / 6 images (measured alternatives in profiles/README.md:
                     // 8 waves x 2 tiles and two half-size workgroups per CU are slower)
-                    if (lk == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st);
-                    else e = launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), st);
+                    const int cfg = get_option("dgrad_cfg", "MRL_DGRAD_CFG", 0);
+                    if (lk == 1 && cfg == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 2, 8, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, 2 * num_cus(), stg, dbgp, st);
+                    else if (lk == 1 && cfg == 2) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 8, 2, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
+                    else
+                    if (lk == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
+                    else e = launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
                     rc = (int)e;
                 } else
                 if (dv >= V_WRES16 && wok) {
@@ -1030,6 +1085,16 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hmask; ef.act = lp.act;
                     rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, Md, l.C, Kd, l.stride * l.stride, Kd, st, fl);
                 }
+            } else if (nw.planes && B >= 1024 && l.K >= 128 && gemm_x6_ok(dz, l.N, l.N) && !tuned(l, "dgrad") &&
+                       get_option("f32_bf16x6", "MRL_F32_BF16X6", 1)) {
+                // dX[b][k] = sum_n dz[b][n] W[k][n]: W's rows are already the k-contiguous B operand
+                char label[40];
+                if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
+                ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
+                EpiMaskAct ef{nw.dz[i - 1], l.K, hmask, lp.act};
+                hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st);
+                if (e == hipSuccess) e = launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st);
+                rc = (int)e;
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
                 const float* W = params + l.w_off;
