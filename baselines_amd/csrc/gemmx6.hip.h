@@ -67,15 +67,20 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
     }
 };
 
-// 128 x (TN*64) x 32 tiles, 4 waves as 2 x 2, each wave 64 x (TN*32)
-template <class AF, class EF, int TN>
+// (WM*64) x (WN*64) x 32 tiles, WM x WN = 4 waves, each wave 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers);
+// 128 x 128 (2 x 2 waves) or 256 x 64 (4 x 1, for the 64-filter conv layers).  Single LDS buffer (60 / 77 KB), two
+// workgroups per CU, one register stage.  Measured alternatives (profiles/README.md): a second register stage spills
+// at 2 waves per SIMD (-18 %); ONE workgroup per CU with double-buffered LDS, two register stages and the staging
+// code scheduled between the MFMAs (sched_group_barrier) is 25-45 % slower -- a lone wave per SIMD stalls the matrix
+// pipe at every LDS wait.
+template <class AF, class EF, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
                                                       int mtiles, int ntiles) {
-    constexpr int BN = TN * 64;
-    constexpr int NQ = BN / 64;                            // 16-byte B chunks per thread and plane
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int NA = BM / 32;                            // float4 of A per thread and tile
+    constexpr int NQ = BN / 64;                            // 16-byte chunks of B per thread, plane and tile
     extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
-    uint16_t* As = x6s;                                   // [3][128][LDK]
-    uint16_t* Bs = x6s + 3 * 128 * X6_LDK;                // [3][BN][LDK]
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nt_i = slot % ntiles;
     const long panel = (long)(slot / ntiles) * 8 + xcd;
@@ -83,21 +88,21 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     const int mt_i = (int)panel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = mt_i * X6_BM, n0 = nt_i * BN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
 
-    f32x16 acc[2][TN];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // staging addresses: A rows p*32 + tid/8, 4 floats at k = (tid&7)*4;  B rows (q*256 + tid)/4, 8 bf16 at ((..)&3)*8
-    const float* ap[4];
+    const float* ap[NA];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < NA; ++p)
         ap[p] = static_cast<const float*>(af.p) + af.row_base(min(m0 + p * 32 + (tid >> 3), M - 1)) + (tid & 7) * 4;
     const uint16_t* bp[NQ];
 #pragma unroll
@@ -106,29 +111,30 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         bp[q] = Bp + (long)min(n0 + (c >> 2), N - 1) * K + (c & 3) * 8;
     }
     const long bplane = (long)N * K;
-    // ONE register stage: a second one (loads issued two tiles ahead) needs 40 more VGPRs, which pushes the kernel
-    // past 256 registers at 2 waves per SIMD -- measured 18 % slower with the spills than the exposed latency costs
-    float4 ra0[4];
-    u32x4v rb0[3 * NQ];         // clang vector type: HIP's uint4 struct in an array is left in scratch memory by SROA
-    auto fetch = [&](float4 (&ra)[4], u32x4v (&rb)[3 * NQ], int k0) {
+    const int ntile = K / X6_BK;
+    float4 ra0[NA];
+    u32x4v rb0[3 * NQ];                // clang vector type: HIP's uint4 struct in an array is left in scratch memory by SROA
+    auto fetch = [&](float4 (&ra)[NA], u32x4v (&rb)[3 * NQ], int t) {
+        const int k0 = min(t, ntile - 1) * X6_BK;          // past the end: re-read the last tile (never consumed)
         const long ko = af.koff(k0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+        for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + k0);
     };
-    auto swrite = [&](const float4 (&ra)[4], const u32x4v (&rb)[3 * NQ]) {
+    auto swrite = [&](const float4 (&ra)[NA], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
+        uint16_t* Bs = As + 3 * BM * X6_LDK;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NA; ++p) {
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
             split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
             split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
             uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
-            *reinterpret_cast<uint2*>(d + 128 * X6_LDK) = make_uint2(a1x, a1y);
-            *reinterpret_cast<uint2*>(d + 2 * 128 * X6_LDK) = make_uint2(a2x, a2y);
+            *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
+            *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
         }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
@@ -138,24 +144,25 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
             }
     };
-    auto mfma_block = [&]() {
+    auto mfma_block = [&](const uint16_t* As) {
+        const uint16_t* Bs = As + 3 * BM * X6_LDK;
 #pragma unroll
         for (int kb = 0; kb < X6_BK / 16; ++kb) {
-            bf16x8 fa[2][3], fb[TN][3];
+            bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * 128 + (wm * 2 + a) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + (wm * 2 + a) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    fb[b][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * TN + b) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+                    fb[b][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * 2 + b) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {      // small terms first
+                for (int b = 0; b < 2; ++b) {       // small terms first
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
@@ -165,26 +172,25 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 }
         }
     };
-
-    const int ntile = K / X6_BK;
+    uint16_t* L0 = x6s;
     fetch(ra0, rb0, 0);
     for (int t = 0; t < ntile; ++t) {
         __syncthreads();                       // previous tile's fragment reads are done
-        swrite(ra0, rb0);
+        swrite(ra0, rb0, L0);
         __syncthreads();
-        if (t + 1 < ntile) fetch(ra0, rb0, (t + 1) * X6_BK);   // next tile in flight during the MFMA block
+        fetch(ra0, rb0, t + 1);                // next tile in flight during the MFMA block (past the end: re-reads the last)
         // fences: without them the compiler hoists the split arithmetic of swrite() up to the loads and waits for
         // them BEFORE the MFMA block (the full memory latency exposed once per tile)
         __builtin_amdgcn_sched_barrier(0);
-        mfma_block();
+        mfma_block(L0);
         __builtin_amdgcn_sched_barrier(0);
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = n0 + (wn * TN + b) * 32 + i;
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + (wn * 2 + b) * 32 + i;
             const int colc = min(col, N - 1);
             long o[16];
             float x[16];
@@ -213,20 +219,29 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
     return hipGetLastError();
 }
 
+template <class AF, class EF, int WM, int WN>
+inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
+    const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
+    auto kern = gemm_x6_kernel<AF, EF, WM, WN>;
+    static bool raised = false;                // per instantiation
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles);
+    return hipGetLastError();
+}
 template <class AF, class EF>
 inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    const bool narrow = N <= 64;                                       // 128 x 64 tiles for the 64-filter conv layers
-    const int bn = narrow ? 64 : 128;
-    const int mtiles = (M + X6_BM - 1) / X6_BM, ntiles = (N + bn - 1) / bn;
-    const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
-    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)3 * (128 + bn) * X6_LDK * sizeof(uint16_t);
-    if (narrow)
-        hipLaunchKernelGGL((gemm_x6_kernel<AF, EF, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles);
-    else
-        hipLaunchKernelGGL((gemm_x6_kernel<AF, EF, 2>), dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles);
-    return hipGetLastError();
+    // 256 x 64 tiles for the 64-filter conv layers, 128 x 128 otherwise
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1>(af, Bp, ef, M, N, K, stream);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2>(af, Bp, ef, M, N, K, stream);
 }
 
 }  // namespace mrl
