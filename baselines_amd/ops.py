@@ -129,7 +129,9 @@ class DeviceModel(object):
     def set_chunk(self, chunk):
         chunk = int(chunk)
         nbytes = int(self.lib.mrl_model_workspace_bytes(self.handle, chunk))
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        # zero-initialised once, as include/mrl.h asks (the carve holds a page of zeros that gathers read for
+        # out-of-map taps and that no kernel ever writes)
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.chunk = chunk
 
     def __del__(self):

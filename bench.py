@@ -25,6 +25,10 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA
+# kernels that run fp32-class products on the bf16 pipe as N exact bf16 products per multiply:
+# their ceiling in algorithmic (fp32-equivalent) flops is the bf16 peak / N
+SPLIT_PRODUCTS = {'c1.fwd': 3, 'c1.wgrad': 3, 'c2.fwd': 6, 'c3.fwd': 6, 'fc1.fwd': 6, 'fc1.dgrad': 6}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -212,8 +216,11 @@ def main():
             d = prof[dom]
             if d['flops'] > 0:
                 ach = d['flops'] / d['count'] / (d['ms'] / d['count'] * 1e-3) / 1e12
-                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                nprod = SPLIT_PRODUCTS.get(dom) if args.workload == 'atari' else None
+                peak = PEAK_BF16_MFMA_TFLOPS / nprod if nprod else PEAK_F32_MFMA_TFLOPS
+                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak,
+                        'pipe': ('bf16 MFMA, %d exact bf16 products per fp32 multiply' % nprod) if nprod else 'fp32 MFMA',
+                        'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                         'launches': d['count'], 'avg_ms': d['ms'] / d['count'],
                         'share_of_kernel_time': d['ms'] / tot_ms}
             else:
@@ -233,9 +240,12 @@ def main():
             'config': {'workload': 'ppo2 update-only (GAE + %dx%d minibatch steps) %s-shaped %s num_envs=%d nsteps=%d'
                                    % (hp['noptepochs'], hp['nminibatches'], args.workload, hp['network'], total_envs, T),
                        'envs_per_gpu': N, 'nbatch_train_per_gpu': nbatch_train, 'chunk': model.dm.chunk,
-                       'arithmetic': 'fp32 accumulate everywhere; fp32 MFMA (bitwise fmaf chain) except the first conv '
-                                     'layer (forward and weight gradient), where exact uint8 pixels meet a 3-way bf16 split of '
-                                     'the other operand on the bf16 pipe',
+                       'arithmetic': 'fp32 storage and fp32 accumulation everywhere. Weight gradients of conv2/conv3/fc1 and the conv '
+                                     'data gradients: fp32 MFMA (bitwise fmaf chain). conv1 forward + weight gradient: exact uint8 '
+                                     'pixels x 3-way exact bf16 split of the other operand on the bf16 pipe. conv2/conv3/fc1 forward '
+                                     'and fc1 data gradient: both operands split exactly into 3 bf16 planes, the 6 products >= 2^-16 '
+                                     'kept (dropped terms < 2^-23 relative): fp32-class results, parity tests unchanged; '
+                                     'MRL_F32_BF16X6=0 / MRL_U8_BF16X3=0 select the all-fp32-MFMA paths',
                        'parallelism': 'dp%d (envs sharded, 1 RCCL all-reduce/minibatch)' % world},
             'model_tflops': flops_per_sample_visit * total_envs * T * hp['noptepochs'] * args.steps / dt / 1e12,
             'full_iteration_env_steps_per_s': total_envs * T / (t_rollout + dt / args.steps),

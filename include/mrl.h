@@ -81,7 +81,8 @@ int  mrl_model_num_tensors(const mrl_model* m);
  * f64 the reference multiplies with (np.sqrt(2), 0.01, 1.0; <0: zeros). */
 int  mrl_model_tensor_info(const mrl_model* m, int i, char* name, int name_cap, int* ndim,
                            int shape[4], long* offset, double* init_scale);
-/* workspace bytes needed to process `chunk` samples at a time (forward+backward). */
+/* workspace bytes needed to process `chunk` samples at a time (forward+backward).  The caller zero-fills the
+ * workspace ONCE after allocating it (it contains a page of zeros that no kernel writes); afterwards it is scratch. */
 size_t mrl_model_workspace_bytes(const mrl_model* m, int chunk);
 
 /* ---- K6+K10: act side --- common/policies.py:77-113, distributions.py:199-201,247-248 -----

@@ -254,6 +254,8 @@ def test_adam_clip_matches_oracle_many_steps():
 def test_engine_options_agree():
     """The fast engines against their plain counterparts on the same minibatch:
        * first conv layer on the bf16 pipe (exact u8 x 3-way bf16 split) vs the fp32 MFMA path,
+       * conv2/conv3/fc1 forward and fc1 data gradient on the bf16 pipe (both operands split into 3 exact bf16 planes,
+         6 products) vs the fp32 MFMA paths (batch >= 1024 so that the tiled split engine takes the fc layer),
        * fused whole-step MLP kernel vs layer-wise launches.
     Gradients agree to fp32 round-off (the split products are exact; only the summation order and the
     folded 1/255 scale differ), well inside the 1e-5 loss-parity bar."""
@@ -284,13 +286,23 @@ def test_engine_options_agree():
 
     try:
         for net, shp, dt, pd, na, vc, B, opt in [('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False, 160, 'u8_bf16x3'),
+                                                 ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False, 1152, 'f32_bf16x6'),
                                                  ('mlp', (376,), np.float32, 'gaussian', 17, True, 200, 'mlp_fused'),
                                                  ('mlp', (4,), np.float32, 'categorical', 2, False, 96, 'mlp_fused')]:
             g1, s1 = grads(net, shp, dt, pd, na, vc, B, opt, 1)
             g0, s0 = grads(net, shp, dt, pd, na, vc, B, opt, 0)
             scale = np.abs(g0).max()
-            assert np.abs(g1 - g0).max() <= 2e-6 * scale + 1e-9, (opt, np.abs(g1 - g0).max(), scale)
+            diff = np.abs(g1 - g0)
+            if B < 1000:
+                assert diff.max() <= 2e-6 * scale + 1e-9, (opt, diff.max(), scale)
+            else:
+                # a thousand samples put a few pre-activations within round-off of the ReLU kink: the unit switches on in
+                # one engine and off in the other (measured: 1 of 590k fc1 units), which moves that sample's gradient
+                # rows by ~1e-4 of the scale.  Everything else agrees to round-off.
+                assert np.percentile(diff, 99.0) <= 2e-6 * scale + 1e-9, (opt, np.percentile(diff, 99.0), scale)
+                assert np.linalg.norm(g1 - g0) <= 1e-3 * np.linalg.norm(g0), (opt, np.linalg.norm(g1 - g0), np.linalg.norm(g0))
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
     finally:
         L.set_option('u8_bf16x3', 1)
+        L.set_option('f32_bf16x6', 1)
         L.set_option('mlp_fused', 1)
