@@ -75,7 +75,7 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 // pipe at every LDS wait.
 template <class AF, class EF, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
-                                                      int mtiles, int ntiles) {
+                                                      int mtiles, int ntiles, long long* dbg) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NA = BM / 32;                            // float4 of A per thread and tile
@@ -174,16 +174,26 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     };
     uint16_t* L0 = x6s;
     fetch(ra0, rb0, 0);
+    // dbg != nullptr (timing experiments): wave 0 of workgroup 0 stamps the phase boundaries of its tiles 8..13
+    auto stamp = [&](int t, int k) {
+        if (dbg && blockIdx.x == 0 && tid == 0 && t >= 8 && t < 14) dbg[(t - 8) * 8 + k] = (long long)__builtin_readcyclecounter();
+    };
     for (int t = 0; t < ntile; ++t) {
+        stamp(t, 0);
         __syncthreads();                       // previous tile's fragment reads are done
+        stamp(t, 1);
         swrite(ra0, rb0, L0);
+        stamp(t, 2);
         __syncthreads();
+        stamp(t, 3);
         fetch(ra0, rb0, t + 1);                // next tile in flight during the MFMA block (past the end: re-reads the last)
         // fences: without them the compiler hoists the split arithmetic of swrite() up to the loads and waits for
         // them BEFORE the MFMA block (the full memory latency exposed once per tile)
         __builtin_amdgcn_sched_barrier(0);
+        stamp(t, 4);
         mfma_block(L0);
         __builtin_amdgcn_sched_barrier(0);
+        stamp(t, 5);
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -220,7 +230,8 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
 }
 
 template <class AF, class EF, int WM, int WN>
-inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream) {
+inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
+                                     hipStream_t stream) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
@@ -233,15 +244,16 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg);
     return hipGetLastError();
 }
 template <class AF, class EF>
-inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream) {
+inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream,
+                                 long long* dbg = nullptr) {
     if (M <= 0 || N <= 0) return hipSuccess;
     // 256 x 64 tiles for the 64-filter conv layers, 128 x 128 otherwise
-    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1>(af, Bp, ef, M, N, K, stream);
-    return launch_gemm_x6_cfg<AF, EF, 2, 2>(af, Bp, ef, M, N, K, stream);
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1>(af, Bp, ef, M, N, K, dbg, stream);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2>(af, Bp, ef, M, N, K, dbg, stream);
 }
 
 }  // namespace mrl

@@ -185,7 +185,8 @@ extern "C" int mrl_model_tensor_info(const mrl_model* m, int i, char* name, int 
 // ---- workspace carving ------------------------------------------------------------------
 struct NetWs {
     std::vector<float*> h, dz;
-    uint16_t* planes;    // bf16 x 3 image of one fc weight matrix (gemmx6.hip.h), shared by both nets
+    uint16_t* planes;    // bf16 x 3 image of one weight matrix (gemmx6.hip.h), shared by both nets
+    long long* dbg;      // timing-experiment stamps (behind the zero page)
 };
 struct Ws {
     NetWs pi, vf;
@@ -229,7 +230,7 @@ static int get_option(const char* name, const char* env, int dflt) {
 }
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
-    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg", "dgrad_stagger", "dgrad_dbg", "dgrad_cfg", "f32_bf16x6", "x6_cfg"};
+    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg", "dgrad_stagger", "dgrad_dbg", "dgrad_cfg", "f32_bf16x6", "x6_cfg", "x6_dbg"};
     for (const char* k : known)
         if (!strcmp(k, name)) { option_table()[name] = value; return 0; }
     return MRL_EINVAL;
@@ -308,6 +309,7 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     ws.advstat = (float*)take(64);
     ws.srow = (int32_t*)take((size_t)chunk * 4);
     ws.zeros = (float*)take(2048);
+    ws.pi.dbg = ws.vf.dbg = base ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
     ws.total = off;
 }
 
@@ -848,7 +850,7 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
 
 static bool tuned(const Layer& l, const char* pass);
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
-                         const float* params, float* hout, uint16_t* planes, int B, hipStream_t st) {
+                         const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st) {
     const float* W = params + l.w_off;
     const float* bias = params + l.b_off;
     RowMC bf{W, l.N, l.N, l.K, is_vec(W, l.N), nullptr};
@@ -934,7 +936,9 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
                 hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st);        // B[n][k] = W[k][n]
                 if (e != hipSuccess) return (int)e;
-                return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st);
+                // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
+                long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) ? dbgbuf : nullptr;
+                return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st, dbgp);
             }
             RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K), nullptr};
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
@@ -945,7 +949,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
 static int net_forward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, int B,
                        hipStream_t st) {
     for (size_t i = 0; i < net.L.size(); ++i) {
-        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, B, st);
+        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st);
         if (rc) return rc;
     }
     return 0;

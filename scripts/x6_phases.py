@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""Phase timestamps of the tiled bf16x6 GEMM (fc1 forward, MRL_X6_DBG=1): workgroup 0, wave 0, tiles 8..13."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['MRL_X6_DBG'] = '1'
+import numpy as np  # noqa
+import torch  # noqa
+from baselines_amd import ops  # noqa
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+dm = ops.DeviceModel(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6, value_copy=False, chunk=B)
+r = np.random.RandomState(1)
+params = torch.from_numpy((r.randn(dm.P) * 0.05).astype(np.float32)).cuda()
+obs = torch.randint(0, 256, (B, 84, 84, 4), dtype=torch.uint8, device='cuda')
+noise = torch.rand((B, 6), device='cuda')
+for _ in range(2):
+    dm.act(params, obs, noise)
+torch.cuda.synchronize()
+st = dm.workspace[-2048 + 512:-2048 + 512 + 6 * 8 * 8].view(torch.int64).cpu().numpy().reshape(6, 8)
+names = ['barrier1', 'swrite', 'barrier2', 'fetch', 'mfma']
+for t in range(6):
+    d = np.diff(st[t, :6])
+    nxt = st[t + 1, 0] - st[t, 5] if t < 5 else 0
+    print('tile %d: ' % (t + 8) + '  '.join('%s=%d' % (n, x) for n, x in zip(names, d)) + '  total=%d  loop=%d' % (st[t, 5] - st[t, 0], nxt))
