@@ -7,7 +7,8 @@ reference rolls the stack axis by one ELEMENT (np.roll shift=-1), which is a fra
 single-channel Atari frames it is used with; that behaviour is kept bit for bit.
 """
 import numpy as np
-import torch
+
+from ._lazy import torch     # resolved on first use: env worker processes import this package without paying for torch
 
 from ... import _lib
 from ..spaces import Box

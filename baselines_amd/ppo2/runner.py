@@ -86,6 +86,7 @@ class Runner(AbstractEnvRunner):
         self.return_host = (not self.device_env) if return_host is None else return_host
         self.fast_step = hasattr(model, 'step_into')
         self._dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=self.device)
+        self._bridge = hasattr(env, 'obs_to_device')     # unwrapped ShmemVecEnv: observations already sit in a staging slot
         self._ob_np = ob_np
 
     # ------------------------------------------------------------------
@@ -119,8 +120,12 @@ class Runner(AbstractEnvRunner):
         rewards_host = np.zeros((T, self.nenv), np.float32)
         dones_host = np.zeros((T, self.nenv), np.bool_)
         for t in range(T):
-            obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
-            ro.obs[t].copy_(torch.from_numpy(obs_np))          # runner.py:30 snapshot, straight into HBM
+            if self._bridge:
+                # host-env bridge (ShmemVecEnv): asynchronous DMA from the page-locked staging slot the workers wrote
+                self.env.obs_to_device(ro.obs[t])
+            else:
+                obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
+                ro.obs[t].copy_(torch.from_numpy(obs_np))      # runner.py:30 snapshot, straight into HBM
             if self.fast_step:
                 self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
                 actions = ro.actions[t].cpu().numpy()
