@@ -230,7 +230,7 @@ static int get_option(const char* name, const char* env, int dflt) {
 }
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
-    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg", "dgrad_stagger", "dgrad_dbg", "dgrad_cfg", "f32_bf16x6", "x6_cfg", "x6_dbg"};
+    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg", "dgrad_stagger", "dgrad_dbg", "dgrad_cfg", "f32_bf16x6", "x6_cfg", "x6_dbg", "heads_wave"};
     for (const char* k : known)
         if (!strcmp(k, name)) { option_table()[name] = value; return 0; }
     return MRL_EINVAL;
@@ -649,6 +649,163 @@ __global__ __launch_bounds__(256) void heads_train_kernel(HeadArgs a) {
         double t = block_sum_256(st[j], sred);
         if (tid == 0) a.spart[blockIdx.x * 5 + j] = t;
     }
+}
+
+// ---- wave-per-sample variant of heads_train_kernel for the NatureCNN head shape -------------------------------------
+// (Categorical, <= 8 actions, value head on the SAME latent, nlat = 64*KPL).  The tile kernel above keeps one workgroup
+// per CU busy with scalar LDS loops (1.65 ms per 131072 samples, 0.33 TB/s); here a wave owns a sample at a time:
+// lane l holds latent elements [KPL*l, KPL*l + KPL) -- a row is one coalesced 2 KB read -- with its slice of Wpi / Wvf
+// in registers; the nact+1 dot products are butterfly-reduced across the wave (every lane ends with the same sums),
+// every lane evaluates the per-sample loss algebra of model.py:57-91 redundantly, writes its slice of the masked dz row
+// and accumulates its slice of the head-weight gradients in registers.  Fixed summation orders: run-to-run identical.
+template <int KPL>
+__global__ __launch_bounds__(256) void heads_train_wave_kernel(HeadArgs a) {
+    constexpr int NA = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][HP] head-gradient partials
+    __shared__ double sst[4][5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nact = a.nact, nlat = a.nlat;
+    float W[KPL][NA], Wv[KPL], gW[KPL][NA], gWv[KPL], gb[NA], gbv = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+        const int k = lane * KPL + kk;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            W[kk][j] = j < nact ? a.Wpi[k * nact + j] : 0.f;
+            gW[kk][j] = 0.f;
+        }
+        Wv[kk] = a.Wvf[k];
+        gWv[kk] = 0.f;
+    }
+    float bpi[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { bpi[j] = j < nact ? a.bpi[j] : 0.f; gb[j] = 0.f; }
+    const float bv = a.bvf[0];
+    double st[5] = {0, 0, 0, 0, 0};
+    const float mean = a.advstat[0], sd = a.advstat[1] + 1e-8f;
+    const float eps = a.cliprange;
+    const float ce = a.ent_coef * a.invB;
+    const int nwaves = gridDim.x * 4;
+    for (int b = blockIdx.x * 4 + wave; b < a.Bc; b += nwaves) {
+        float x[KPL];
+        const float4* src = reinterpret_cast<const float4*>(a.lat + (long)b * nlat + lane * KPL);
+#pragma unroll
+        for (int q = 0; q < KPL / 4; ++q) {
+            const float4 v = src[q];
+            x[q * 4 + 0] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
+        }
+        const long r = a.idx ? envmajor_to_row(a.idx[b], a.T, a.N) : a.row0 + b;
+        const float R = a.returns[r], oldv = a.values[r], oldnlp = a.neglogp[r];
+        const int act = static_cast<const int32_t*>(a.actions)[r];
+        float pi[NA], v = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) t = fmaf(x[kk], W[kk][j], t);
+            pi[j] = t;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPL; ++kk) v = fmaf(x[kk], Wv[kk], v);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                if (j < nact) pi[j] += __shfl_xor(pi[j], off);
+            v += __shfl_xor(v, off);
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) pi[j] += bpi[j];
+        v += bv;
+        // ---- per-sample loss algebra, identical in every lane (same formulas as heads_train_kernel)
+        const float adv = ((R - oldv) - mean) / sd;
+        float mx = pi[0];
+#pragma unroll
+        for (int j = 1; j < NA; ++j) if (j < nact) mx = fmaxf(mx, pi[j]);
+        float z0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) if (j < nact) z0 += expf(pi[j] - mx);
+        const float logz = logf(z0);
+        float pact = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) if (j == act) pact = pi[j];
+        const float nlp = logz - (pact - mx);
+        float H = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (j < nact) {
+                const float a0 = pi[j] - mx;
+                H += (expf(a0) / z0) * (logz - a0);
+            }
+        const float ratio = expf(oldnlp - nlp);
+        const float pg1 = -adv * ratio;
+        const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+        const float pg2 = -adv * rc;
+        const float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+        const float dnlp = dr * (-ratio) * a.invB;
+        float dpi[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            dpi[j] = 0.f;
+            if (j < nact) {
+                const float a0 = pi[j] - mx;
+                const float p = expf(a0) / z0;
+                const float logp = a0 - logz;
+                dpi[j] = dnlp * (p - (j == act ? 1.f : 0.f)) + ce * p * (logp + H);
+            }
+        }
+        const float dvc = fminf(fmaxf(v - oldv, -eps), eps);
+        const float vclip = oldv + dvc;
+        const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+        const float dl = (l1 >= l2) ? (v - R) : ((v - oldv >= -eps && v - oldv <= eps) ? (vclip - R) : 0.f);
+        const float dv = a.vf_coef * a.invB * dl;
+        st[0] += (double)fmaxf(pg1, pg2);
+        st[1] += 0.5 * (double)fmaxf(l1, l2);
+        st[2] += (double)H;
+        st[3] += 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
+        st[4] += (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
+        // ---- dz of the latent layer (masked by act') and this lane's slice of the head gradients
+        float g[KPL];
+#pragma unroll
+        for (int kk = 0; kk < KPL; ++kk) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) t = fmaf(dpi[j], W[kk][j], t);
+            t = fmaf(dv, Wv[kk], t);
+            g[kk] = t * act_bwd_from_out(x[kk], a.lat_act);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) gW[kk][j] = fmaf(x[kk], dpi[j], gW[kk][j]);
+            gWv[kk] = fmaf(x[kk], dv, gWv[kk]);
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) gb[j] += dpi[j];
+        gbv += dv;
+        float4* dst = reinterpret_cast<float4*>(a.dz_pi + (long)b * nlat + lane * KPL);
+#pragma unroll
+        for (int q = 0; q < KPL / 4; ++q) dst[q] = make_float4(g[q * 4], g[q * 4 + 1], g[q * 4 + 2], g[q * 4 + 3]);
+    }
+    // ---- combine the 4 waves of the block in fixed order -> one partial slab per block (layout of heads_train_kernel)
+    float* mine = smem + (long)wave * a.HP;
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+        const int k = lane * KPL + kk;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (j < nact) mine[k * nact + j] = gW[kk][j];
+        mine[nlat * nact + nact + k] = gWv[kk];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (j < nact) mine[nlat * nact + j] = gb[j];
+        mine[nlat * nact + nact + nlat] = gbv;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sst[wave][j] = st[j];
+    }
+    __syncthreads();
+    for (int e = tid; e < a.HP; e += 256)
+        a.hpart[(long)blockIdx.x * a.HP + e] = ((smem[e] + smem[a.HP + e]) + smem[2 * a.HP + e]) + smem[3 * a.HP + e];
+    if (tid < 5) a.spart[blockIdx.x * 5 + tid] = ((sst[0][tid] + sst[1][tid]) + sst[2][tid]) + sst[3][tid];
 }
 
 // stats_acc[j] += sum_blk spart[blk][j]
@@ -1316,10 +1473,27 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
+        // wave-per-sample kernel for the NatureCNN head shape (Categorical <= 8 actions, shared 512-wide latent)
+        const bool wave_ok = a.has_pi_head && a.shared && a.pd_kind == MRL_PD_CATEGORICAL && a.nact <= 8 && a.nlat == 512 &&
+                             m->HP == a.nlat * a.nact + a.nact + a.nlat + 1 && (uintptr_t)a.lat % 16 == 0 &&
+                             (uintptr_t)a.dz_pi % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 1);
+        if (wave_ok) nblk = std::min((Bc + 31) / 32, HEAD_MAXBLK);       // >= 8 samples per wave
         {
             // algorithmic traffic: latent in, dz out, per-sample rollout scalars
             ProfScope ps("heads_loss", 0.0, (double)Bc * (8.0 * a.nlat + (a.shared ? 0 : 8.0 * a.nlatv) + 28.0), st);
-            hipLaunchKernelGGL(heads_train_kernel, dim3(nblk), dim3(256), lds, st, a);
+            if (wave_ok) {
+                const size_t wl = (size_t)4 * m->HP * sizeof(float);
+                static bool raised = false;
+                if (!raised && wl > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute((const void*)heads_train_wave_kernel<8>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return (int)e;
+                    raised = true;
+                }
+                hipLaunchKernelGGL(heads_train_wave_kernel<8>, dim3(nblk), dim3(256), wl, st, a);
+            } else {
+                hipLaunchKernelGGL(heads_train_kernel, dim3(nblk), dim3(256), lds, st, a);
+            }
         }
         MRL_LAUNCH_CHECK();
         if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st))) return rc;

@@ -289,6 +289,8 @@ def test_engine_options_agree():
                                                  ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False, 1152, 'f32_bf16x6'),
                                                  ('mlp', (376,), np.float32, 'gaussian', 17, True, 200, 'mlp_fused'),
                                                  ('mlp', (4,), np.float32, 'categorical', 2, False, 96, 'mlp_fused')]:
+            for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused'):
+                L.set_option(o, 1)                      # every case starts from the defaults
             g1, s1 = grads(net, shp, dt, pd, na, vc, B, opt, 1)
             g0, s0 = grads(net, shp, dt, pd, na, vc, B, opt, 0)
             scale = np.abs(g0).max()
@@ -298,8 +300,8 @@ def test_engine_options_agree():
             else:
                 # a thousand samples put a few pre-activations within round-off of the ReLU kink: the unit switches on in
                 # one engine and off in the other (measured: 1 of 590k fc1 units), which moves that sample's gradient
-                # rows by ~1e-4 of the scale.  Everything else agrees to round-off.
-                assert np.percentile(diff, 99.0) <= 2e-6 * scale + 1e-9, (opt, np.percentile(diff, 99.0), scale)
+                # rows by ~1e-4 of the scale and, through the conv weight gradients (sums over all samples), everything a little.
+                assert np.percentile(diff, 99.0) <= 1e-5 * scale + 1e-9, (opt, np.percentile(diff, 99.0), scale)
                 assert np.linalg.norm(g1 - g0) <= 1e-3 * np.linalg.norm(g0), (opt, np.linalg.norm(g1 - g0), np.linalg.norm(g0))
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
     finally:
