@@ -274,6 +274,198 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Asynchronous variant (the default): the three memory phases of a group no longer sit between the MFMA streams.
+//   * staging is LDS-DMA (`global_load_lds`, 1 KB per wave instruction, no VGPR round trip, no ds_write): issued right
+//     after the barrier that ends a group's MFMA phase, it runs while the waves compute the NEXT group's destination
+//     offsets.  The DMA image is lane-linear, so the pixel rows cannot be padded; bank conflicts are avoided by an XOR
+//     swizzle applied through the SOURCE address (chunk c of pixel p is stored at position c ^ (p & 15)) and undone
+//     in the fragment reads;
+//   * the act' mask values (h_prev) are loaded BEFORE the MFMA stream into registers (8 waves x 2 row tiles leave
+//     room: 256 VGPRs per lane) and the destination offsets are computed once per group and kept -- the epilogue is
+//     32 fire-and-forget stores per wave.
+// ------------------------------------------------------------------------------------------
+template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES_, int TMW_>
+struct LdsDgradAsyncCfg : LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES_, TMW_> {
+    using Base = LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES_, TMW_>;
+    static constexpr int QUADS = (G * Base::NPIX + 3) / 4;           // 4 pixels (1 KB) per DMA instruction
+    static constexpr int ZPIX = QUADS * 4;                           // index of the zero pixel
+    static constexpr int DZ_FLOATS = (ZPIX + 1) * NF;
+    static constexpr size_t LDS_BYTES = (size_t)(Base::W_FLOATS + DZ_FLOATS) * 4;
+    static_assert(NF == 64, "a pixel is 16 chunks of 16 bytes (the swizzle domain)");
+    static_assert(LDS_BYTES <= 160 * 1024, "filter slice + image group must fit the CU's LDS");
+};
+
+template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW>
+__global__ __launch_bounds__(WAVES * 64) void lds_dgrad_async_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                      const float* __restrict__ hprev, float* __restrict__ out,
+                                                                      int act, int B, long long* dbg) {
+    using K = LdsDgradAsyncCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wt = smem;                                   // [32][KP]   wt[c][tap*NF + n]
+    float* dzs = smem + K::W_FLOATS;                    // [ZPIX + 1][NF], chunk-swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x / K::ROLES;                                 // host launches a multiple of 8*ROLES
+    const int xcd = blockIdx.x % 8, rest = blockIdx.x / 8;
+    const int role = rest % K::ROLES, wg = (rest / K::ROLES) * 8 + xcd;   // the ROLES readers of a group share one XCD
+    const int z = role / K::NSPL, cs = role % K::NSPL;
+    const int py = z / STRIDE, px = z % STRIDE;
+    const int ngroups = (B + G - 1) / G;
+    for (int e = tid; e < 32 * K::KD; e += K::NT) {
+        const int n = e % NF, t = (e / NF) % (K::TAPS * K::TAPS), c = e / (NF * K::TAPS * K::TAPS);
+        const int a = t / K::TAPS, b2 = t % K::TAPS;
+        const int ky = py + STRIDE * a, kx = px + STRIDE * b2;
+        float v = 0.f;
+        if (ky < RF && kx < RF) v = w[((long)(ky * RF + kx) * C + cs * 32 + c) * NF + n];
+        wt[c * K::KP + t * NF + n] = v;
+    }
+    for (int e = tid; e < NF; e += K::NT) dzs[(long)K::ZPIX * NF + e] = 0.f;        // zero pixel
+
+    const long pixmax = (long)B * K::NPIX - 1;
+    auto issue_stage = [&](int grp) {
+        const long pix0 = (long)grp * G * K::NPIX;
+        for (int q = wave; q < K::QUADS; q += WAVES) {
+            const int pl = 4 * q + (lane >> 4);
+            const long gp = min(pix0 + pl, pixmax);              // past the end: duplicates, never referenced
+            const float* src = dz + gp * NF + (((lane & 15) ^ (pl & 15)) << 2);
+            __builtin_amdgcn_global_load_lds(src, dzs + (long)4 * q * NF, 16, 0, 0);
+        }
+    };
+    int it = 0;
+    auto stamp = [&](int k) {
+        if (dbg && wg == 0 && role == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1) && it < 6)
+            dbg[((wave ? 1 : 0) * 6 + it) * 8 + k] = (long long)__builtin_readcyclecounter();
+    };
+    if (wg < ngroups) issue_stage(wg);
+    for (int grp = wg; grp < ngroups; grp += nwg, ++it) {
+        stamp(0);
+        const int b0 = grp * G;
+        // ---- destination offsets of this wave's tiles (32-bit, relative to the group's first image), kept for the epilogue
+        const long gbase = (long)b0 * (H * W * C) + cs * 32 + i;
+        const int gleft = B - b0;
+        int goff[TMW][16];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) {
+            const int m0 = (wave * TMW + t) * 32 + 4 * h;
+            const int g0 = m0 / K::PER, r0 = m0 % K::PER;
+            const int yy0 = r0 / K::WX, xx0 = r0 % K::WX;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2);
+                int yy1 = yy0 + d / K::WX, g1 = g0;
+                int xx1 = xx0 + d % K::WX;
+                if (xx1 >= K::WX) { xx1 -= K::WX; ++yy1; }
+                if (yy1 >= 2 * K::HY) { yy1 -= 2 * K::HY; g1 += 2; }
+                if (yy1 >= K::HY) { yy1 -= K::HY; ++g1; }
+                const int iy = yy1 * STRIDE + py, ix = xx1 * STRIDE + px;
+                const bool ok = g1 < G && g1 < gleft && iy < H && ix < W;
+                goff[t][r] = ok ? ((g1 * H + iy) * W + ix) * C : -1;
+            }
+        }
+        stamp(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this group's DMA has landed
+        __syncthreads();
+        stamp(2);
+        // ---- act' mask values: in flight during the MFMA stream
+        float hv[TMW][16];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[t][r] = hprev[gbase + (goff[t][r] < 0 ? 0 : goff[t][r])];
+        __builtin_amdgcn_sched_barrier(0);
+
+        int pixbase[TMW], yy[TMW], xx[TMW];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) {
+            const int m = (wave * TMW + t) * 32 + i;
+            const int g = m / K::PER, r = m % K::PER;
+            const bool ok = m < K::ROWS && b0 + g < B;
+            yy[t] = ok ? r / K::WX : -0x10000;
+            xx[t] = r % K::WX;
+            pixbase[t] = g * K::NPIX;
+        }
+        f32x16 acc[TMW];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const float* wrow = wt + i * K::KP + h * 4;
+        constexpr int NBLK = NF / 8;
+#pragma unroll
+        for (int tap = 0; tap < K::TAPS * K::TAPS; ++tap) {
+            const int a = tap / K::TAPS, b2 = tap % K::TAPS;
+            const float* ap[TMW];
+            int sw[TMW];
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                const int oy = yy[t] - a, ox = xx[t] - b2;
+                const bool ok = (unsigned)oy < (unsigned)K::OH && (unsigned)ox < (unsigned)K::OW;
+                const int pix = ok ? pixbase[t] + oy * K::OW + ox : K::ZPIX;
+                ap[t] = dzs + (long)pix * NF;
+                sw[t] = pix & 15;
+            }
+            // chunk (2j + h) of pixel p sits at position (2j + h) ^ (p & 15)
+            float4 fa[TMW], fb;
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) fa[t] = *reinterpret_cast<const float4*>(ap[t] + ((h ^ sw[t]) << 2));
+            fb = *reinterpret_cast<const float4*>(wrow + tap * NF);
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) {
+                float4 na[TMW], nb;
+                if (j + 1 < NBLK) {
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t)
+                        na[t] = *reinterpret_cast<const float4*>(ap[t] + ((((j + 1) * 2 + h) ^ sw[t]) << 2));
+                    nb = *reinterpret_cast<const float4*>(wrow + tap * NF + (j + 1) * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < TMW; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t].x, fb.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t].y, fb.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t].z, fb.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t].w, fb.w, acc[t], 0, 0, 0);
+                }
+                if (j + 1 < NBLK) {
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) fa[t] = na[t];
+                    fb = nb;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        stamp(3);
+        // ---- epilogue: stores only (mask values arrived long ago)
+#pragma unroll
+        for (int t = 0; t < TMW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (goff[t][r] >= 0) out[gbase + goff[t][r]] = acc[t][r] * act_bwd_from_out(hv[t][r], act);
+        stamp(4);
+        __syncthreads();                                 // everyone is done reading this group's dz
+        stamp(5);
+        if (grp + nwg < ngroups) issue_stage(grp + nwg);
+        stamp(6);
+    }
+}
+
+template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW>
+inline hipError_t launch_lds_dgrad_async(const float* dz, const float* w, const float* hprev, float* out, int act, int B,
+                                         int num_cus, long long* dbg, hipStream_t stream) {
+    using K = LdsDgradAsyncCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
+    auto kern = lds_dgrad_async_kernel<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    const int ngroups = (B + G - 1) / G;
+    int per_role = std::max(8, std::min(num_cus / K::ROLES, (ngroups + 7) / 8 * 8) / 8 * 8);   // multiple of 8 (XCD decode)
+    hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, w, hprev, out, act, B, dbg);
+    return hipGetLastError();
+}
+
 template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW, int DBG>
 inline hipError_t launch_lds_dgrad(const float* dz, const float* hcur, const float* w, const float* hprev, float* out,
                                    int act, int B, int num_cus, int stagger, long long* dbg, hipStream_t stream) {

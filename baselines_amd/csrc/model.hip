@@ -1224,6 +1224,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     // 16 waves x 1 row tile, groups of 5 / 6 images (measured alternatives in profiles/README.md:
                     // 8 waves x 2 tiles and two half-size workgroups per CU are slower)
                     const int cfg = get_option("dgrad_cfg", "MRL_DGRAD_CFG", 0);
+                    // asynchronous variant (LDS-DMA staging, mask prefetch) where it measures faster: conv2 (4 taps per
+                    // class: the memory phases are a third of a group) 9.05 -> 8.7 ms; conv3 (9 taps) 6.6 -> 6.9 ms, stays
+                    // on the synchronous kernel
+                    if (cfg == 0 && lk == 1 && !hcur && hmask) {
+                        e = launch_lds_dgrad_async<20, 20, 32, 4, 2, 64, 5, 8, 2>(dz, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), dbgp, st);
+                    } else
                     if (lk == 1 && cfg == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 2, 8, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, 2 * num_cus(), stg, dbgp, st);
                     else if (lk == 1 && cfg == 2) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 8, 2, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
                     else

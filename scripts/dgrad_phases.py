@@ -31,7 +31,8 @@ for it in range(2):
 torch.cuda.synchronize()
 ws = model.dm.workspace
 st = ws[-2048 + 512:-2048 + 512 + 96 * 8].view(torch.int64).cpu().numpy().reshape(2, 6, 8)
-names = ['wait prev (barrier)', 'stage', 'barrier', 'MFMA stream', 'epi loads issued', 'epi stores issued']
+names = (['offsets', 'dma-wait+barrier', 'masks+MFMA', 'stores', 'barrier', 'dma-issue'] if os.environ.get('MRL_DGRAD_CFG', '0') == '0'
+         else ['wait prev (barrier)', 'stage', 'barrier', 'MFMA stream', 'epi loads issued', 'epi stores issued'])
 for w, wn in enumerate(('wave 0', 'last wave')):
     print(wn)
     for it in range(6):
