@@ -53,6 +53,8 @@ SIGNATURES = {
     'mrl_adam_scratch_bytes': (c_size_t, [c_long]),
     'mrl_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'mrl_adam_clip_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float,
+                                       c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'mrl_synth_env_obs': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -152,8 +154,18 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_PROF_ON = False
+
+
 def prof_enable(on=True):
+    global _PROF_ON
+    _PROF_ON = bool(on)
     load().mrl_prof_enable(1 if on else 0)
+
+
+def prof_enabled():
+    """True while per-kernel HIP events are being recorded (they cannot be recorded inside a launch-graph capture)."""
+    return _PROF_ON
 
 
 def prof_report():

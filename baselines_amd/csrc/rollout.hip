@@ -257,10 +257,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ v, long P, float alpha, float beta1,
                                                    float beta2, float eps, float max_grad_norm, float total_weight,
                                                    const double* __restrict__ part, int npart,
-                                                   float* __restrict__ gnorm_out) {
+                                                   float* __restrict__ gnorm_out, const float* __restrict__ alpha_dev) {
     __shared__ double sh[4];
     __shared__ float s_scale;
     float scale = 1.f;
+    if (alpha_dev) alpha = alpha_dev[0];      // step size kept in device memory (replayable launch graphs)
     if (max_grad_norm >= 0.f) {
         double s = 0.0;
         for (int i = threadIdx.x; i < npart; i += 256) s += part[i];
@@ -337,9 +338,9 @@ extern "C" size_t mrl_adam_scratch_bytes(long P) {
     return ADAM_MAX_PART * sizeof(double);
 }
 
-extern "C" int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, float alpha, float beta1,
-                                  float beta2, float eps, float max_grad_norm, float total_weight, float* gnorm_out,
-                                  void* scratch, void* stream) {
+static int adam_clip_step_impl(float* params, float* grads, float* m, float* v, long P, float alpha, const float* alpha_dev,
+                               float beta1, float beta2, float eps, float max_grad_norm, float total_weight,
+                               float* gnorm_out, void* scratch, void* stream) {
     if (!params || !grads || !m || !v || P <= 0 || !scratch || total_weight <= 0.f) return MRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int blocks = (int)min((P + 1023) / 1024, (long)ADAM_MAX_PART);
@@ -349,7 +350,22 @@ extern "C" int mrl_adam_clip_step(float* params, float* grads, float* m, float* 
         MRL_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, P, alpha, beta1, beta2, eps,
-                       max_grad_norm, total_weight, (const double*)scratch, blocks, gnorm_out);
+                       max_grad_norm, total_weight, (const double*)scratch, blocks, gnorm_out, alpha_dev);
     MRL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, float alpha, float beta1,
+                                  float beta2, float eps, float max_grad_norm, float total_weight, float* gnorm_out,
+                                  void* scratch, void* stream) {
+    return adam_clip_step_impl(params, grads, m, v, P, alpha, nullptr, beta1, beta2, eps, max_grad_norm, total_weight,
+                               gnorm_out, scratch, stream);
+}
+
+extern "C" int mrl_adam_clip_step_dev(float* params, float* grads, float* m, float* v, long P, const float* alpha_dev,
+                                      float beta1, float beta2, float eps, float max_grad_norm, float total_weight,
+                                      float* gnorm_out, void* scratch, void* stream) {
+    if (!alpha_dev) return MRL_EINVAL;
+    return adam_clip_step_impl(params, grads, m, v, P, 0.f, alpha_dev, beta1, beta2, eps, max_grad_norm, total_weight,
+                               gnorm_out, scratch, stream);
 }

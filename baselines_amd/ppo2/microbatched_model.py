@@ -70,6 +70,11 @@ class MicrobatchedModel(Model):
             return stats_out
         return stats
 
+    def train_epoch(self, lr, cliprange, rollout, inds_dev):
+        B = self.minibatch_size
+        return torch.stack([self.train_indexed(lr, cliprange, rollout, inds_dev[k * B:(k + 1) * B])
+                            for k in range(inds_dev.numel() // B)])
+
     def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
         assert states is None, 'microbatches with recurrent models are not supported yet'
         obs = self._to_dev_obs(obs)

@@ -85,6 +85,7 @@ class Model(object):
         self._gen.manual_seed(int(torch.initial_seed()) & 0x7fffffff)
         self._train_calls = 0
         self._fast = None
+        self._epoch_graph = None
         # ---- multi-rank: total weight (mpi_adam_optimizer.py:25-27), sync_from_root (model.py:129-131) ----
         self.total_weight = 1.0
         if self.comm is not None and self.comm.Get_size() > 1:
@@ -204,6 +205,67 @@ class Model(object):
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
         self._train_calls += 1
         return stats
+
+    # ------------------------------------------------------------------ one epoch as a replayable launch graph
+    def _next_alpha(self, lr):
+        """TF-1 Adam step size for the next step + the beta-power update (host f32 arithmetic, model.py:98-100)"""
+        one = np.float32(1)
+        alpha = np.float32(lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self._train_calls += 1
+        return alpha
+
+    def train_epoch(self, lr, cliprange, rollout, inds_dev):
+        """All minibatch steps of one epoch (`inds_dev`: the epoch's permutation, nminibatches * nbatch_train env-major
+        indices on the device).  Returns a device tensor [nminibatches, 5] of loss stats.
+
+        The launch-bound MLP configurations (320 steps of ~7 small kernels per update) run the epoch as ONE hipGraph:
+        the step sequence is captured once per update (the learning rate and the clip range are fixed inside an update),
+        reads its indices and its Adam step sizes from device buffers that are refreshed before every replay, and
+        is replayed once per epoch -- HIP graphs instead of ~2,000 individual launches per update.  Large-kernel
+        configurations (NatureCNN), multi-rank runs (the all-reduce sits between the two halves of a step) and
+        per-kernel profiling use the plain step loop."""
+        B = self.nbatch_train
+        M = inds_dev.numel() // B
+        graphable = (not self.multi and self.dm.network == 'mlp' and self._train_calls > 0 and not _lib.prof_enabled()
+                     and type(self).train_indexed is Model.train_indexed          # subclasses that hook the step keep it
+                     and os.environ.get('MRL_EPOCH_GRAPH', '1') != '0')
+        if not graphable:
+            return torch.stack([self.train_indexed(lr, cliprange, rollout, inds_dev[k * B:(k + 1) * B]) for k in range(M)])
+        key = (float(lr), float(cliprange), rollout.obs.data_ptr(), rollout.returns.data_ptr(), rollout.values.data_ptr(), M, B)
+        g = self._epoch_graph
+        if g is None or g['key'] != key:
+            g = self._epoch_graph = self._capture_epoch(key, cliprange, rollout, M, B)
+        g['idx'].copy_(inds_dev.view(M, B))
+        g['alpha'].copy_(torch.from_numpy(np.array([self._next_alpha(lr) for _ in range(M)], dtype=np.float32)))
+        g['graph'].replay()
+        return g['stats'].clone()
+
+    def _capture_epoch(self, key, cliprange, rollout, M, B):
+        lib, st_dtype = _lib.load(), torch.float32
+        idx = torch.zeros((M, B), dtype=torch.int64, device=self.device)
+        alpha = torch.zeros(M, dtype=torch.float32, device=self.device)
+        stats = torch.zeros((M, 5), dtype=st_dtype, device=self.device)
+        mgn = -1.0 if self.max_grad_norm is None else float(self.max_grad_norm)
+        P = self.params.numel()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            st = _lib.stream_ptr()                         # the capturing stream
+            for k in range(M):
+                _lib.check(lib.mrl_model_grad(self.dm.handle, _lib.ptr(self.params), _lib.ptr(rollout.obs),
+                                              _lib.ptr(rollout.actions), _lib.ptr(rollout.returns), _lib.ptr(rollout.values),
+                                              _lib.ptr(rollout.neglogpacs), _lib.ptr(idx[k]), B, int(rollout.T), int(rollout.N),
+                                              float(cliprange), self.ent_coef, self.vf_coef, _lib.ptr(self.grads),
+                                              _lib.ptr(stats[k]), _lib.ptr(self.dm.workspace), self.dm.workspace.numel(),
+                                              self.dm.chunk, st), 'mrl_model_grad')
+                _lib.check(lib.mrl_adam_clip_step_dev(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                                      _lib.ptr(self.adam_v), P, _lib.ptr(alpha[k:k + 1]), float(self.beta1),
+                                                      float(self.beta2), float(self.epsilon), mgn, float(self.total_weight),
+                                                      _lib.ptr(self._gnorm), _lib.ptr(self._scratch), st),
+                           'mrl_adam_clip_step_dev')
+        return dict(key=key, graph=graph, idx=idx, alpha=alpha, stats=stats)
 
     def _field(self, x, dtype):
         if isinstance(x, torch.Tensor):

@@ -141,9 +141,12 @@ def learn(*, network, env, total_timesteps, eval_env=None, seed=None, nsteps=204
             np.random.shuffle(inds)
             if fast:
                 inds_dev = torch.from_numpy(inds).to(model.device)
-                for lo in range(0, nbatch, nbatch_train):
-                    step_stats.append(model.train_indexed(lrnow, cliprangenow, runner.rollout,
-                                                          inds_dev[lo:lo + nbatch_train]))
+                if hasattr(model, 'train_epoch'):           # one replayable launch graph per epoch where that pays
+                    step_stats.extend(model.train_epoch(lrnow, cliprangenow, runner.rollout, inds_dev).unbind(0))
+                else:
+                    for lo in range(0, nbatch, nbatch_train):
+                        step_stats.append(model.train_indexed(lrnow, cliprangenow, runner.rollout,
+                                                              inds_dev[lo:lo + nbatch_train]))
             else:
                 for lo in range(0, nbatch, nbatch_train):
                     pick = inds[lo:lo + nbatch_train]

@@ -180,13 +180,18 @@ def main():
         for _ in range(hp['noptepochs']):
             np.random.shuffle(inds)
             inds_dev = torch.from_numpy(inds).to(model.device)
-            for start in range(0, nbatch, nbatch_train):
-                stats.append(model.train_indexed(hp['lr'], hp['cliprange'], ro, inds_dev[start:start + nbatch_train]))
+            stats.extend(model.train_epoch(hp['lr'], hp['cliprange'], ro, inds_dev).unbind(0))
         return torch.stack(stats).mean(dim=0)
 
+    # The launch-bound MLP workload runs each epoch as one replayed hipGraph (Model.train_epoch); HIP events cannot be
+    # recorded inside a graph, so there the per-kernel times come from one extra, untimed, eager update after the
+    # timed region.  The Atari workload (the metric) launches every kernel individually: events sit inside the timed region.
+    graph_mode = (args.workload == 'mujoco' and world == 1 and os.environ.get('MRL_EPOCH_GRAPH', '1') != '0')
     for _ in range(args.warmup):
         update()
-    if not args.no_prof:
+    if graph_mode:
+        update()                                   # the first update after the eager warm-up captures; keep that out too
+    if not args.no_prof and not graph_mode:
         _lib.prof_enable(True)
     sync()
     t0 = time.perf_counter()
@@ -195,7 +200,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = {}
+    prof_steps = args.steps
     if not args.no_prof:
+        if graph_mode:
+            _lib.prof_enable(True)
+            update()
+            sync()
+            prof_steps = 1
         _lib.prof_enable(False)
         prof = _lib.prof_report()
     if world > 1:
@@ -253,8 +264,10 @@ def main():
             'loss': [float(x) for x in lossvals],
             'roofline': roof,
         }
+        if graph_mode:
+            out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps); kernel times from a separate eager update'
         if prof:
-            out['kernel_ms_per_step'] = {k: round(v['ms'] / args.steps, 3) for k, v in
+            out['kernel_ms_per_step'] = {k: round(v['ms'] / prof_steps, 3) for k, v in
                                          sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)

@@ -133,6 +133,12 @@ size_t mrl_adam_scratch_bytes(long P);
 int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, float alpha,
                        float beta1, float beta2, float eps, float max_grad_norm,
                        float total_weight, float* gnorm_out, void* scratch, void* stream);
+/* Same, with the step size read from device memory (f32 [1]) when the kernel runs: the launch carries no
+ * per-step scalar, so a captured hipGraph of an epoch's minibatch steps can be replayed (the caller refreshes the
+ * alpha array between replays -- TF keeps beta1_power/beta2_power in device variables for the same reason). */
+int mrl_adam_clip_step_dev(float* params, float* grads, float* m, float* v, long P, const float* alpha_dev,
+                           float beta1, float beta2, float eps, float max_grad_norm,
+                           float total_weight, float* gnorm_out, void* scratch, void* stream);
 
 /* ---- K13: HBM replay ring --- deepq/replay_buffer.py:24-43 ----------------------------------
  * SoA ring buffers [maxsize][...]: obs_t / obs_tp1 raw bytes (ob_bytes per transition), act int32,

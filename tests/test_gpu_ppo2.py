@@ -220,3 +220,27 @@ def test_total_timesteps_zero_builds_model_only():
     assert a.shape == (4,) and a.dtype == np.int64 and v.shape == (4,) and s is None and nlp.shape == (4,)
     with pytest.raises(ValueError):
         ppo2.learn(network='lstm', env=env, total_timesteps=0)
+
+
+@pytest.mark.parametrize('kind', ['cartpole', 'mujoco'])
+def test_epoch_graph_replay_equals_step_loop(kind, monkeypatch):
+    """Model.train_epoch: an epoch replayed as one hipGraph (indices and Adam step sizes refreshed in device buffers)
+    ends bit-identical to the individually launched steps -- parameters after 3 updates and the logged loss stats."""
+    from baselines_amd import ppo2
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
+    vn = 'copy' if kind == 'mujoco' else None
+
+    def run(flag):
+        monkeypatch.setenv('MRL_EPOCH_GRAPH', flag)
+        seen = []
+        model = ppo2.learn(network='mlp', env=SyntheticVecEnv(kind, 16, seed=4), total_timesteps=3 * 16 * 32, seed=1, nsteps=32,
+                           nminibatches=4, noptepochs=3, lr=lambda f: 1e-3 * f, cliprange=lambda f: 0.2 * f, value_network=vn,
+                           log_interval=100, update_fn=seen.append)
+        assert seen == [1, 2, 3]
+        return model
+    eager = run('0')
+    graphed = run('1')
+    assert graphed._epoch_graph is not None and eager._epoch_graph is None
+    np.testing.assert_array_equal(eager.get_flat_params(), graphed.get_flat_params())
+    np.testing.assert_array_equal(eager.adam_v.cpu().numpy(), graphed.adam_v.cpu().numpy())
+    assert eager.beta1_power == graphed.beta1_power and eager._train_calls == graphed._train_calls == 36
