@@ -239,6 +239,18 @@ def main():
                 roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'launches': d['count'],
                         'avg_ms': d['ms'] / d['count'], 'share_of_kernel_time': d['ms'] / tot_ms}
+            # HBM-side bytes per launch of the dominant kernel from the committed PMC passes of the same shape
+            # (profiles/*_pmc_hbm.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, gfx950 corrections applied
+            # by scripts/pmc_to_json.py); PMC counters cannot be collected from inside this process
+            if args.workload == 'atari' and N * T // hp['nminibatches'] == 131072:
+                import glob
+                cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_pmc_hbm.json')))
+                if cand:
+                    with open(cand[-1]) as fh:
+                        per = json.load(fh).get('per_launch', {})
+                    if dom in per:
+                        roof['traffic'] = per[dom]['hbm_bytes']
+                        roof['traffic_source'] = 'profiles/' + os.path.basename(cand[-1])
             gemm_ms = sum(v['ms'] for v in prof.values() if v['flops'] > 0)
             gemm_fl = sum(v['flops'] for v in prof.values() if v['flops'] > 0)
             roof['all_gemm_tflops'] = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None

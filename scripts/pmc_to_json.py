@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""profiles/<tag>_pmc_hbm.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_epoch.sh (one epoch at the bench
+shape, B = 131072 per launch).  Corrections per MI355X_MICROARCH.md "HBM": the counters are in KB; on gfx950 FETCH_SIZE
+tallies the 128-byte requests of wide coalesced reads at 64 bytes -> doubled; WRITE_SIZE taken as is (checked here:
+c2.dgrad writes exactly its 6.71 GB).  Only kernels whose every dispatch in the run has the minibatch shape are listed
+(the backward kernels: 4 dispatches); forward kernels also serve the act side with other batch sizes.
+usage: pmc_to_json.py fetch.txt write.txt out.json"""
+import json
+import sys
+
+LABELS = {
+    'c2.dgrad': 'lds_dgrad_async_kernel<20, 20, 32',
+    'c3.dgrad': 'lds_dgrad_kernel<9, 9, 64',
+    'c1.wgrad': 'imgres_u8x3_wgrad_kernel<84',
+    'c2.wgrad': 'imgres_wgrad_kernel<false, 20, 20, 32',
+    'c3.wgrad': 'imgres_wgrad_kernel<false, 9, 9, 64',
+    'fc1.wgrad': 'gemm_kernel<mrl::RowMC, mrl::RowMC, mrl::EpiPartial',
+    'fc1.dgrad': 'gemm_x6_kernel<mrl::X6DenseA, mrl::EpiMaskAct',
+}
+
+
+def parse(path, counter):
+    out, name = {}, None
+    for line in open(path):
+        if not line.startswith(' '):
+            name = line
+        elif counter in line and name:
+            out[name] = float(line.split()[-1])
+    return out
+
+
+def main(fetch_txt, write_txt, out_json):
+    f, w = parse(fetch_txt, 'FETCH_SIZE'), parse(write_txt, 'WRITE_SIZE')
+    res = {}
+    for label, sub in LABELS.items():
+        fk = [v for k, v in f.items() if sub in k]
+        wk = [v for k, v in w.items() if sub in k]
+        if fk and wk:
+            res[label] = {'fetch_bytes': fk[0] * 1024 * 2, 'write_bytes': wk[0] * 1024,
+                          'hbm_bytes': fk[0] * 1024 * 2 + wk[0] * 1024,
+                          'raw': {'FETCH_SIZE_KB': fk[0], 'WRITE_SIZE_KB': wk[0]}}
+    json.dump({'note': __doc__.split('usage')[0].strip(), 'per_launch': res}, open(out_json, 'w'), indent=1)
+    for k, v in res.items():
+        print('%-10s fetch %.2f GB  write %.2f GB' % (k, v['fetch_bytes'] / 1e9, v['write_bytes'] / 1e9))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:4])
