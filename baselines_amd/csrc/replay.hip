@@ -99,8 +99,29 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
                                                            const float* __restrict__ td, double eps, double alpha,
                                                            double* __restrict__ max_priority, long ring_start,
                                                            long ring_maxsize, double leaf_const, int n) {
-    __shared__ double smax[1024];
+    // 64 KB of LDS: first the duplicate table (open-addressing hash leaf index -> largest entry j that names it), later
+    // reused for the running-max reduction
+    constexpr int HS = 8192;
+    __shared__ __attribute__((aligned(16))) int hs[2 * HS];
+    int* hkey = hs;
+    int* hval = hs + HS;
+    double* smax = reinterpret_cast<double*>(hs);
     const int tid = threadIdx.x, nt = blockDim.x;
+    const bool hashed = idx && n <= HS / 2;                 // larger batches: O(n^2) scan below
+    if (hashed) {
+        for (int e = tid; e < HS; e += nt) { hkey[e] = -1; hval[e] = -1; }
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) {
+            const int key = idx[j];
+            int slot = (int)(((unsigned)key * 2654435761u) >> 19) & (HS - 1);
+            while (true) {
+                const int prev = atomicCAS(&hkey[slot], -1, key);
+                if (prev == -1 || prev == key) { atomicMax(&hval[slot], j); break; }
+                slot = (slot + 1) & (HS - 1);
+            }
+        }
+        __syncthreads();
+    }
     double lmax = 0.0;
     for (int j = tid; j < n; j += nt) {
         long i;
@@ -115,8 +136,14 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
             } else {
                 v = leaf[j];
             }
-            for (int k = j + 1; k < n; ++k)
-                if (idx[k] == i) { write = false; break; }   // a later duplicate wins
+            if (hashed) {                                    // a later duplicate wins
+                int slot = (int)(((unsigned)idx[j] * 2654435761u) >> 19) & (HS - 1);
+                while (hkey[slot] != (int)i) slot = (slot + 1) & (HS - 1);
+                write = hval[slot] == j;
+            } else {
+                for (int k = j + 1; k < n; ++k)
+                    if (idx[k] == i) { write = false; break; }
+            }
         } else {
             i = (ring_start + j) % ring_maxsize;
             v = leaf_const;
@@ -128,6 +155,7 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
         }
     }
     if (td && max_priority) {                                // replay_buffer.py:191 running max
+        __syncthreads();                                     // the duplicate table is dead: its LDS becomes smax
         smax[tid] = lmax;
         __syncthreads();
         for (int s = nt >> 1; s > 0; s >>= 1) {
