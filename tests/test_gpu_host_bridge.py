@@ -12,6 +12,9 @@ from baselines_amd.common.vec_env import DummyVecEnv, ShmemVecEnv          # noq
 
 def make_fn(seed):
     def make():
+        import numpy as np                                           # imported here: the closure is shipped by value
+        from baselines_amd.common.spaces import Box, Discrete       # to spawned workers (cloudpickle)
+
         class Walk(object):
             """float32 random-walk observations driven by the actions; episodes of 9-11 steps"""
             observation_space = Box(low=-np.inf, high=np.inf, shape=(6,), dtype=np.float32)
@@ -39,7 +42,7 @@ def test_learn_through_bridge_matches_dummy():
     fns = [make_fn(i) for i in range(8)]
     kw = dict(network='mlp', total_timesteps=2 * 8 * 16, seed=3, nsteps=16, nminibatches=2, noptepochs=2, log_interval=10)
     ref = ppo2.learn(env=DummyVecEnv(fns), **kw)
-    bridge = ShmemVecEnv(fns, context='fork', in_series=2)
+    bridge = ShmemVecEnv(fns, context='spawn', in_series=2)     # spawn: the workers must not inherit the HIP context
     try:
         assert bridge.staging.is_pinned() or bridge._registered          # page-locked in place
         dst = torch.empty((8, 6), dtype=torch.float32, device='cuda')
