@@ -48,10 +48,10 @@ struct LdsDgradCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "filter slice + image group must fit the CU's LDS");
 };
 
-template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW, int DBG>
-__global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ hcur,
-                                                                const float* __restrict__ w, const float* __restrict__ hprev,
-                                                                float* __restrict__ out, int act, int B, int stagger, long long* dbg) {
+template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW>
+__global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                const float* __restrict__ hprev, float* __restrict__ out,
+                                                                int act, int B, long long* dbg) {
     using K = LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wt = smem;                                   // [32][KP]   wt[c][tap*NF + n]
@@ -67,14 +67,6 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
     const int z = role / K::NSPL, cs = role % K::NSPL;
     const int py = z / STRIDE, px = z % STRIDE;
     const int ngroups = (B + G - 1) / G;
-    // De-phasing: every workgroup runs the same stage -> MFMA -> store cycle; started together they hit HBM in
-    // bursts (all stores at once, then silence).  A one-time start delay spreads the phases of the workgroups
-    // over one cycle so the memory phases of some overlap the MFMA phases of the others.
-    if (stagger > 0) {
-        const long long wait = (long long)(wg % 16) * stagger / 16, t0 = clock64();
-        while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-    // DBG (timing experiments only): 1 = skip the epilogue, 2 = skip the per-group staging, 3 = both
     // ---- filter slice -> LDS (once): wt[c][ (a*TAPS + b2)*NF + n ] = W[py + s*a][px + s*b2][cs*32 + c][n]
     for (int e = tid; e < 32 * K::KD; e += K::NT) {
         const int n = e % NF, t = (e / NF) % (K::TAPS * K::TAPS), c = e / (NF * K::TAPS * K::TAPS);
@@ -86,38 +78,27 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
     }
     for (int e = tid; e < K::NFP; e += K::NT) dzs[(long)G * K::NPIX * K::NFP + e] = 0.f;    // zero pixel
 
-    // Deferred activation mask: when hcur != nullptr the incoming dz is the gradient w.r.t. this layer's
-    // OUTPUT (the producer skipped its act' epilogue, whose loads cannot overlap anything there); the ReLU
-    // mask (hcur > 0) is applied here, while copying into LDS.
-    //
-    // The copy is a plain synchronous phase between two barriers (global -> VGPR -> LDS, 4 vectors in
-    // flight per thread): ~5 % of a group's time.  Holding the next group in registers across the MFMA
-    // stream instead made the compiler spill and serialise (measured slower); the epilogue's stores of the
-    // previous group are still in flight during the copy, so the two memory phases overlap each other.
+    // The copy is a plain synchronous phase between two barriers (global -> VGPR -> LDS, 4 vectors in flight per
+    // thread).  Holding the next group in registers across the MFMA stream instead made the compiler spill and
+    // serialise (measured slower); the epilogue's stores of the previous group are still in flight during the copy.
     auto stage_group = [&](int grp) {
         const long base4 = (long)grp * K::DZV;
         const float4* src = reinterpret_cast<const float4*>(dz) + base4;
-        const float4* hsrc = reinterpret_cast<const float4*>(hcur) + base4;
         const long left4 = (long)B * K::NPIX * NF / 4 - base4;
         const int nvalid = (int)(left4 < (long)K::DZV ? left4 : (long)K::DZV);
         constexpr int U = 4;
         for (int e0 = tid; e0 < K::DZV; e0 += U * K::NT) {
-            float4 v[U], hm[U];
+            float4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = min(e0 + u * K::NT, nvalid - 1);
                 v[u] = src[e];
-                if (hcur) hm[u] = hsrc[e];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = e0 + u * K::NT;
                 if (e < K::DZV) {
                     float4 t = e < nvalid ? v[u] : f4zero();
-                    if (hcur) {
-                        t.x = hm[u].x > 0.f ? t.x : 0.f; t.y = hm[u].y > 0.f ? t.y : 0.f;
-                        t.z = hm[u].z > 0.f ? t.z : 0.f; t.w = hm[u].w > 0.f ? t.w : 0.f;
-                    }
                     const int pix = (e * 4) / NF, n = (e * 4) % NF;     // NF/4 float4 per pixel
                     *reinterpret_cast<float4*>(dzs + (long)pix * K::NFP + n) = t;
                 }
@@ -135,7 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
         stamp(0);
         __syncthreads();                                 // everyone is done reading the previous group
         stamp(1);
-        if (!(DBG & 2) || grp == wg) stage_group(grp);
+        stage_group(grp);
         stamp(2);
         __syncthreads();
         stamp(3);
@@ -203,15 +184,6 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
         // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*h
         // all act'-mask loads of both tiles are issued before the first store (a load -> wait -> store
         // chain per element costs 32 serial memory round trips per group)
-        if ((DBG & 1) && B > 0) {          // keep the accumulators alive without touching memory
-            float t = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < K::TMW; ++tt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[tt][r];
-            if (t == 123.456f) out[0] = t;
-            continue;
-        }
         float hv[K::TMW][16];
         // Destination offsets.  The row -> (image, iy, ix) map is invariant across groups: left alone the compiler
         // hoists all 32 offsets out of the group loop (64+ VGPRs live across the MFMA stream -> spills that
@@ -245,32 +217,22 @@ __global__ __launch_bounds__(WAVES * 64) void lds_dgrad_kernel(const float* __re
             }
         }
         auto off = [&](int t, int r) -> long { return goff[t][r] < 0 ? -1 : gbase + goff[t][r]; };
-        if (hprev) {
 #pragma unroll
-            for (int t = 0; t < K::TMW; ++t)
+        for (int t = 0; t < K::TMW; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long o = off(t, r);
-                    hv[t][r] = hprev[o < 0 ? 0 : o];
-                }
-            stamp(5);
+            for (int r = 0; r < 16; ++r) {
+                const long o = off(t, r);
+                hv[t][r] = hprev[o < 0 ? 0 : o];
+            }
+        stamp(5);
 #pragma unroll
-            for (int t = 0; t < K::TMW; ++t)
+        for (int t = 0; t < K::TMW; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long o = off(t, r);
-                    if (o >= 0) out[o] = acc[t][r] * act_bwd_from_out(hv[t][r], act);
-                }
-            stamp(6);
-        } else {                                   // mask deferred to the consumers: fire-and-forget stores
-#pragma unroll
-            for (int t = 0; t < K::TMW; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long o = off(t, r);
-                    if (o >= 0) out[o] = acc[t][r];
-                }
-        }
+            for (int r = 0; r < 16; ++r) {
+                const long o = off(t, r);
+                if (o >= 0) out[o] = acc[t][r] * act_bwd_from_out(hv[t][r], act);
+            }
+        stamp(6);
     }
 }
 
@@ -466,11 +428,11 @@ inline hipError_t launch_lds_dgrad_async(const float* dz, const float* w, const 
     return hipGetLastError();
 }
 
-template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW, int DBG>
-inline hipError_t launch_lds_dgrad(const float* dz, const float* hcur, const float* w, const float* hprev, float* out,
-                                   int act, int B, int num_cus, int stagger, long long* dbg, hipStream_t stream) {
+template <int H, int W, int C, int RF, int STRIDE, int NF, int G, int WAVES, int TMW>
+inline hipError_t launch_lds_dgrad(const float* dz, const float* w, const float* hprev, float* out, int act, int B,
+                                   int num_cus, long long* dbg, hipStream_t stream) {
     using K = LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
-    auto kern = lds_dgrad_kernel<H, W, C, RF, STRIDE, NF, G, WAVES, TMW, DBG>;
+    auto kern = lds_dgrad_kernel<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -479,7 +441,7 @@ inline hipError_t launch_lds_dgrad(const float* dz, const float* hcur, const flo
     }
     const int ngroups = (B + G - 1) / G;
     int per_role = std::max(8, std::min(num_cus / K::ROLES, (ngroups + 7) / 8 * 8) / 8 * 8);   // multiple of 8 (XCD decode)
-    hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, hcur, w, hprev, out, act, B, stagger, dbg);
+    hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, w, hprev, out, act, B, dbg);
     return hipGetLastError();
 }
 

@@ -230,7 +230,7 @@ static int get_option(const char* name, const char* env, int dflt) {
 }
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
-    static const char* known[] = {"u8_bf16x3", "defer_mask", "mlp_fused", "imgres_nacc", "mlp_dbg", "dgrad_stagger", "dgrad_dbg", "dgrad_cfg", "f32_bf16x6", "x6_cfg", "x6_dbg", "heads_wave"};
+    static const char* known[] = {"u8_bf16x3", "f32_bf16x6", "mlp_fused", "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg"};
     for (const char* k : known)
         if (!strcmp(k, name)) { option_table()[name] = value; return 0; }
     return MRL_EINVAL;
@@ -1034,13 +1034,11 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 return wres_dispatch(l.name, "fwd", var, l.NF, wa, wb, we, 1, l.K, tiles, fl, st);
             } else {
                 // fp32 activations: bf16 x 6 split engine (wres.hip.h) unless MRL_F32_BF16X6=0 asks for the fmaf chain
-                // group = PF blocks of 16 k inside one patch row; the deeper the group the more time its prefetch has
+                // fp32 activations: tiled bf16 x 6 engine with the im2col row map (gemmx6.hip.h) unless MRL_F32_BF16X6=0 asks
+                // for the fp32-MFMA weights-resident path
                 const int x6 = get_option("f32_bf16x6", "MRL_F32_BF16X6", 1);
                 const int rowk = l.rf * l.C;
-                const int pf = rowk % 128 == 0 ? 8 : rowk % 96 == 0 ? 6 : rowk % 64 == 0 ? 4 : 0;
-                if (x6 && planes && get_option("x6_cfg", "MRL_X6_CFG", 0) == 0 && rowk % X6_BK == 0 && l.C % 4 == 0 &&
-                    (uintptr_t)hprev % 16 == 0) {
-                    // tiled engine with the im2col row map: the split of an activation is shared by both 32-column blocks
+                if (x6 && planes && rowk % X6_BK == 0 && l.C % 4 == 0 && (uintptr_t)hprev % 16 == 0) {
                     X6ConvA ca;
                     fill_conv(ca, l, hprev, npix, nullptr);
                     char label[40];
@@ -1050,17 +1048,6 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     if (e != hipSuccess) return (int)e;
                     EpiBiasAct efx{hout, l.NF, bias, l.act};
                     return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st);
-                }
-                if (x6 && pf && l.C % 4 == 0 && wres_f32x6_lds_bytes(l.K) <= 160 * 1024) {
-                    WresFwdA8 wa8;
-                    fill_conv(wa8, l, hprev, npix, nullptr);
-                    char label[40];
-                    if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
-                    ProfScope ps(label, fl, 0.0, st);
-                    if (get_option("x6_cfg", "MRL_X6_CFG", 0) == 1) return (int)launch_wres_f32x6<WresEpiBiasAct, 4, 12>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
-                    if (pf == 8) return (int)launch_wres_f32x6<WresEpiBiasAct, 8, 8>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
-                    if (pf == 6) return (int)launch_wres_f32x6<WresEpiBiasAct, 6, 8>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
-                    return (int)launch_wres_f32x6<WresEpiBiasAct, 4, 8>(wa8, W, we, l.K, l.NF, tiles, num_cus(), st);
                 }
                 WresFwdA<false> wa;
                 fill_conv(wa, l, hprev, npix, nullptr);
@@ -1126,24 +1113,10 @@ static bool tuned(const Layer& l, const char* pass) {
 // backward through one net; nw.dz[last] already holds dloss/d(pre-activation of the last layer)
 static int net_backward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws,
                         float* grads, int B, int accumulate, hipStream_t st) {
-    // Deferred ReLU mask (see ldsdgrad.hip.h; OFF by default, MRL_DEFER_MASK=1 enables it: measured slower
-    // because the consumers' staging is a synchronous memory phase): defer[j] == true means nw.dz[j] holds the gradient w.r.t. layer
-    // j's OUTPUT and both of its consumers (layer j's weight- and data-gradient kernels) apply (h[j] > 0)
-    // while staging it into LDS.  Only when every consumer is one of the LDS-resident engines.
-    std::vector<char> defer(net.L.size(), 0);
-    const int defer_on = get_option("defer_mask", "MRL_DEFER_MASK", 0);
-    for (size_t j = 0; defer_on && j + 1 < net.L.size(); ++j) {
-        const Layer& lj = net.L[j];
-        const void* src = j == 0 ? in.obs : (const void*)nw.h[j - 1];
-        const bool wg_ok = imgres_kind(lj, j == 0 && m->d.ob_dtype == MRL_OB_U8, src) != 0 && !tuned(lj, "wgrad");
-        const bool dg_ok = j == 0 || (ldsdgrad_kind(lj, nw.dz[j]) != 0 && !tuned(lj, "dgrad"));
-        defer[j] = lj.act == ACT_RELU && wg_ok && dg_ok;
-    }
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
         const float* dz = nw.dz[i];
-        const float* hcur = defer[i] ? nw.h[i] : nullptr;            // mask-in source for this layer's consumers
-        const float* hmask = (i > 0 && defer[i - 1]) ? nullptr : hprev_of(nw, i);   // mask-out source (nullptr: deferred)
+        const float* hmask = hprev_of(nw, i);                        // act' source of the layer below
         const float* hprev = i ? nw.h[i - 1] : nullptr;
         const long rows = layer_rows(l, B);
         const bool first = (i == 0);
@@ -1159,7 +1132,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
             nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;
-            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, hcur, B, ws.part, nblocks, st);
+            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, nullptr, B, ws.part, nblocks, st);
             if (rc) return rc;
             rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st);
             if (rc) return rc;
@@ -1218,23 +1191,17 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     ProfScope ps(label, fl, 0.0, st);
                     hipError_t e;
                     const float* wsrc = params + l.w_off;
-                    const int stg = get_option("dgrad_stagger", "MRL_DGRAD_STAGGER", 0);   // start-phase spread (cycles)
                     // MRL_DGRAD_DBG=<layer index>: phase timestamps of workgroup 0 land behind the zero page
                     long long* dbgp = get_option("dgrad_dbg", "MRL_DGRAD_DBG", 0) == i ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
-                    // 16 waves x 1 row tile, groups of 5 / 6 images (measured alternatives in profiles/README.md:
-                    // 8 waves x 2 tiles and two half-size workgroups per CU are slower)
-                    const int cfg = get_option("dgrad_cfg", "MRL_DGRAD_CFG", 0);
-                    // asynchronous variant (LDS-DMA staging, mask prefetch) where it measures faster: conv2 (4 taps per
-                    // class: the memory phases are a third of a group) 9.05 -> 8.7 ms; conv3 (9 taps) 6.6 -> 6.9 ms, stays
-                    // on the synchronous kernel
-                    if (cfg == 0 && lk == 1 && !hcur && hmask) {
+                    // conv2 (4 taps per class: the memory phases are a third of a group): asynchronous variant (LDS-DMA
+                    // staging, mask prefetch) 9.05 -> 8.7 ms; conv3 (9 taps): 6.6 -> 6.9 ms, stays on the synchronous kernel
+                    // (16 waves x 1 row tile, groups of 6 images; 8 x 2 and two half-size workgroups per CU are slower)
+                    if (lk == 1 && get_option("dgrad_async", "MRL_DGRAD_ASYNC", 1))
                         e = launch_lds_dgrad_async<20, 20, 32, 4, 2, 64, 5, 8, 2>(dz, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), dbgp, st);
-                    } else
-                    if (lk == 1 && cfg == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 2, 8, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, 2 * num_cus(), stg, dbgp, st);
-                    else if (lk == 1 && cfg == 2) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 8, 2, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
+                    else if (lk == 1)
+                        e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1>(dz, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), dbgp, st);
                     else
-                    if (lk == 1) e = launch_lds_dgrad<20, 20, 32, 4, 2, 64, 5, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
-                    else e = launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1, 0>(dz, hcur, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), stg, dbgp, st);
+                        e = launch_lds_dgrad<9, 9, 64, 3, 1, 64, 6, 16, 1>(dz, wsrc, hmask, nw.dz[i - 1], lp.act, B, num_cus(), dbgp, st);
                     rc = (int)e;
                 } else
                 if (dv >= V_WRES16 && wok) {

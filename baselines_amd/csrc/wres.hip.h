@@ -429,37 +429,11 @@ inline hipError_t launch_wres_u8x3(const WresFwdA<true>& al, const float* w, con
 }
 
 // ------------------------------------------------------------------------------------------
-// fp32 conv forward on the BF16 matrix pipe ("bf16 x 6"): both operands are split EXACTLY into three bf16 planes
-//   x = x0 + x1 + x2,  w = w0 + w1 + w2   (8 + 8 + 8 significant bits, truncation split: every residual is exact)
-// and the product keeps the six terms down to 2^-16 relative: x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0); the
-// dropped terms (x1w2, x2w1, x2w2) are <= 2^-23 of the product, i.e. below the rounding of one fp32 multiply, and
-// every kept bf16 product is exact in the fp32 accumulator.  fp32-class accuracy (parity tests unchanged; not the
-// bitwise fmaf chain of the fp32 MFMA) at 6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) per 16 k instead of 8
-// v_mfma_f32_32x32x2_f32 (64 cycles): 2.7x less matrix time.
-// Structure = wres_kernel: filter planes resident in LDS (3 planes x 32 columns: a workgroup owns ONE 32-column
-// half of the layer, the two halves of a tile run on the same XCD and share its L2), A fragments global -> VGPR
-// (8 consecutive k per lane), split per lane on the VALU, no barrier in the main loop.
+// Exact 3-way bf16 split of fp32 values (used by the bf16 x 6 engine, gemmx6.hip.h): x = x0 + x1 + x2 with 8 + 8 + 8
+// significant bits; truncation split, every residual is exact.  Two floats -> three packed bf16 pairs (plane 0/1/2).
+// (A weights-resident bf16 x 6 forward built on per-lane global -> VGPR fragments was measured TA/L1-bound -- each
+// 16-byte-per-lane gather is 64 cache-line lookups -- and is not kept: profiles/README.md.)
 // ------------------------------------------------------------------------------------------
-struct WresFwdA8 : ConvGeom {        // fp32 activations, lane (i, g) holds k = 16*blk + 8g .. +7 of its row
-    struct RowState { long base; long koff; int kr; const float* g; };
-    __device__ __forceinline__ void row_init(RowState& s, long tile, int i, int h) const {
-        int m = (int)min(tile * 32 + i, (long)npix - 1);
-        const int ohw = OH * OW;
-        int b = (int)d_ohw.div((uint32_t)m), r = m - b * ohw;
-        int oy = (int)d_ow.div((uint32_t)r), ox = r - oy * OW;
-        long img = srow ? (long)srow[b] : (long)b;
-        s.base = ((img * H + oy * stride) * W + ox * stride) * C + h * 8;
-        s.koff = 0;
-        s.kr = 0;
-    }
-    template <int PF> __device__ __forceinline__ void prep_group(RowState& s) const {
-        s.g = static_cast<const float*>(p) + s.base + s.koff + s.kr;
-        s.kr += 16 * PF;
-        if (s.kr >= rowk) { s.kr = 0; s.koff += (long)W * C; }
-    }
-};
-
-// two floats -> three packed bf16 pairs (plane 0/1/2), exact truncation split
 __device__ __forceinline__ void split2_bf16x3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
     const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     p0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
@@ -468,132 +442,6 @@ __device__ __forceinline__ void split2_bf16x3(float x0, float x1, uint32_t& p0, 
     p1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
     const float l0 = r0 - __uint_as_float(v0 & 0xffff0000u), l1 = r1 - __uint_as_float(v1 & 0xffff0000u);
     p2 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
-}
-
-template <class EF, int PF, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void wres_f32x6_kernel(WresFwdA8 al, const float* __restrict__ w, EF ef,
-                                                                int K, int N, long total_tiles) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t wp[];     // [3][32][KP] bf16 planes, KP = K + 8
-    const int KP = K + 8;
-    const int tid = threadIdx.x;
-    const int NH = (N + 31) / 32;                                      // 32-column halves
-    // block id -> (xcd, half, slot): the NH workgroups that walk the same tiles sit on one XCD (shared L2)
-    const int xcd = blockIdx.x % 8, rest = blockIdx.x / 8;
-    const int half = rest % NH, widx = (rest / NH) * 8 + xcd, nw = gridDim.x / NH;
-    const int col0 = half * 32;
-    for (int e = tid; e < 3 * 32 * KP; e += WAVES * 64) wp[e] = 0;
-    __syncthreads();
-    for (int e = tid; e < K * 32; e += WAVES * 64) {
-        const int k = e >> 5, n = e & 31;
-        if (col0 + n < N) {
-            const float v = w[(long)k * N + col0 + n];
-            const uint32_t u = __float_as_uint(v);
-            const float r1 = v - __uint_as_float(u & 0xffff0000u);
-            const uint32_t u1 = __float_as_uint(r1);
-            const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-            wp[(0 * 32 + n) * KP + k] = (uint16_t)(u >> 16);
-            wp[(1 * 32 + n) * KP + k] = (uint16_t)(u1 >> 16);
-            wp[(2 * 32 + n) * KP + k] = (uint16_t)(__float_as_uint(r2) >> 16);
-        }
-    }
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const long stride_t = (long)nw * WAVES;
-    long tile = (long)widx * WAVES + wave;
-    if (tile >= total_tiles) return;
-    const int NG = K / (16 * PF);
-
-    WresFwdA8::RowState rs;
-    float4 fr[PF][2];
-    al.row_init(rs, tile, i, h);
-    al.template prep_group<PF>(rs);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        fr[u][0] = *reinterpret_cast<const float4*>(rs.g + u * 16);
-        fr[u][1] = *reinterpret_cast<const float4*>(rs.g + u * 16 + 4);
-    }
-    const uint16_t* wrow = wp + (long)i * KP + 8 * h;                  // + plane*32*KP + blk*16
-
-    auto body = [&](const WresFwdA8::RowState& src, int blk0, f32x16& acc) {
-        float4 fn[PF][2];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            fn[u][0] = *reinterpret_cast<const float4*>(src.g + u * 16);
-            fn[u][1] = *reinterpret_cast<const float4*>(src.g + u * 16 + 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            U32x4 a0, a1, a2;
-            split2_bf16x3(fr[u][0].x, fr[u][0].y, a0.x, a1.x, a2.x);
-            split2_bf16x3(fr[u][0].z, fr[u][0].w, a0.y, a1.y, a2.y);
-            split2_bf16x3(fr[u][1].x, fr[u][1].y, a0.z, a1.z, a2.z);
-            split2_bf16x3(fr[u][1].z, fr[u][1].w, a0.w, a1.w, a2.w);
-            const bf16x8 x0 = __builtin_bit_cast(bf16x8, a0), x1 = __builtin_bit_cast(bf16x8, a1),
-                         x2 = __builtin_bit_cast(bf16x8, a2);
-            const uint16_t* wb = wrow + (blk0 + u) * 16;
-            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wb);
-            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wb + (long)32 * KP);
-            const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wb + (long)64 * KP);
-            // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, w2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, w1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, w0, acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { fr[u][0] = fn[u][0]; fr[u][1] = fn[u][1]; }
-    };
-
-    while (true) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int g = 0; g + 1 < NG; ++g) {
-            al.template prep_group<PF>(rs);
-            body(rs, g * PF, acc);
-        }
-        const long next = tile + stride_t;
-        WresFwdA8::RowState rn;
-        al.row_init(rn, min(next, total_tiles - 1), i, h);
-        al.template prep_group<PF>(rn);
-        body(rn, (NG - 1) * PF, acc);
-        long o[16];
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = ef.addr(tile, 0, (r & 3) + 8 * (r >> 2) + 4 * h, col0 + i);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = ef.aux(o[r] < 0 ? 0 : o[r], col0 + i);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (o[r] >= 0) ef.put(o[r], acc[r], x[r]);
-        if (next >= total_tiles) break;
-        rs = rn;
-        tile = next;
-    }
-}
-
-inline size_t wres_f32x6_lds_bytes(int K) { return (size_t)3 * 32 * (K + 8) * sizeof(uint16_t); }
-
-template <class EF, int PF, int WAVES>
-inline hipError_t launch_wres_f32x6(const WresFwdA8& al, const float* w, const EF& ef, int K, int N, long total_tiles,
-                                    int num_cus, hipStream_t stream) {
-    const size_t lds = wres_f32x6_lds_bytes(K);
-    auto kern = wres_f32x6_kernel<EF, PF, WAVES>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
-    const int NH = (N + 31) / 32;
-    int grid = std::max(num_cus / (8 * NH), 1) * 8 * NH;               // multiple of 8*NH (XCD decode)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, al, w, ef, K, N, total_tiles);
-    return hipGetLastError();
 }
 
 inline int wres_kp(int K) { return (K + 63) / 64 * 64 + 4; }

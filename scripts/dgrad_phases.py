@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Phase timestamps of the LDS-resident data-gradient kernel (MRL_DGRAD_DBG=<layer index 1|2>), workgroup 0,
+"""Phase timestamps of the LDS-resident data-gradient kernels (MRL_DGRAD_DBG=<layer index 1|2>; conv2 runs the
+asynchronous variant unless MRL_DGRAD_ASYNC=0), workgroup 0,
 first and last wave, first 6 image groups.   python scripts/dgrad_phases.py [num_envs]"""
 import os
 import sys
@@ -31,7 +32,7 @@ for it in range(2):
 torch.cuda.synchronize()
 ws = model.dm.workspace
 st = ws[-2048 + 512:-2048 + 512 + 96 * 8].view(torch.int64).cpu().numpy().reshape(2, 6, 8)
-names = (['offsets', 'dma-wait+barrier', 'masks+MFMA', 'stores', 'barrier', 'dma-issue'] if os.environ.get('MRL_DGRAD_CFG', '0') == '0'
+names = (['offsets', 'dma-wait+barrier', 'masks+MFMA', 'stores', 'barrier', 'dma-issue'] if os.environ.get('MRL_DGRAD_ASYNC', '1') != '0' and os.environ.get('MRL_DGRAD_DBG') == '1'
          else ['wait prev (barrier)', 'stage', 'barrier', 'MFMA stream', 'epi loads issued', 'epi stores issued'])
 for w, wn in enumerate(('wave 0', 'last wave')):
     print(wn)
