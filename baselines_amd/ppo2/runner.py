@@ -14,10 +14,12 @@ when the caller wants them (`return_host=True`, default for host environments); 
 `return_host=False` it returns `RolloutField` handles that behave like those arrays under
 `arr[mbinds]` but gather on the device.
 """
+import os
+
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..common.runners import AbstractEnvRunner
 
 
@@ -88,9 +90,12 @@ class Runner(AbstractEnvRunner):
         self._dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=self.device)
         self._bridge = hasattr(env, 'obs_to_device')     # unwrapped ShmemVecEnv: observations already sit in a staging slot
         self._ob_np = ob_np
+        self._graph, self._graph_out, self._eager_rollouts = None, None, 0
 
     # ------------------------------------------------------------------
-    def _run_device_env(self, ro):
+    def _rollout_steps(self, ro):
+        """the T act + env steps of one rollout, all on the device, written straight into the HBM rollout
+        -> (last_values [N], fin_r [T, N], fin_l [T, N])"""
         T = self.nsteps
         fin_r, fin_l = [], []
         ro.obs[0].copy_(self.obs)                      # cursor -> slot 0
@@ -104,15 +109,51 @@ class Runner(AbstractEnvRunner):
             fin_r.append(info['fin_r'])
             fin_l.append(info['fin_l'])
         self.obs = nxt_last
-        last_values = self.model.value_dev(self.obs)
-        epinfos = []
-        fl = torch.stack(fin_l)
+        return self.model.value_dev(self.obs), torch.stack(fin_r), torch.stack(fin_l)
+
+    def _graphable(self):
+        """A rollout is one static launch sequence when both sides are ours: the stock Model (its noise comes from a
+        torch generator that can be registered with the graph) and the stock device env (its state lives in device
+        arrays).  Wrappers, subclasses and teacher-forced test models keep the eager loop."""
+        from .model import Model
+        from ..common.vec_env.synthetic_vec_env import SyntheticVecEnv
+        return (type(self.model) is Model and type(self.env) is SyntheticVecEnv and not _lib.prof_enabled()
+                and os.environ.get('MRL_ROLLOUT_GRAPH', '1') != '0' and self._graph is not False)
+
+    def _run_device_env(self, ro):
+        """The whole rollout (T x ~12 small launches) is captured once as a hipGraph and replayed per update: every
+        buffer it touches is static (rollout SoA, observation cursor, env state, parameters updated in place)."""
+        if self._graphable():
+            if self._graph is None and self._eager_rollouts >= 1:        # capture after one eager warm-up rollout
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    g.register_generator_state(self.model._gen)
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g):
+                        out = self._rollout_steps(ro)
+                    self._graph, self._graph_out = g, out
+                except Exception as exc:                                    # capture unsupported here: stay eager
+                    import warnings
+                    warnings.warn('rollout graph capture failed (%s); using the step loop' % (exc,))
+                    self._graph = False
+                    torch.cuda.synchronize()
+                    return self._run_device_env(ro)
+            if self._graph:
+                self._graph.replay()
+                last_values, fr, fl = self._graph_out
+                return last_values, self._epinfos(fr, fl)
+        self._eager_rollouts += 1
+        last_values, fr, fl = self._rollout_steps(ro)
+        return last_values, self._epinfos(fr, fl)
+
+    @staticmethod
+    def _epinfos(fr, fl):
         mask = fl > 0
-        if bool(mask.any()):                           # one host sync per rollout, not per step
-            rs = torch.stack(fin_r)[mask].cpu().numpy()
-            ls = fl[mask].cpu().numpy()
-            epinfos = [{'r': float(r), 'l': int(l)} for r, l in zip(rs, ls)]
-        return last_values, epinfos
+        if not bool(mask.any()):                       # one host sync per rollout, not per step
+            return []
+        rs = fr[mask].cpu().numpy()
+        ls = fl[mask].cpu().numpy()
+        return [{'r': float(r), 'l': int(l)} for r, l in zip(rs, ls)]
 
     def _run_host_env(self, ro):
         T = self.nsteps

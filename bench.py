@@ -161,7 +161,10 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    # one full iteration fills the rollout (and gives the "full iteration" figure)
+    # rollouts fill the HBM rollout buffer and give the "full iteration" figure: the first one runs the step loop, the
+    # second captures the rollout as a hipGraph (Runner._run_device_env), the third -- the timed one -- replays it
+    for _ in range(2):
+        runner.run()
     sync()
     t0 = time.perf_counter()
     runner.run()

@@ -244,3 +244,40 @@ def test_epoch_graph_replay_equals_step_loop(kind, monkeypatch):
     np.testing.assert_array_equal(eager.get_flat_params(), graphed.get_flat_params())
     np.testing.assert_array_equal(eager.adam_v.cpu().numpy(), graphed.adam_v.cpu().numpy())
     assert eager.beta1_power == graphed.beta1_power and eager._train_calls == graphed._train_calls == 36
+
+
+@pytest.mark.parametrize('kind', ['cartpole', 'atari'])
+def test_rollout_graph_replay_equals_step_loop(kind, monkeypatch):
+    """Runner: the rollout replayed as one hipGraph (policy noise from the registered torch generator, env state in device
+    arrays) fills the HBM rollout exactly like the step loop -- compared over 3 updates of learn()."""
+    from baselines_amd import ppo2
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
+    net = 'cnn' if kind == 'atari' else 'mlp'
+    N, T = (4, 8) if kind == 'atari' else (16, 32)
+
+    def run(flag):
+        monkeypatch.setenv('MRL_ROLLOUT_GRAPH', flag)
+        got = {}
+
+        def grab(update):
+            got[update] = {k: getattr(runner_ref[0].rollout, k).cpu().numpy().copy() for k in
+                           ('obs', 'actions', 'values', 'neglogpacs', 'rewards', 'dones', 'returns')}
+        runner_ref = []
+        orig = ppo2.ppo2.Runner
+
+        class Spy(orig):
+            def __init__(self, **kw):
+                super().__init__(**kw)
+                runner_ref.append(self)
+        monkeypatch.setattr(ppo2.ppo2, 'Runner', Spy)
+        model = ppo2.learn(network=net, env=SyntheticVecEnv(kind, N, seed=4), total_timesteps=3 * N * T, seed=1, nsteps=T,
+                           nminibatches=2, noptepochs=2, log_interval=100, update_fn=grab)
+        monkeypatch.setattr(ppo2.ppo2, 'Runner', orig)
+        return model, got, runner_ref[0]
+    m0, r0, run0 = run('0')
+    m1, r1, run1 = run('1')
+    assert run0._graph is None and run1._graph not in (None, False)
+    for u in (1, 2, 3):
+        for k in r0[u]:
+            np.testing.assert_array_equal(r0[u][k], r1[u][k], err_msg='update %d field %s' % (u, k))
+    np.testing.assert_array_equal(m0.get_flat_params(), m1.get_flat_params())
