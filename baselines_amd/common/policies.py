@@ -21,8 +21,16 @@ class PolicySpec(object):
             self.pd_kind, self.nact = 'gaussian', int(ac_space.shape[0])
         else:
             raise NotImplementedError('action space {} is outside the supported hot path'.format(ac_space))
-        self.ob_shape = tuple(ob_space.shape)
-        self.ob_dtype = np.dtype(ob_space.dtype)
+        # common/input.py:43-63 encode_observation: Discrete observations become one-hot float32 rows (the device model
+        # then sees a Box of n floats); Box observations pass through (uint8 pixels are scaled inside the first conv layer)
+        self.ob_onehot = int(ob_space.n) if is_discrete(ob_space) else 0
+        if self.ob_onehot:
+            self.ob_shape, self.ob_dtype = (self.ob_onehot,), np.dtype(np.float32)
+        elif is_box(ob_space):
+            self.ob_shape = tuple(ob_space.shape)
+            self.ob_dtype = np.dtype(ob_space.dtype)
+        else:
+            raise NotImplementedError('observation space {} is outside the supported hot path'.format(ob_space))
 
     def device_model_kwargs(self):
         kw = dict(network=self.network.kind, ob_shape=self.ob_shape, ob_dtype=self.ob_dtype, pd_kind=self.pd_kind,

@@ -96,6 +96,11 @@ class Model(object):
 
     # ------------------------------------------------------------------ act side
     def _to_dev_obs(self, obs):
+        if self.policy.ob_onehot:                   # Discrete observations: tf.one_hot of input.py:57-58
+            t = obs.to(self.device) if isinstance(obs, torch.Tensor) else torch.from_numpy(np.asarray(obs)).to(self.device)
+            if t.dim() < 2 or t.shape[-1] != self.policy.ob_onehot or not t.is_floating_point():
+                t = torch.nn.functional.one_hot(t.reshape(-1).long(), self.policy.ob_onehot)
+            return t.to(torch.float32).reshape(-1, self.policy.ob_onehot).contiguous()
         if isinstance(obs, torch.Tensor):
             t = obs.to(self.device)
         else:

@@ -79,12 +79,18 @@ class Runner(AbstractEnvRunner):
         ob_space = env.observation_space
         ob_np = np.dtype(ob_space.dtype)
         ob_t = torch.uint8 if ob_np in (np.dtype(np.uint8), np.dtype(np.int8)) else torch.float32
+        # Discrete observations live in the HBM rollout in their encoded (one-hot float32) form; `run()` hands that form
+        # back (the reference returns the raw integers -- its own train() re-encodes them; ours accepts both)
+        self._onehot = int(getattr(getattr(model, 'policy', None), 'ob_onehot', 0) or 0)
+        ob_shape = (self._onehot,) if self._onehot else ob_space.shape
+        if self._onehot:
+            ob_np, ob_t = np.dtype(np.float32), torch.float32
         pd_kind = getattr(model, 'pd_kind', None)
         if pd_kind is None:
             pd_kind = 'categorical' if type(env.action_space).__name__ == 'Discrete' else 'gaussian'
         nact = getattr(model, 'nact', None) or (env.action_space.n if pd_kind == 'categorical'
                                                 else env.action_space.shape[0])
-        self.rollout = Rollout(nsteps, self.nenv, ob_space.shape, ob_t, pd_kind, nact, self.device)
+        self.rollout = Rollout(nsteps, self.nenv, ob_shape, ob_t, pd_kind, nact, self.device)
         self.return_host = (not self.device_env) if return_host is None else return_host
         self.fast_step = hasattr(model, 'step_into')
         self._dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=self.device)
@@ -164,6 +170,8 @@ class Runner(AbstractEnvRunner):
             if self._bridge:
                 # host-env bridge (ShmemVecEnv): asynchronous DMA from the page-locked staging slot the workers wrote
                 self.env.obs_to_device(ro.obs[t])
+            elif self._onehot:
+                ro.obs[t].copy_(self.model._to_dev_obs(self.obs))
             else:
                 obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
                 ro.obs[t].copy_(torch.from_numpy(obs_np))      # runner.py:30 snapshot, straight into HBM
@@ -187,7 +195,9 @@ class Runner(AbstractEnvRunner):
         ro.rewards.copy_(torch.from_numpy(rewards_host))
         ro.dones.copy_(torch.from_numpy(dones_host.view(np.uint8)))
         self._dones_dev.copy_(torch.from_numpy(np.asarray(self.dones, np.bool_).view(np.uint8)))
-        if hasattr(self.model, 'value_dev'):
+        if hasattr(self.model, 'value_dev') and self._onehot:
+            last_values = self.model.value_dev(self.model._to_dev_obs(self.obs))
+        elif hasattr(self.model, 'value_dev'):
             obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
             last_values = self.model.value_dev(torch.from_numpy(obs_np).to(self.device))
         else:

@@ -3,6 +3,7 @@ TEST INFRASTRUCTURE ONLY.  Golden vectors for the actor-side wrappers (SURVEY.md
 REFERENCE's own classes (imported from /root/reference, never copied):
   * baselines.common.vec_env.vec_frame_stack.VecFrameStack   (np.roll shift, zero on done, newest frame last)
   * baselines.common.vec_env.vec_normalize.VecNormalize + running_mean_std.RunningMeanStd (use_tf=False)
+  * baselines.common.vec_env.vec_monitor.VecMonitor + bench.monitor.ResultsWriter (episode records, monitor.csv)
 `gym` and `tensorflow` are not installed here: minimal stub modules are injected (only attribute containers --
 no arithmetic of the wrappers lives in them).   Run:  python oracle/make_golden_wrappers.py
 """
@@ -115,6 +116,33 @@ def main():
         out[tag + '_ob_mean'], out[tag + '_ob_var'], out[tag + '_ob_count'] = vn.ob_rms.mean, vn.ob_rms.var, vn.ob_rms.count
         out[tag + '_ret_mean'], out[tag + '_ret_var'], out[tag + '_ret_count'] = vn.ret_rms.mean, vn.ret_rms.var, vn.ret_rms.count
         out[tag + '_ret'] = vn.ret
+    # ---- VecMonitor (+ its monitor.csv writer): episode records and the csv text, wall-clock column masked
+    import tempfile
+    from baselines.common.vec_env.vec_monitor import VecMonitor
+    rng = np.random.RandomState(11)
+    N, steps = 5, 40
+    rews = (rng.randn(steps + 1, N) * 2).astype(np.float32)
+    dones = rng.rand(steps + 1, N) < 0.2
+    obs = rng.randn(steps + 1, N, 3).astype(np.float32)
+    space = Box(low=-np.ones(3, np.float32), high=np.ones(3, np.float32), dtype=np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        vm = VecMonitor(FakeVenv(space, obs, rews, dones), filename=os.path.join(tmp, 'run'), keep_buf=7)
+        vm.reset()
+        recs = []
+        for t in range(1, steps + 1):
+            _, _, d, infos = vm.step_wait()
+            for e in range(N):
+                if d[e]:
+                    recs.append((t, e, infos[e]['episode']['r'], infos[e]['episode']['l']))
+                else:
+                    assert 'episode' not in infos[e]
+        vm.results_writer.f.close()
+        text = open(os.path.join(tmp, 'run.monitor.csv')).read().splitlines()
+    out['vm_in_rews'], out['vm_in_dones'], out['vm_in_obs'] = rews, dones, obs
+    out['vm_records'] = np.array(recs, dtype=np.float64)             # (step, env, r as f32 value, l)
+    out['vm_csv_rl'] = np.array([ln.rsplit(',', 1)[0] for ln in text[2:]])     # "r,l" of every row, 't' dropped
+    out['vm_csv_header'] = np.array(text[1])
+    out['vm_keep_r'], out['vm_keep_l'] = np.array(vm.epret_buf, np.float64), np.array(vm.eplen_buf, np.int64)
     np.savez_compressed(os.path.join(OUT, 'wrappers.npz'), **out)
     print('written', os.path.join(OUT, 'wrappers.npz'), {k: (v.shape, v.dtype) for k, v in out.items() if hasattr(v, 'shape')})
 
