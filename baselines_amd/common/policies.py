@@ -24,6 +24,7 @@ class PolicySpec(object):
         # common/input.py:43-63 encode_observation: Discrete observations become one-hot float32 rows (the device model
         # then sees a Box of n floats); Box observations pass through (uint8 pixels are scaled inside the first conv layer)
         self.ob_onehot = int(ob_space.n) if is_discrete(ob_space) else 0
+        self.ob_clip = None                 # set by build_policy(normalize_observations=True)
         if self.ob_onehot:
             self.ob_shape, self.ob_dtype = (self.ob_onehot,), np.dtype(np.float32)
         elif is_box(ob_space):
@@ -41,10 +42,18 @@ class PolicySpec(object):
 
 def build_policy(env, policy_network, value_network=None, normalize_observations=False, estimate_q=False,
                  **policy_kwargs):
-    if normalize_observations or estimate_q:
-        raise NotImplementedError('normalize_observations / estimate_q are outside the PPO2 hot path')
+    if estimate_q:
+        raise NotImplementedError('estimate_q (Q-value heads) is outside the PPO2 hot path')
     if isinstance(policy_network, str):
         policy_network = get_network_builder(policy_network)(**policy_kwargs)
     if not isinstance(policy_network, NetworkDesc):
         raise NotImplementedError('custom TF network functions cannot run on the HIP path; register a NetworkDesc')
-    return PolicySpec(env.observation_space, env.action_space, policy_network, value_network)
+    spec = PolicySpec(env.observation_space, env.action_space, policy_network, value_network)
+    if normalize_observations:
+        # policies.py:133-135,182-185: clip((x - rms.mean) / rms.std, -5, 5) with a RunningMeanStd that ppo2 never
+        # updates (only trpo_mpi / ppo1 call rms.update): mean stays 0 and std 1, i.e. the observation is clipped to
+        # [-5, 5].  Float Box observations only, like the reference (`X.dtype == tf.float32`).
+        if spec.ob_dtype != np.dtype(np.float32) or spec.ob_onehot:
+            raise NotImplementedError('normalize_observations applies to float32 Box observations')
+        spec.ob_clip = 5.0
+    return spec

@@ -110,6 +110,8 @@ class Model(object):
             t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         if t.dtype != self.dm.torch_ob_dtype:
             t = t.to(self.dm.torch_ob_dtype)
+        if self.policy.ob_clip:                     # normalize_observations: see build_policy
+            t = t.clamp(-self.policy.ob_clip, self.policy.ob_clip)
         # tf_util.adjust_shape (tf_util.py:377-401): anything reshapeable to [-1, *ob_shape] is accepted
         return t.reshape((-1,) + tuple(self.policy.ob_shape)).contiguous()
 
@@ -146,6 +148,8 @@ class Model(object):
         return self.dm.act(self.params, obs, None, want_actions=False)[1].cpu().numpy()
 
     def value_dev(self, obs_dev):
+        if self.policy.ob_clip:
+            obs_dev = obs_dev.clamp(-self.policy.ob_clip, self.policy.ob_clip)
         return self.dm.act(self.params, obs_dev, None, want_actions=False)[1]
 
     # ------------------------------------------------------------------ learner

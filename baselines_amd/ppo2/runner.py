@@ -97,6 +97,7 @@ class Runner(AbstractEnvRunner):
         self._bridge = hasattr(env, 'obs_to_device')     # unwrapped ShmemVecEnv: observations already sit in a staging slot
         self._ob_np = ob_np
         self._graph, self._graph_out, self._eager_rollouts = None, None, 0
+        self._ob_clip = getattr(getattr(model, 'policy', None), 'ob_clip', None)
 
     # ------------------------------------------------------------------
     def _rollout_steps(self, ro):
@@ -107,6 +108,8 @@ class Runner(AbstractEnvRunner):
         ro.obs[0].copy_(self.obs)                      # cursor -> slot 0
         nxt_last = self.obs                            # reused as the landing buffer of the last step
         for t in range(T):
+            if self._ob_clip:                          # normalize_observations: the rollout holds the clipped observations
+                ro.obs[t].clamp_(-self._ob_clip, self._ob_clip)
             self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
             ro.dones[t].copy_(self._dones_dev)
             obs_out = ro.obs[t + 1] if t + 1 < T else nxt_last
@@ -175,6 +178,8 @@ class Runner(AbstractEnvRunner):
             else:
                 obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
                 ro.obs[t].copy_(torch.from_numpy(obs_np))      # runner.py:30 snapshot, straight into HBM
+            if self._ob_clip:
+                ro.obs[t].clamp_(-self._ob_clip, self._ob_clip)
             if self.fast_step:
                 self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
                 actions = ro.actions[t].cpu().numpy()

@@ -281,3 +281,30 @@ def test_rollout_graph_replay_equals_step_loop(kind, monkeypatch):
         for k in r0[u]:
             np.testing.assert_array_equal(r0[u][k], r1[u][k], err_msg='update %d field %s' % (u, k))
     np.testing.assert_array_equal(m0.get_flat_params(), m1.get_flat_params())
+
+
+def test_normalize_observations_is_the_references_clip():
+    """build_policy(normalize_observations=True) under ppo2 (policies.py:133-135,182-185 with a never-updated
+    RunningMeanStd): observations are clipped to [-5, 5] on both the act and the train side."""
+    from baselines_amd import ppo2
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
+
+    class Wide(SyntheticVecEnv):                     # observations scaled to +-20 so that the clip matters
+        def reset(self, out=None):
+            o = super().reset(out)
+            return o.mul_(20.0)
+
+        def step_into(self, actions, obs_out=None, rew_out=None, done_out=None):
+            o, r, d, i = super().step_into(actions, obs_out=obs_out, rew_out=rew_out, done_out=done_out)
+            o.mul_(20.0)
+            return o, r, d, i
+    m = ppo2.learn(network='mlp', env=Wide('mujoco', 8, seed=2), total_timesteps=2 * 8 * 16, seed=0, nsteps=16, nminibatches=2,
+                   noptepochs=1, value_network='copy', normalize_observations=True, log_interval=100)
+    x = (np.random.RandomState(0).randn(4, 376) * 20).astype(np.float32)
+    noise = np.random.RandomState(1).randn(4, 17).astype(np.float32)
+    a1, v1, _, n1 = m.step(x, noise=noise)
+    a2, v2, _, n2 = m.step(np.clip(x, -5, 5), noise=noise)
+    np.testing.assert_array_equal(a1, a2)
+    np.testing.assert_array_equal(v1, v2)
+    np.testing.assert_array_equal(m.value(x), m.value(np.clip(x, -5, 5)))
+    assert np.isfinite(m.get_flat_params()).all()
