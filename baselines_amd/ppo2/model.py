@@ -237,7 +237,8 @@ class Model(object):
         per-kernel profiling use the plain step loop."""
         B = self.nbatch_train
         M = inds_dev.numel() // B
-        graphable = (not self.multi and self.dm.network == 'mlp' and self._train_calls > 0 and not _lib.prof_enabled()
+        graphable = (self._epoch_graph is not False and not self.multi and self.dm.network == 'mlp'
+                     and self._train_calls > 0 and not _lib.prof_enabled()
                      and type(self).train_indexed is Model.train_indexed          # subclasses that hook the step keep it
                      and os.environ.get('MRL_EPOCH_GRAPH', '1') != '0')
         if not graphable:
@@ -245,7 +246,14 @@ class Model(object):
         key = (float(lr), float(cliprange), rollout.obs.data_ptr(), rollout.returns.data_ptr(), rollout.values.data_ptr(), M, B)
         g = self._epoch_graph
         if g is None or g['key'] != key:
-            g = self._epoch_graph = self._capture_epoch(key, cliprange, rollout, M, B)
+            try:
+                g = self._epoch_graph = self._capture_epoch(key, cliprange, rollout, M, B)
+            except Exception as exc:                     # capture unsupported here: keep the step loop from now on
+                import warnings
+                warnings.warn('epoch graph capture failed (%s); using the step loop' % (exc,))
+                self._epoch_graph = False
+                torch.cuda.synchronize()
+                return self.train_epoch(lr, cliprange, rollout, inds_dev)
         g['idx'].copy_(inds_dev.view(M, B))
         g['alpha'].copy_(torch.from_numpy(np.array([self._next_alpha(lr) for _ in range(M)], dtype=np.float32)))
         g['graph'].replay()
