@@ -4,8 +4,8 @@
 //
 // Both operands are split EXACTLY into three bf16 planes, x = x0 + x1 + x2 (8 + 8 + 8 significant bits, truncation
 // split, every residual exact), and the six products down to 2^-16 relative are accumulated in fp32:
-//   x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0);   dropped: x1w2, x2w1, x2w2 <= 2^-23 of the product,
-// i.e. below the rounding of one fp32 multiply.  6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace
+//   x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0);   dropped: x1w2, x2w1, x2w2 < 2^-21 of the product worst case,
+// 4e-8 on average (twice the rounding of one fp32 multiply; tests/test_split_arithmetic.py).  6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace
 // 8 v_mfma_f32_32x32x2_f32 (64 cycles): 2.7x less matrix time.  Not the bitwise fmaf chain of the fp32 MFMA engines
 // (gemm.hip.h stays the reference path, MRL_F32_BF16X6=0 selects it); parity tests hold unchanged.
 //

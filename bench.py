@@ -270,7 +270,7 @@ def main():
                                      'data gradients: fp32 MFMA (bitwise fmaf chain). conv1 forward + weight gradient: exact uint8 '
                                      'pixels x 3-way exact bf16 split of the other operand on the bf16 pipe. conv2/conv3/fc1 forward '
                                      'and fc1 data gradient: both operands split exactly into 3 bf16 planes, the 6 products >= 2^-16 '
-                                     'kept (dropped terms < 2^-23 relative): fp32-class results, parity tests unchanged; '
+                                     'kept (dropped terms < 2^-21 of a product worst case, 4e-8 on average = 2x the rounding of one fp32 multiply): fp32-class results, parity tests unchanged; '
                                      'MRL_F32_BF16X6=0 / MRL_U8_BF16X3=0 select the all-fp32-MFMA paths',
                        'parallelism': 'dp%d (envs sharded, 1 RCCL all-reduce/minibatch)' % world},
             'model_tflops': flops_per_sample_visit * total_envs * T * hp['noptepochs'] * args.steps / dt / 1e12,

@@ -1,0 +1,86 @@
+"""CPU: the arithmetic claim behind the bf16 x 3 / bf16 x 6 engines, checked with a NumPy emulation of
+`split2_bf16x3` (csrc/wres.hip.h): the three planes are bf16-representable, their sum is the fp32 value EXACTLY, every
+kept plane product is exact in fp32, and the six-term product differs from the exact product by < 2^-21 relative in the
+worst case (|x1| < 2^-7 |x|, |x2| < 2^-15 |x|: the dropped x1w2 + x2w1 + x2w2 < 2^-22 + 2^-22 + 2^-30) and by ~4e-8 on average."""
+import numpy as np
+
+
+def split3(x):
+    x = np.asarray(x, np.float32)
+    u = x.view(np.uint32)
+    p0 = (u & np.uint32(0xffff0000)).view(np.float32)
+    r1 = x - p0
+    p1 = (r1.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    p2 = r1 - p1
+    return p0, p1, p2
+
+
+def _is_bf16(p):
+    return np.all((np.asarray(p, np.float32).view(np.uint32) & np.uint32(0xffff)) == 0)
+
+
+def _values(rng, n):
+    mags = np.exp(rng.uniform(np.log(1e-6), np.log(1e4), n))
+    x = (mags * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    x[:8] = [0.0, 1.0, -1.0, 255.0, 1.0 / 255.0, 3.0e38, -1.17549435e-38 * 4, 0.1]
+    return x
+
+
+def test_three_way_split_is_exact_and_bf16():
+    rng = np.random.RandomState(0)
+    x = _values(rng, 200000)
+    p0, p1, p2 = split3(x)
+    assert _is_bf16(p0) and _is_bf16(p1) and _is_bf16(p2)
+    # exact in any association: the planes do not overlap bit ranges
+    np.testing.assert_array_equal((p0.astype(np.float64) + p1.astype(np.float64) + p2.astype(np.float64)), x.astype(np.float64))
+    np.testing.assert_array_equal((p0 + p1) + p2, x)
+    assert np.all(np.abs(p1) < np.abs(p0) * 2.0 ** -7 + 1e-45) and np.all(np.abs(p2) < np.abs(p0) * 2.0 ** -15 + 1e-45)
+
+
+def test_u8_times_three_planes_is_exact():
+    """bf16 x 3 (first conv layer): integer pixels 0..255 are bf16 values; pixel * plane is exact in fp32"""
+    rng = np.random.RandomState(1)
+    w = _values(rng, 50000) / np.float32(255.0)
+    pix = rng.randint(0, 256, w.size).astype(np.float32)
+    for p in split3(w):
+        prod32 = pix * p
+        np.testing.assert_array_equal(prod32.astype(np.float64), pix.astype(np.float64) * p.astype(np.float64))
+
+
+def test_six_term_product_error_bound():
+    rng = np.random.RandomState(2)
+    a, b = _values(rng, 100000)[8:], _values(rng, 100000)[::-1][8:]
+    keep = (np.abs(a.astype(np.float64) * b) < 1e30) & (np.abs(a.astype(np.float64) * b) > 1e-30)
+    a, b = a[keep], b[keep]
+    a0, a1, a2 = (p.astype(np.float64) for p in split3(a))
+    b0, b1, b2 = (p.astype(np.float64) for p in split3(b))
+    for x, y in ((a0, b0), (a0, b1), (a1, b0), (a0, b2), (a1, b1), (a2, b0)):           # 8 x 8 significant bits: exact in fp32
+        np.testing.assert_array_equal((x * y).astype(np.float32).astype(np.float64), x * y)
+    six = a0 * b0 + (a0 * b1 + a1 * b0) + (a0 * b2 + a1 * b1 + a2 * b0)
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    rel = np.abs(six - exact) / np.abs(exact)
+    assert rel.max() < 2.0 ** -21, rel.max()                     # dropped: a1b2 + a2b1 + a2b2 < (2^-22 + 2^-22 + 2^-30)|ab|
+    assert rel.mean() < 6e-8                                     # ~2x the mean rounding error of one fp32 multiply (2.2e-8)
+    # for comparison: rounding the exact product to fp32 costs up to 2^-24
+    assert (np.abs(exact.astype(np.float32).astype(np.float64) - exact) / np.abs(exact)).max() <= 2.0 ** -24
+
+
+def test_split_dot_products_are_fp32_class():
+    """a 512-long dot product (conv2's K) through the six-term products with fp32 accumulation vs plain fp32 accumulation:
+    both sit within the same distance of the fp64 result"""
+    rng = np.random.RandomState(3)
+    A = rng.randn(256, 512).astype(np.float32)
+    B = (rng.randn(512, 64) * 0.05).astype(np.float32)
+    exact = A.astype(np.float64) @ B.astype(np.float64)
+    plain = np.zeros((256, 64), np.float32)
+    split = np.zeros((256, 64), np.float32)
+    a = split3(A)
+    b = split3(B)
+    for k0 in range(0, 512, 16):                                 # one MFMA k-block at a time, fp32 accumulator
+        sl = slice(k0, k0 + 16)
+        plain = plain + (A[:, sl].astype(np.float64) @ B[sl].astype(np.float64)).astype(np.float32)
+        for i, j in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)):          # the kernels' order: small terms first
+            split = split + (a[i][:, sl].astype(np.float64) @ b[j][sl].astype(np.float64)).astype(np.float32)
+    scale = np.abs(exact).max()
+    e_plain, e_split = np.abs(plain - exact).max() / scale, np.abs(split - exact).max() / scale
+    assert e_split < 2e-6 and e_split < 4 * e_plain + 1e-7, (e_plain, e_split)
