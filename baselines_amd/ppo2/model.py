@@ -268,7 +268,7 @@ class Model(object):
         P = self.params.numel()
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             st = _lib.stream_ptr()                         # the capturing stream
             for k in range(M):
                 _lib.check(lib.mrl_model_grad(self.dm.handle, _lib.ptr(self.params), _lib.ptr(rollout.obs),

@@ -123,10 +123,11 @@ class Runner(AbstractEnvRunner):
     def _graphable(self):
         """A rollout is one static launch sequence when both sides are ours: the stock Model (its noise comes from a
         torch generator that can be registered with the graph) and the stock device env (its state lives in device
-        arrays).  Wrappers, subclasses and teacher-forced test models keep the eager loop."""
+        arrays).  Wrappers, subclasses, teacher-forced test models and multi-rank runs (other threads of the
+        process talk to the runtime while we would be capturing) keep the eager loop."""
         from .model import Model
         from ..common.vec_env.synthetic_vec_env import SyntheticVecEnv
-        return (type(self.model) is Model and type(self.env) is SyntheticVecEnv and not _lib.prof_enabled()
+        return (type(self.model) is Model and not self.model.multi and type(self.env) is SyntheticVecEnv and not _lib.prof_enabled()
                 and os.environ.get('MRL_ROLLOUT_GRAPH', '1') != '0' and self._graph is not False)
 
     def _run_device_env(self, ro):
@@ -138,7 +139,7 @@ class Runner(AbstractEnvRunner):
                     g = torch.cuda.CUDAGraph()
                     g.register_generator_state(self.model._gen)
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
                         out = self._rollout_steps(ro)
                     self._graph, self._graph_out = g, out
                 except Exception as exc:                                    # capture unsupported here: stay eager
