@@ -7,7 +7,8 @@
 //   x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0);   dropped: x1w2, x2w1, x2w2 < 2^-21 of the product worst case,
 // 4e-8 on average (twice the rounding of one fp32 multiply; tests/test_split_arithmetic.py).  6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace
 // 8 v_mfma_f32_32x32x2_f32 (64 cycles): 2.7x less matrix time.  Not the bitwise fmaf chain of the fp32 MFMA engines
-// (gemm.hip.h stays the reference path, MRL_F32_BF16X6=0 selects it); parity tests hold unchanged.
+// (gemm.hip.h stays the reference path, MRL_F32_BF16X6=0 selects it; =2 keeps x1w2 and x2w1 too: 8 products, error
+// < 2^-29 per product, +15 % time); parity tests hold unchanged.
 //
 //   * B (the weight matrix, 1.6 M elements) is split and laid out [plane][n][k] ONCE per call by split_planes_kernel
 //     -- its staging is then a plain 16-byte copy;
@@ -73,7 +74,7 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 // at 2 waves per SIMD (-18 %); ONE workgroup per CU with double-buffered LDS, two register stages and the staging
 // code scheduled between the MFMAs (sched_group_barrier) is 25-45 % slower -- a lone wave per SIMD stalls the matrix
 // pipe at every LDS wait.
-template <class AF, class EF, int WM, int WN>
+template <class AF, class EF, int WM, int WN, bool X8>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
                                                       int mtiles, int ntiles, long long* dbg) {
     static_assert(WM * WN == 4, "4 waves");
@@ -168,6 +169,10 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {       // small terms first
+                    if (X8) {                       // the two 2^-22 terms: 8 products, dropped part < 2^-29 of a product
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][2], acc[a][b], 0, 0, 0);
+                    }
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
@@ -234,7 +239,7 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
     return hipGetLastError();
 }
 
-template <class AF, class EF, int WM, int WN>
+template <class AF, class EF, int WM, int WN, bool X8>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
                                      hipStream_t stream) {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -242,7 +247,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
     const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
-    auto kern = gemm_x6_kernel<AF, EF, WM, WN>;
+    auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8>;
     static bool raised = false;                // per instantiation
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -254,11 +259,15 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
 }
 template <class AF, class EF>
 inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream,
-                                 long long* dbg = nullptr) {
+                                 long long* dbg = nullptr, bool x8 = false) {
     if (M <= 0 || N <= 0) return hipSuccess;
     // 256 x 64 tiles for the 64-filter conv layers, 128 x 128 otherwise
-    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1>(af, Bp, ef, M, N, K, dbg, stream);
-    return launch_gemm_x6_cfg<AF, EF, 2, 2>(af, Bp, ef, M, N, K, dbg, stream);
+    if (x8) {          // MRL_F32_BF16X6=2: eight products per multiply (x1w2 and x2w1 kept too)
+        if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true>(af, Bp, ef, M, N, K, dbg, stream);
+        return launch_gemm_x6_cfg<AF, EF, 2, 2, true>(af, Bp, ef, M, N, K, dbg, stream);
+    }
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, false>(af, Bp, ef, M, N, K, dbg, stream);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2, false>(af, Bp, ef, M, N, K, dbg, stream);
 }
 
 }  // namespace mrl

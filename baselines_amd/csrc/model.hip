@@ -1047,7 +1047,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st);
                     if (e != hipSuccess) return (int)e;
                     EpiBiasAct efx{hout, l.NF, bias, l.act};
-                    return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st);
+                    return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st, nullptr, x6 == 2);
                 }
                 WresFwdA<false> wa;
                 fill_conv(wa, l, hprev, npix, nullptr);
@@ -1082,7 +1082,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 if (e != hipSuccess) return (int)e;
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
                 long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) ? dbgbuf : nullptr;
-                return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st, dbgp);
+                return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st, dbgp,
+                                           get_option("f32_bf16x6", "MRL_F32_BF16X6", 1) == 2);
             }
             RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K), nullptr};
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
@@ -1227,7 +1228,9 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
                 EpiMaskAct ef{nw.dz[i - 1], l.K, hmask, lp.act};
                 hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st);
-                if (e == hipSuccess) e = launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st);
+                if (e == hipSuccess)
+                    e = launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr,
+                                       get_option("f32_bf16x6", "MRL_F32_BF16X6", 1) == 2);
                 rc = (int)e;
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};

@@ -293,6 +293,10 @@ def test_engine_options_agree():
                 L.set_option(o, 1)                      # every case starts from the defaults
             g1, s1 = grads(net, shp, dt, pd, na, vc, B, opt, 1)
             g0, s0 = grads(net, shp, dt, pd, na, vc, B, opt, 0)
+            if opt == 'f32_bf16x6':                     # value 2: eight products per multiply (x1w2, x2w1 kept too)
+                g2, s2 = grads(net, shp, dt, pd, na, vc, B, opt, 2)
+                assert np.percentile(np.abs(g2 - g0), 99.0) <= 1e-5 * np.abs(g0).max() + 1e-9
+                np.testing.assert_allclose(s2, s0, rtol=1e-5, atol=1e-6)
             scale = np.abs(g0).max()
             diff = np.abs(g1 - g0)
             if B < 1000:
