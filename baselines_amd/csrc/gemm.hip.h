@@ -359,7 +359,7 @@ struct EpiMaskAct {       // out[m*ld + n] = acc * act'(h[m*ld + n])      (fc da
     static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* h; int act;
     __device__ __forceinline__ long addr(int m, int n, int) const { return (long)m * ld + n; }
-    // h == nullptr: the act' mask is deferred to the consumers of `out` (store the plain product)
+    // h == nullptr: no activation below (store the plain product)
     __device__ __forceinline__ float aux(long o, int) const { return h ? h[o] : 1.f; }
     __device__ __forceinline__ void put(long o, float acc, float hv) const { out[o] = h ? acc * act_bwd_from_out(hv, act) : acc; }
 };

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void imgres_wgrad_kernel(const void* __
     // stream (holding the whole 79 KB stage in registers made the compiler spill and serialise the loads).
     constexpr int NCHUNK = G::NXV + G::NDV;
     // hcur != nullptr: dz is the gradient w.r.t. this layer's OUTPUT; the ReLU mask (hcur > 0) is applied
-    // while the chunk is written to LDS (deferred activation mask, see ldsdgrad.hip.h)
+    // while the chunk is written to LDS (optional mask-in of the incoming gradient; the callers pass hcur == nullptr)
     const uint4* gx = nullptr;
     const float4* gd = nullptr;
     const float4* gh = nullptr;

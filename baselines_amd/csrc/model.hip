@@ -1210,7 +1210,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     const long tpc = ((long)Md + 31) / 32;
                     WresDgradA wa; static_cast<DgradGeom&>(wa) = g; wa.dz = dz; wa.zeros = ws.zeros; wa.tiles_per_class = tpc;
                     WresDgradB wb; static_cast<DgradGeom&>(wb) = g; wb.w = params + l.w_off;
-                    WresEpiDgrad we; static_cast<DgradGeom&>(we) = g; we.out = nw.dz[i - 1]; we.hprev = hprev;   /* wres data-gradient always masks: not used when deferring */
+                    WresEpiDgrad we; static_cast<DgradGeom&>(we) = g; we.out = nw.dz[i - 1]; we.hprev = hprev;
                     we.act = lp.act; we.tiles_per_class = tpc;
                     rc = wres_dispatch(l.name, "dgrad", dv, l.C, wa, wb, we, zc, Kd, tpc * zc, fl, st);
                 } else {
