@@ -239,3 +239,49 @@ def test_vecmonitor_matches_reference_run(golden_dir, tmp_path):
     text = open(str(tmp_path / 'run.monitor.csv')).read().splitlines()
     assert text[0].startswith('# {"t_start": ') and text[1] == str(g['vm_csv_header'])
     assert [ln.rsplit(',', 1)[0] for ln in text[2:]] == [str(x) for x in g['vm_csv_rl']]
+
+
+def test_lstm_closed_form_backward_matches_autograd():
+    """groundwork for the recurrent policies: the NumPy restatement of a2c/utils.py:81-102 and its
+    closed-form backward pass against torch autograd of the same forward, float64, masks included"""
+    import torch
+    from oracle import lstm_numpy as LN
+    rng = np.random.RandomState(0)
+    T, E, nin, nh = 7, 5, 6, 4
+    xs = rng.randn(T, E, nin)
+    ms = (rng.rand(T, E) < 0.3).astype(np.float64)
+    s0 = rng.randn(E, 2 * nh) * 0.5
+    wx, wh, b = rng.randn(nin, 4 * nh) * 0.4, rng.randn(nh, 4 * nh) * 0.4, rng.randn(4 * nh) * 0.1
+    hs, s_last, cache = LN.lstm_forward(xs, ms, s0, wx, wh, b)
+    g_h, g_s = rng.randn(T, E, nh), rng.randn(E, 2 * nh)
+    dxs, ds0, dwx, dwh, db = LN.lstm_backward(g_h, g_s, xs, wx, wh, cache)
+
+    t = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in
+         dict(xs=xs, s0=s0, wx=wx, wh=wh, b=b).items()}
+    c, h = t['s0'][:, :nh], t['s0'][:, nh:]
+    outs = []
+    for step in range(T):
+        keep = torch.tensor(1.0 - ms[step])[:, None]
+        c, h = c * keep, h * keep
+        z = t['xs'][step] @ t['wx'] + h @ t['wh'] + t['b']
+        i, f, o, u = torch.sigmoid(z[:, :nh]), torch.sigmoid(z[:, nh:2 * nh]), torch.sigmoid(z[:, 2 * nh:3 * nh]), torch.tanh(z[:, 3 * nh:])
+        c = f * c + i * u
+        h = o * torch.tanh(c)
+        outs.append(h)
+    H = torch.stack(outs)
+    np.testing.assert_allclose(hs, H.detach().numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(s_last, torch.cat([c, h], 1).detach().numpy(), rtol=1e-12, atol=1e-13)
+    loss = (H * torch.tensor(g_h)).sum() + (torch.cat([c, h], 1) * torch.tensor(g_s)).sum()
+    loss.backward()
+    for got, key in ((dxs, 'xs'), (ds0, 's0'), (dwx, 'wx'), (dwh, 'wh'), (db, 'b')):
+        np.testing.assert_allclose(got, t[key].grad.numpy(), rtol=1e-10, atol=1e-12, err_msg=key)
+
+
+def test_recurrent_minibatches_cover_whole_trajectories():
+    from oracle import lstm_numpy as LN
+    seen = []
+    for envs, flat in LN.recurrent_minibatches(8, 5, 4, np.random.RandomState(3)):
+        assert len(envs) == 2 and flat.shape == (10,)
+        np.testing.assert_array_equal(flat.reshape(2, 5), envs[:, None] * 5 + np.arange(5)[None, :])
+        seen.extend(envs.tolist())
+    assert sorted(seen) == list(range(8))
