@@ -77,6 +77,19 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p]),
     'mrl_tune_set': (c_int, [c_char_p, c_int]),
     'mrl_set_option': (c_int, [c_char_p, c_int]),
+    'mrl_get_option': (c_int, [c_char_p, ctypes.POINTER(c_int)]),
+    'mrl_model_train_step': (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_void_p,
+                                     c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_int, c_void_p]),
+    'mrl_comm_unique_id': (c_int, [c_void_p]),
+    'mrl_comm_create': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'mrl_comm_destroy': (None, [c_void_p]),
+    'mrl_comm_size': (c_int, [c_void_p]),
+    'mrl_comm_rank': (c_int, [c_void_p]),
+    'mrl_comm_last_error': (c_char_p, []),
+    'mrl_allreduce_grads': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    'mrl_broadcast_state': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_model_attach_comm': (c_int, [c_void_p, c_void_p, c_float]),
     'mrl_prof_enable': (c_int, [c_int]),
     'mrl_prof_num_labels': (c_int, []),
     'mrl_prof_get': (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_double),
@@ -122,7 +135,10 @@ def bind(name, restype, argtypes):
 def check(rc, what='mrl call'):
     if rc != 0:
         msg = load().mrl_strerror(int(rc))
-        raise MrlError('%s failed: rc=%d (%s)' % (what, rc, msg.decode() if msg else '?'))
+        text = msg.decode() if msg else '?'
+        if int(rc) == -4:
+            text += ': ' + load().mrl_comm_last_error().decode()
+        raise MrlError('%s failed: rc=%d (%s)' % (what, rc, text))
 
 
 _gpu_ok = None
@@ -189,3 +205,10 @@ def tune_set(label, variant):
 def set_option(name, value):
     """Engine option (include/mrl.h: "u8_bf16x3", "mlp_fused", ...)."""
     check(load().mrl_set_option(name.encode(), int(value)), 'mrl_set_option')
+
+
+def get_option(name):
+    """Value in effect of an engine option (default, environment variable or set_option)."""
+    v = c_int()
+    check(load().mrl_get_option(name.encode(), ctypes.byref(v)), 'mrl_get_option')
+    return v.value

@@ -5,14 +5,39 @@ mpi4py communicator the reference threads through `learn(..., comm=)` (ppo2/mode
 One process per GPU.  The only data-path collective is ONE in-place all-reduce(sum) of the flat
 fp32 gradient per minibatch step over xGMI; weights/Adam slots are broadcast from rank 0 once after
 initialisation.  The class is backend-agnostic so the N>1 logic is testable with gloo on CPU."""
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class Comm(object):
+    """`native`: handle of the in-library RCCL communicator (`mrl_comm`, include/mrl.h).  When present the
+    gradient all-reduce is issued by libmrl.so itself from inside the backward pass (Model attaches it to its
+    mrl_model) and the broadcasts below go through it too; torch.distributed is then only the bootstrap channel
+    for the RCCL unique id and the control plane (total weight, check_synced)."""
+
     def __init__(self, group=None):
         assert dist.is_initialized(), 'torch.distributed is not initialised'
         self.group = group
+        self.native = None
+
+    def enable_native(self):
+        """Create the mrl_comm of this rank: rank 0 draws the RCCL unique id, torch.distributed ships it."""
+        from .. import _lib
+        lib = _lib.load()
+        size, rank = self.Get_size(), self.Get_rank()
+        box = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(lib.mrl_comm_unique_id(buf), 'mrl_comm_unique_id')
+            box[0] = bytes(buf.raw)
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        h = ctypes.c_void_p()
+        _lib.check(lib.mrl_comm_create(box[0], size, rank, ctypes.byref(h)), 'mrl_comm_create')
+        self.native = h
+        return self
 
     def Get_size(self):
         return dist.get_world_size(self.group)
@@ -22,6 +47,11 @@ class Comm(object):
 
     def allreduce_sum_(self, t):
         """mpi_adam_optimizer.py:39: Allreduce(flat_grad, SUM), in place."""
+        if self.native is not None and t.is_cuda and t.dtype == torch.float32:
+            from .. import _lib
+            _lib.check(_lib.load().mrl_allreduce_grads(self.native, _lib.ptr(t), t.numel(), _lib.stream_ptr()),
+                       'mrl_allreduce_grads')
+            return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -34,6 +64,11 @@ class Comm(object):
 
     def bcast_(self, t, root=0):
         """mpi_util.py:15-26 sync_from_root."""
+        if self.native is not None and t.is_cuda:
+            from .. import _lib
+            _lib.check(_lib.load().mrl_broadcast_state(self.native, _lib.ptr(t), t.numel() * t.element_size(), int(root),
+                                                       _lib.stream_ptr()), 'mrl_broadcast_state')
+            return t
         dist.broadcast(t, src=root, group=self.group)
         return t
 
@@ -47,9 +82,13 @@ class Comm(object):
 
 
 def default_comm():
-    """`if MPI is not None and comm is None: comm = MPI.COMM_WORLD` (ppo2/model.py:31-32)."""
+    """`if MPI is not None and comm is None: comm = MPI.COMM_WORLD` (ppo2/model.py:31-32).  Over the RCCL backend
+    the communicator is the in-library one (MRL_NATIVE_COMM=0 keeps the collectives in torch.distributed)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return Comm()
+        comm = Comm()
+        if dist.get_backend() == 'nccl' and os.environ.get('MRL_NATIVE_COMM', '1') != '0':
+            comm.enable_native()
+        return comm
     return None
 
 

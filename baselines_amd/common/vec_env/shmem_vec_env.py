@@ -42,9 +42,11 @@ def _views(buf, num_envs, ob_shape, ob_dtype, ring):
 def _worker(pipe, parent_pipe, env_fns_wrapped, shm_name, first, num_envs, ob_shape, ob_dtype, ring):
     """serves envs [first, first+len) of the vector: commands ('reset', slot) / ('step', slot, actions) / ('close',)"""
     parent_pipe.close()
-    shm = shared_memory.SharedMemory(name=shm_name)
+    shm = None
+    obs = rew = done = None
     envs = []
     try:
+        shm = shared_memory.SharedMemory(name=shm_name)      # inside the try: a failed attach is reported, not a hang
         obs, rew, done = _views(shm.buf, num_envs, ob_shape, ob_dtype, ring)
         envs = [make() for make in env_fns_wrapped.x]
         while True:
@@ -80,12 +82,13 @@ def _worker(pipe, parent_pipe, env_fns_wrapped, shm_name, first, num_envs, ob_sh
         except Exception:
             pass
     finally:
-        del obs, rew, done
+        obs = rew = done = None                   # drop the views before the mapping goes away
         for env in envs:
             closer = getattr(env, 'close', None)
             if closer is not None:
                 closer()
-        shm.close()
+        if shm is not None:
+            shm.close()
 
 
 class ShmemVecEnv(VecEnv):

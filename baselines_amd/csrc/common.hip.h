@@ -49,4 +49,10 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(st); }
 };
 
+
+// clip_by_global_norm + TF-1 Adam (rollout.hip); ready_part: sum-of-squares partials left behind by the gradient's producer
+int adam_clip_apply(float* params, float* grads, float* m, float* v, long P, float alpha, const float* alpha_dev,
+                    float beta1, float beta2, float eps, float max_grad_norm, float total_weight, float* gnorm_out,
+                    void* scratch, const double* ready_part, int ready_npart, hipStream_t st);
+
 }  // namespace mrl

@@ -23,6 +23,7 @@
 #include "ldsdgrad.hip.h"
 #include "gemmx6.hip.h"
 #include "mlpstep.hip.h"
+#include "comm.hip.h"
 
 using namespace mrl;
 
@@ -64,6 +65,8 @@ struct mrl_model {
     long P;
     long ob_elems;
     std::vector<TensorInfo> tensors;
+    mrl_comm* comm = nullptr;              // data-parallel communicator (mrl_model_attach_comm); not owned
+    float rank_weight = 1.f;               // mpi_adam_optimizer.py:21 `flat_grad * mpi_rank_weight`
 };
 
 static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> shape, double scale) {
@@ -194,6 +197,7 @@ struct Ws {
     float* part;         // split-K / bias / head partial slabs
     size_t part_floats;
     double* dscratch;    // adv partials [ADV_G][2] | head stat partials [HEAD_MAXBLK][5] | stats acc [5]
+    double* sqpart;      // [SQ_MAX_PART] sum-of-squares partials of the gradient (StepCtx)
     float* advstat;      // [2]
     int32_t* srow;       // [chunk] storage rows of the minibatch samples (env-major index translated)
     float* zeros;        // 256 zero floats (out-of-map taps of the weights-resident data-gradient)
@@ -201,6 +205,8 @@ struct Ws {
 };
 
 constexpr int ADV_G = 256;
+constexpr int SQ_MAX_PART = 8192;            // sum-of-squares partial slots per step
+constexpr int SQ_BLOCKS_PER_LAUNCH = 1024;   // reduce_slabs blocks (= slots) per launch while they are collected
 constexpr int HEAD_MAXBLK = 512;
 constexpr int SPART_MAX = 2048;             // stat partials: max(HEAD_MAXBLK, MLP_MAX_TILES)
 constexpr int WGRAD_TARGET_WGS = 1536;
@@ -228,11 +234,26 @@ static int get_option(const char* name, const char* env, int dflt) {
     t[name] = v;
     return v;
 }
+// fp32 x fp32 GEMM sites that run on the bf16 pipe: 0 = fp32 MFMA (bitwise fmaf chain), 1 = six bf16 products per
+// multiply (dropped part < 2^-21 of a product), 2 = eight products (dropped part < 2^-29: below one fp32 rounding).
+// Default 2: every product of the update is then at least as accurate as an IEEE fp32 multiply.
+static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 2); }
+static const char* const kOptionEnv[][2] = {
+    {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
+    {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
+    {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
+    {"fused_norm", "MRL_FUSED_NORM"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1};
+extern "C" int mrl_get_option(const char* name, int* value_out) {
+    if (!name || !value_out) return MRL_EINVAL;
+    for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
+        if (!strcmp(kOptionEnv[i][0], name)) { *value_out = get_option(name, kOptionEnv[i][1], kOptionDefault[i]); return 0; }
+    return MRL_EINVAL;
+}
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
-    static const char* known[] = {"u8_bf16x3", "f32_bf16x6", "mlp_fused", "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg"};
-    for (const char* k : known)
-        if (!strcmp(k, name)) { option_table()[name] = value; return 0; }
+    for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
+        if (!strcmp(kOptionEnv[i][0], name)) { option_table()[name] = value; return 0; }
     return MRL_EINVAL;
 }
 extern "C" int mrl_tune_set(const char* label, int variant) {
@@ -306,6 +327,7 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     ws.part = (float*)take(part_floats * 4);
     ws.part_floats = part_floats;
     ws.dscratch = (double*)take((size_t)(ADV_G * 2 + SPART_MAX * 5 + 8) * 8);
+    ws.sqpart = (double*)take((size_t)SQ_MAX_PART * 8);
     ws.advstat = (float*)take(64);
     ws.srow = (int32_t*)take((size_t)chunk * 4);
     ws.zeros = (float*)take(2048);
@@ -324,13 +346,29 @@ extern "C" size_t mrl_model_workspace_bytes(const mrl_model* m, int chunk) {
 // small kernels
 // ============================================================================================
 
+// per-call state threaded through the layer launches of one gradient computation
+struct StepCtx {
+    double* sqpart = nullptr;   // sum-of-squares partials of the FINAL gradient, one per reduce_slabs block (nullptr: not collected)
+    int sqcap = 0, sqn = 0;     // capacity / slots used so far
+    mrl_comm* comm = nullptr;   // data-parallel all-reduce of finished gradient slices (only on the last chunk)
+    float rank_weight = 1.f;
+    bool final_chunk = true;
+    int early_layer = -1;       // pi-net layer after whose weight gradient [early_lo, P) is complete and can travel
+    long early_lo = 0;
+};
+
 // out[i] = (accumulate ? out[i] : 0) + sum_z part[z*slab + i]   (fixed order -> deterministic).
 // 64 outputs x 4 z-lanes per block: lane q sums z = q, q+4, ... with 4 loads in flight, the four
-// lane sums are combined in a fixed order through LDS.
+// lane sums are combined in a fixed order through LDS.  sq != nullptr: the block also leaves the f64 sum of squares of
+// the values it wrote in sq[blockIdx.x] -- the global-norm partials of tf.clip_by_global_norm (model.py:105-107) come
+// out of the pass that produces the gradient instead of a second pass over it.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, long slab, int nz,
-                                                           float* __restrict__ out, long n, int accumulate) {
+                                                           float* __restrict__ out, long n, int accumulate,
+                                                           double* __restrict__ sq) {
     __shared__ float sh[4][64];
+    __shared__ double shd[4];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double ssq = 0.0;
     for (long i0 = blockIdx.x * 64L; i0 < n; i0 += (long)gridDim.x * 64L) {
         const long i = i0 + c;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -348,15 +386,29 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         __syncthreads();
         if (q == 0 && i < n) {
             float t = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
-            out[i] = accumulate ? out[i] + t : t;
+            if (accumulate) t = out[i] + t;
+            out[i] = t;
+            ssq += (double)t * (double)t;
         }
         __syncthreads();
     }
+    if (sq) {
+        const double r = block_sum_256(ssq, shd);
+        if (threadIdx.x == 0) sq[blockIdx.x] = r;
+    }
 }
-static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st) {
+static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st,
+                        StepCtx* ctx = nullptr) {
     int blocks = (int)std::min<long>((n + 63) / 64, 8192);
+    double* sq = nullptr;
+    if (ctx && ctx->sqpart) {
+        blocks = std::min(blocks, SQ_BLOCKS_PER_LAUNCH);
+        if (ctx->sqn + blocks > ctx->sqcap) return MRL_ENOSPC;
+        sq = ctx->sqpart + ctx->sqn;
+        ctx->sqn += blocks;
+    }
     ProfScope ps("reduce_slabs", 0.0, 4.0 * n * (nz + 1 + (accumulate ? 1 : 0)), st);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate, sq);
     MRL_LAUNCH_CHECK();
     return 0;
 }
@@ -1036,7 +1088,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 // fp32 activations: bf16 x 6 split engine (wres.hip.h) unless MRL_F32_BF16X6=0 asks for the fmaf chain
                 // fp32 activations: tiled bf16 x 6 engine with the im2col row map (gemmx6.hip.h) unless MRL_F32_BF16X6=0 asks
                 // for the fp32-MFMA weights-resident path
-                const int x6 = get_option("f32_bf16x6", "MRL_F32_BF16X6", 1);
+                const int x6 = f32_split_mode();
                 const int rowk = l.rf * l.C;
                 if (x6 && planes && rowk % X6_BK == 0 && l.C % 4 == 0 && (uintptr_t)hprev % 16 == 0) {
                     X6ConvA ca;
@@ -1074,7 +1126,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
         } else {
             // hidden fc layer: bf16 x 6 tiled engine (gemmx6.hip.h) on large batches unless MRL_F32_BF16X6=0
             if (planes && B >= 1024 && l.N >= 128 && gemm_x6_ok(hprev, l.K, l.K) && !tuned(l, "fwd") &&
-                get_option("f32_bf16x6", "MRL_F32_BF16X6", 1)) {
+                f32_split_mode()) {
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
@@ -1083,7 +1135,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
                 long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) ? dbgbuf : nullptr;
                 return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st, dbgp,
-                                           get_option("f32_bf16x6", "MRL_F32_BF16X6", 1) == 2);
+                                           f32_split_mode() == 2);
             }
             RowKC af{hprev, l.K, B, l.K, is_vec(hprev, l.K), nullptr};
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
@@ -1113,7 +1165,7 @@ static bool tuned(const Layer& l, const char* pass) {
 
 // backward through one net; nw.dz[last] already holds dloss/d(pre-activation of the last layer)
 static int net_backward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws,
-                        float* grads, int B, int accumulate, hipStream_t st) {
+                        float* grads, int B, int accumulate, hipStream_t st, StepCtx& ctx, bool is_pi) {
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
         const float* dz = nw.dz[i];
@@ -1135,7 +1187,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             if (nblocks < 1) return MRL_ENOSPC;
             rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, nullptr, B, ws.part, nblocks, st);
             if (rc) return rc;
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st);
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
             if (rc) return rc;
         } else {
         if (var >= V_WRES16) var = l.N <= 32 ? V_128x32 : (l.N <= 64 ? V_128x64_W41 : V_128x128);
@@ -1165,8 +1217,14 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             }
         }
         if (rc) return rc;
-        rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, st);
+        rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, st, &ctx);
         if (rc) return rc;
+        }
+        // data parallel: the tail of the flat gradient [this layer .. heads] is final -> it travels (RCCL, communication
+        // stream) while the layers below are still being back-propagated
+        if (ctx.comm && ctx.final_chunk && is_pi && i == ctx.early_layer) {
+            rc = comm_allreduce_async(ctx.comm, grads + ctx.early_lo, m->P - ctx.early_lo, ctx.rank_weight, st);
+            if (rc) return rc;
         }
         // ---- data gradient into dz[i-1] (masked by act' of layer i-1)
         if (!first) {
@@ -1221,7 +1279,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     rc = gemm_dispatch(l.name, "dgrad", dv, af, bf, ef, Md, l.C, Kd, l.stride * l.stride, Kd, st, fl);
                 }
             } else if (nw.planes && B >= 1024 && l.K >= 128 && gemm_x6_ok(dz, l.N, l.N) && !tuned(l, "dgrad") &&
-                       get_option("f32_bf16x6", "MRL_F32_BF16X6", 1)) {
+                       f32_split_mode()) {
                 // dX[b][k] = sum_n dz[b][n] W[k][n]: W's rows are already the k-contiguous B operand
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
@@ -1230,7 +1288,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st);
                 if (e == hipSuccess)
                     e = launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr,
-                                       get_option("f32_bf16x6", "MRL_F32_BF16X6", 1) == 2);
+                                       f32_split_mode() == 2);
                 rc = (int)e;
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
@@ -1324,7 +1382,8 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
                             const float* returns, const float* values, const float* neglogpacs,
                             const int64_t* idx, int Bstat, int mb0, int mbn, int T, int N, float cliprange, float ent_coef,
                             float vf_coef, float* grads_out, float* stats_out, void* workspace,
-                            size_t workspace_bytes, int chunk, void* stream) {
+                            size_t workspace_bytes, int chunk, void* stream, bool want_sq = false, int* sqn_out = nullptr) {
+    if (sqn_out) *sqn_out = 0;
     if (!m || !params || !obs || !actions || !returns || !values || !neglogpacs || !grads_out || !stats_out ||
         !workspace || Bstat <= 0 || chunk <= 0 || mb0 < 0 || mbn <= 0 || mb0 + mbn > Bstat)
         return MRL_EINVAL;
@@ -1336,6 +1395,18 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
     Ws ws;
     carve(m, chunk, (char*)workspace, ws);
     if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    StepCtx ctx;
+    ctx.comm = m->comm;
+    ctx.rank_weight = m->rank_weight;
+    if (ctx.comm && !m->vf_copy && m->pi.L.size() >= 2) {       // flat layout: pi layers in order, then the heads
+        ctx.early_layer = (int)m->pi.L.size() - 1;
+        ctx.early_lo = m->pi.L.back().w_off;
+    }
+    // global-norm partials ride on the slab reductions when the gradient is final after one pass and stays local
+    if (want_sq && !ctx.comm && mbn <= chunk && get_option("fused_norm", "MRL_FUSED_NORM", 1)) {
+        ctx.sqpart = ws.sqpart;
+        ctx.sqcap = SQ_MAX_PART;
+    }
     double* advpart = ws.dscratch;
     double* spart = ws.dscratch + ADV_G * 2;
     double* stats_acc = spart + SPART_MAX * 5;
@@ -1407,16 +1478,22 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
                 hipLaunchKernelGGL(mlp_step_kernel, dim3(ntiles), dim3(256), lds, st, a);
             }
             MRL_LAUNCH_CHECK();
-            int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st);
+            int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st, &ctx);
             if (rc) return rc;
             hipLaunchKernelGGL(stats_reduce_finalize_kernel, dim3(1), dim3(64), 0, st, spart, ntiles, invB, stats_out);
             MRL_LAUNCH_CHECK();
+            if (ctx.comm) {
+                if ((rc = comm_allreduce_async(ctx.comm, grads_out, m->P, ctx.rank_weight, st))) return rc;
+                if ((rc = comm_join(ctx.comm, st))) return rc;
+            }
+            if (sqn_out) *sqn_out = ctx.sqn;
             return 0;
         }
     }
     for (int c0 = 0; c0 < B; c0 += chunk) {
         const int Bc = std::min(chunk, B - c0);
         const int accumulate = c0 > 0;
+        ctx.final_chunk = c0 + chunk >= B;
         In in;
         if (idx) {
             if (c0 > 0 || !whole) {                      // chunk 0 of a whole minibatch was translated by advstat_part_kernel
@@ -1472,15 +1549,21 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
             }
         }
         MRL_LAUNCH_CHECK();
-        if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st))) return rc;
+        if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st, &ctx))) return rc;
         hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, nblk, stats_acc);
         MRL_LAUNCH_CHECK();
-        if ((rc = net_backward(m, m->pi, in, params, ws.pi, ws, grads_out, Bc, accumulate, st))) return rc;
-        if (m->vf_copy && (rc = net_backward(m, m->vf, in, params, ws.vf, ws, grads_out, Bc, accumulate, st)))
+        if ((rc = net_backward(m, m->pi, in, params, ws.pi, ws, grads_out, Bc, accumulate, st, ctx, true))) return rc;
+        if (m->vf_copy && (rc = net_backward(m, m->vf, in, params, ws.vf, ws, grads_out, Bc, accumulate, st, ctx, false)))
             return rc;
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, st, stats_acc, invB, stats_out);
     MRL_LAUNCH_CHECK();
+    if (ctx.comm) {        // the rest of the flat gradient, then the compute stream waits for both collectives
+        int rc = comm_allreduce_async(ctx.comm, grads_out, ctx.early_layer >= 0 ? ctx.early_lo : m->P, ctx.rank_weight, st);
+        if (rc) return rc;
+        if ((rc = comm_join(ctx.comm, st))) return rc;
+    }
+    if (sqn_out) *sqn_out = ctx.sqn;
     return 0;
 }
 
@@ -1500,4 +1583,33 @@ extern "C" int mrl_model_grad_micro(const mrl_model* m, const float* params, con
                                     size_t workspace_bytes, int chunk, void* stream) {
     return model_grad_range(m, params, obs, actions, returns, values, neglogpacs, idx, B, mb0, mbn, T, N, cliprange,
                             ent_coef, vf_coef, grads_out, stats_out, workspace, workspace_bytes, chunk, stream);
+}
+
+// ---- data-parallel attachment --- common/mpi_adam_optimizer.py:18-51 -----------------------------------------------
+extern "C" int mrl_model_attach_comm(mrl_model* m, mrl_comm* comm, float rank_weight) {
+    if (!m || rank_weight <= 0.f) return MRL_EINVAL;
+    m->comm = comm;
+    m->rank_weight = rank_weight;
+    return 0;
+}
+
+// ---- Model.train in ONE call --- ppo2/model.py:133-158 + :97-114 ---------------------------------------------------
+// gather -> forward -> loss -> backward -> [RCCL all-reduce] -> / total weight -> clip_by_global_norm -> Adam.
+// Single-rank, single-chunk steps take the global norm from the partials the gradient's slab reductions leave behind.
+extern "C" int mrl_model_train_step(const mrl_model* m, float* params, float* grads, float* adam_m, float* adam_v,
+                                    const void* obs, const void* actions, const float* returns, const float* values,
+                                    const float* neglogpacs, const int64_t* idx, int B, int T, int N, float cliprange,
+                                    float ent_coef, float vf_coef, float alpha, const float* alpha_dev, float beta1,
+                                    float beta2, float eps, float max_grad_norm, float total_weight, float* stats_out,
+                                    float* gnorm_out, void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+    if (!m || !adam_m || !adam_v || total_weight <= 0.f) return MRL_EINVAL;
+    int sqn = 0;
+    const bool want_sq = max_grad_norm >= 0.f && total_weight == 1.f;
+    int rc = model_grad_range(m, params, obs, actions, returns, values, neglogpacs, idx, B, 0, B, T, N, cliprange, ent_coef,
+                              vf_coef, grads, stats_out, workspace, workspace_bytes, chunk, stream, want_sq, &sqn);
+    if (rc) return rc;
+    Ws ws;
+    carve(m, chunk, (char*)workspace, ws);
+    return adam_clip_apply(params, grads, adam_m, adam_v, m->P, alpha, alpha_dev, beta1, beta2, eps, max_grad_norm,
+                           total_weight, gnorm_out, ws.sqpart, sqn > 0 ? ws.sqpart : nullptr, sqn, (hipStream_t)stream);
 }

@@ -92,6 +92,7 @@ extern "C" const char* mrl_strerror(int code) {
         case MRL_EINVAL: return "mrl: invalid argument";
         case MRL_ENOSPC: return "mrl: workspace too small";
         case MRL_EUNSUP: return "mrl: unsupported configuration";
+        case MRL_ECOMM: return "mrl: RCCL communicator error";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "mrl: unknown error";
     }
 }
@@ -232,11 +233,13 @@ extern "C" int mrl_sf01(const void* src, void* dst, int T, int N, int row_bytes,
 }
 
 // ------------------------------------------------------------------------------------------
-// clip_by_global_norm + Adam (TF-1 ApplyAdam form).  Two launches:
-//   1) sumsq partials (f64, fixed order) of g/total_weight;
-//   2) every block re-reduces the partials in the same order -> identical norm everywhere,
-//      then updates its slice:  m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps).
-// Algorithmic traffic 28 B/param (read p,g,m,v; write p,m,v) + 4 B/param for the norm pass.
+// clip_by_global_norm + Adam (TF-1 ApplyAdam form), 16-byte accesses:
+//   [1) sumsq partials (f64, fixed order) of g/total_weight -- skipped when the producer of the gradient already
+//       left them behind: reduce_slabs in model.hip emits the partial sums of squares of what it writes, so the
+//       gradient is not read a second time for its norm (mrl_model_train_step);]
+//   2) every block re-reduces the partials in the same order -> identical norm everywhere, then updates its
+//      slice:  m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps).
+// Algorithmic traffic 28 B/param (read p,g,m,v; write p,m,v) [+ 4 B/param for a separate norm pass].
 // ------------------------------------------------------------------------------------------
 constexpr int ADAM_MAX_PART = 1024;
 
@@ -244,13 +247,31 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
                                                     double* __restrict__ part) {
     __shared__ double sh[4];
     double s = 0.0;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < P; i += (long)gridDim.x * 256L) {
-        float x = g[i];
+    const long P4 = P >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < P4; i += (long)gridDim.x * 256L) {
+        float4 x = g4[i];
+        if (total_weight != 1.f) { x.x /= total_weight; x.y /= total_weight; x.z /= total_weight; x.w /= total_weight; }
+        s += ((double)x.x * (double)x.x + (double)x.y * (double)x.y) + ((double)x.z * (double)x.z + (double)x.w * (double)x.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(P & 3)) {          // tail
+        float x = g[P4 * 4 + threadIdx.x];
         if (total_weight != 1.f) x = x / total_weight;
         s += (double)x * (double)x;
     }
     double r = block_sum_256(s, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, float alpha, float omb1, float omb2,
+                                          float eps, float total_weight, float scale) {
+    float x = g;
+    if (total_weight != 1.f) x = x / total_weight;
+    x = x * scale;
+    g = x;          // the clipped, averaged gradient (model.py:112 self.grads)
+    m = m + (x - m) * omb1;
+    v = v + (x * x - v) * omb2;
+    p = p - (m * alpha) / (sqrtf(v) + eps);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -276,17 +297,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         scale = s_scale;
     }
     const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < P; i += (long)gridDim.x * 256L) {
-        float x = g[i];
-        if (total_weight != 1.f) x = x / total_weight;
-        x = x * scale;
-        g[i] = x;   // the clipped, averaged gradient (model.py:112 self.grads)
-        float mi = m[i], vi = v[i];
-        mi = mi + (x - mi) * omb1;
-        vi = vi + (x * x - vi) * omb2;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    const long P4 = P >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < P4; i += (long)gridDim.x * 256L) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, alpha, omb1, omb2, eps, total_weight, scale);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, alpha, omb1, omb2, eps, total_weight, scale);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, alpha, omb1, omb2, eps, total_weight, scale);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, alpha, omb1, omb2, eps, total_weight, scale);
+        g4[i] = gg; m4[i] = mm; v4[i] = vv; p4[i] = pp;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(P & 3)) {          // tail
+        const long i = P4 * 4 + threadIdx.x;
+        float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        adam_elem(pp, gg, mm, vv, alpha, omb1, omb2, eps, total_weight, scale);
+        g[i] = gg; m[i] = mm; v[i] = vv; p[i] = pp;
     }
 }
 
@@ -317,9 +345,12 @@ __global__ __launch_bounds__(256) void clip_accumulate_kernel(const float* __res
     }
 }
 
+static inline bool vec16(const void* p) { return (uintptr_t)p % 16 == 0; }
+
 extern "C" int mrl_clip_accumulate(const float* grads, float* acc, long P, float max_grad_norm, float total_weight,
                                    int first, void* scratch, void* stream) {
     if (!grads || !acc || P <= 0 || !scratch || total_weight <= 0.f) return MRL_EINVAL;
+    if (!vec16(grads)) return MRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int blocks = (int)min((P + 1023) / 1024, (long)ADAM_MAX_PART);
     ProfScope ps("clip+accumulate", 0.0, (max_grad_norm >= 0.f ? 16.0 : 12.0) * P, st);
@@ -338,34 +369,44 @@ extern "C" size_t mrl_adam_scratch_bytes(long P) {
     return ADAM_MAX_PART * sizeof(double);
 }
 
-static int adam_clip_step_impl(float* params, float* grads, float* m, float* v, long P, float alpha, const float* alpha_dev,
-                               float beta1, float beta2, float eps, float max_grad_norm, float total_weight,
-                               float* gnorm_out, void* scratch, void* stream) {
-    if (!params || !grads || !m || !v || P <= 0 || !scratch || total_weight <= 0.f) return MRL_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    int blocks = (int)min((P + 1023) / 1024, (long)ADAM_MAX_PART);
-    ProfScope ps("clip+adam", 0.0, (max_grad_norm >= 0.f ? 32.0 : 28.0) * P, st);
-    if (max_grad_norm >= 0.f) {
-        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, grads, P, total_weight, (double*)scratch);
+namespace mrl {
+// `ready_part` / `ready_npart`: sum-of-squares partials of the (single-rank, un-averaged) gradient left behind by its
+// producer; nullptr: computed here with one extra pass over the gradient into `scratch`.
+int adam_clip_apply(float* params, float* grads, float* m, float* v, long P, float alpha, const float* alpha_dev,
+                    float beta1, float beta2, float eps, float max_grad_norm, float total_weight, float* gnorm_out,
+                    void* scratch, const double* ready_part, int ready_npart, hipStream_t st) {
+    if (!params || !grads || !m || !v || P <= 0 || total_weight <= 0.f) return MRL_EINVAL;
+    if (!vec16(params) || !vec16(grads) || !vec16(m) || !vec16(v)) return MRL_EINVAL;
+    if (max_grad_norm >= 0.f && !ready_part && !scratch) return MRL_EINVAL;
+    const bool fused = ready_part != nullptr && max_grad_norm >= 0.f;
+    ProfScope ps("clip+adam", 0.0, (max_grad_norm >= 0.f && !fused ? 32.0 : 28.0) * P, st);
+    const double* part = ready_part;
+    int npart = ready_npart;
+    if (max_grad_norm >= 0.f && !ready_part) {
+        npart = (int)min((P + 4095) / 4096, (long)ADAM_MAX_PART);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(npart), dim3(256), 0, st, grads, P, total_weight, (double*)scratch);
         MRL_LAUNCH_CHECK();
+        part = (const double*)scratch;
     }
+    const int blocks = (int)min((P / 4 + 255) / 256 + 1, (long)2048);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, P, alpha, beta1, beta2, eps,
-                       max_grad_norm, total_weight, (const double*)scratch, blocks, gnorm_out, alpha_dev);
+                       max_grad_norm, total_weight, part, npart, gnorm_out, alpha_dev);
     MRL_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace mrl
 
 extern "C" int mrl_adam_clip_step(float* params, float* grads, float* m, float* v, long P, float alpha, float beta1,
                                   float beta2, float eps, float max_grad_norm, float total_weight, float* gnorm_out,
                                   void* scratch, void* stream) {
-    return adam_clip_step_impl(params, grads, m, v, P, alpha, nullptr, beta1, beta2, eps, max_grad_norm, total_weight,
-                               gnorm_out, scratch, stream);
+    return adam_clip_apply(params, grads, m, v, P, alpha, nullptr, beta1, beta2, eps, max_grad_norm, total_weight,
+                           gnorm_out, scratch, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int mrl_adam_clip_step_dev(float* params, float* grads, float* m, float* v, long P, const float* alpha_dev,
                                       float beta1, float beta2, float eps, float max_grad_norm, float total_weight,
                                       float* gnorm_out, void* scratch, void* stream) {
     if (!alpha_dev) return MRL_EINVAL;
-    return adam_clip_step_impl(params, grads, m, v, P, 0.f, alpha_dev, beta1, beta2, eps, max_grad_norm, total_weight,
-                               gnorm_out, scratch, stream);
+    return adam_clip_apply(params, grads, m, v, P, 0.f, alpha_dev, beta1, beta2, eps, max_grad_norm, total_weight,
+                           gnorm_out, scratch, nullptr, 0, (hipStream_t)stream);
 }

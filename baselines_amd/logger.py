@@ -9,11 +9,12 @@ from collections import OrderedDict, defaultdict
 
 
 class _Logger(object):
-    def __init__(self, dir=None, stdout=True):
+    def __init__(self, dir=None, stdout=True, files=True):
         self.name2val = OrderedDict()
         self.name2cnt = defaultdict(int)
         self.dir = dir
         self.stdout = stdout
+        self.files = files
         self._csv_keys = None
         if dir:
             os.makedirs(dir, exist_ok=True)
@@ -36,14 +37,25 @@ class _Logger(object):
             lines = [dash] + ['| %s | %s |' % (k.ljust(kw), vals[k].ljust(vw)) for k in sorted(d)] + [dash]
             sys.stdout.write('\n'.join(lines) + '\n')
             sys.stdout.flush()
-        if self.dir and d:
+        if self.dir and self.files and d:
             with open(os.path.join(self.dir, 'progress.json'), 'at') as f:
                 f.write(json.dumps({k: (float(v) if hasattr(v, '__float__') else v) for k, v in d.items()}) + '\n')
             path = os.path.join(self.dir, 'progress.csv')
+            new = [k for k in d if k not in (self._csv_keys or [])]
             if self._csv_keys is None:
                 self._csv_keys = list(d.keys())
                 with open(path, 'wt') as f:
                     f.write(','.join(self._csv_keys) + '\n')
+            elif new:
+                # keys that appear later extend the header: the file is rewritten with the wider header and the old rows
+                # padded (the reference's CSVOutputFormat does the same, logger.py:104-121)
+                with open(path, 'rt') as f:
+                    rows = f.read().splitlines()[1:]
+                self._csv_keys += new
+                with open(path, 'wt') as f:
+                    f.write(','.join(self._csv_keys) + '\n')
+                    for r in rows:
+                        f.write(r + ',' * len(new) + '\n')
             with open(path, 'at') as f:
                 f.write(','.join(str(d.get(k, '')) for k in self._csv_keys) + '\n')
         self.name2val.clear()
@@ -55,10 +67,12 @@ _current = _Logger(dir=os.environ.get('OPENAI_LOGDIR'), stdout=True)
 
 
 def configure(dir=None, format_strs=None, comm=None, log_suffix=''):
-    """format_strs == [] silences every writer (what run.py does for non-root ranks, run.py:209-214)."""
+    """format_strs == [] silences every writer, the files included (what run.py does for non-root ranks,
+    run.py:209-214); None: stdout + files; a list: 'stdout' and/or 'csv'/'json' select the writers."""
     global _current
     _current = _Logger(dir=dir or os.environ.get('OPENAI_LOGDIR'),
-                       stdout=(format_strs is None or 'stdout' in format_strs))
+                       stdout=(format_strs is None or 'stdout' in format_strs),
+                       files=(format_strs is None or any(f in format_strs for f in ('csv', 'json', 'log'))))
 
 
 def logkv(key, val):

@@ -180,6 +180,11 @@ class DeviceModel(object):
                                       ptr(self.workspace), self.workspace.numel(), self.chunk, stream_ptr()),
               'mrl_model_grad')
 
+    def attach_comm(self, native_comm, rank_weight=1.0):
+        """data parallel: gradients returned by grad/grad_micro/train_step become rank-weighted sums over ranks (RCCL
+        all-reduce issued from inside the backward pass); None detaches."""
+        check(self.lib.mrl_model_attach_comm(self.handle, native_comm, float(rank_weight)), 'mrl_model_attach_comm')
+
     def grad_micro(self, params, obs, actions, returns, values, neglogpacs, idx, B, mb0, mbn, T, N, cliprange, ent_coef,
                    vf_coef, grads_out, stats_out):
         """one MicrobatchedModel slice: advantage statistics over all B samples, loss/gradient over [mb0, mb0+mbn)."""

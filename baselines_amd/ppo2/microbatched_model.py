@@ -42,7 +42,7 @@ class MicrobatchedModel(Model):
         stats = torch.empty((nmicro, 5), dtype=torch.float32, device=self.device)
         for k in range(nmicro):
             grad_call(k * self.microbatch_size, self.microbatch_size, stats[k])
-            if self.multi:
+            if self.multi and not self.native_dp:     # native: mrl_model_grad_micro already summed over ranks
                 if self.mpi_rank_weight != 1:
                     self.grads.mul_(float(self.mpi_rank_weight))
                 self.comm.allreduce_sum_(self.grads)

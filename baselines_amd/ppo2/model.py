@@ -8,8 +8,9 @@
 
 Where the reference builds a TF graph and calls sess.run, this object owns flat fp32 device
 buffers (params / grads / Adam m, v) and drives the HIP kernels through the C ABI:
-    mrl_model_act   (policy forward + sampling)        mrl_model_grad (gather + fwd + loss + bwd)
-    [RCCL all-reduce of the flat gradient]             mrl_adam_clip_step (avg -> clip -> Adam)
+    mrl_model_act   (policy forward + sampling)
+    mrl_model_train_step  (gather + fwd + loss + bwd + [RCCL all-reduce inside the backward] + avg -> clip -> Adam)
+    (pieces: mrl_model_grad, mrl_allreduce_grads, mrl_adam_clip_step)
 Extra, faster entry points used by our Runner / learn (no host round trips):
     .step_into(...)   .train_indexed(lr, cliprange, rollout, idx_dev)
 """
@@ -93,6 +94,10 @@ class Model(object):
             for t in (self.params, self.adam_m, self.adam_v):
                 self.comm.bcast_(t, 0)
         self.multi = self.comm is not None and self.comm.Get_size() > 1
+        # in-library RCCL communicator: the all-reduce is issued by libmrl.so from inside the backward pass
+        self.native_dp = self.multi and getattr(self.comm, 'native', None) is not None
+        if self.native_dp:
+            self.dm.attach_comm(self.comm.native, float(mpi_rank_weight))
 
     # ------------------------------------------------------------------ act side
     def _to_dev_obs(self, obs):
@@ -157,9 +162,10 @@ class Model(object):
         """[RCCL all-reduce] -> / total weight -> clip_by_global_norm -> Adam   (model.py:102-114,
         mpi_adam_optimizer.py:21,39-40).  Everything stays on the device / on the stream."""
         if self.multi:
-            if self.mpi_rank_weight != 1:
-                self.grads.mul_(float(self.mpi_rank_weight))
-            self.comm.allreduce_sum_(self.grads)
+            if not self.native_dp:                    # else: mrl_model_grad already returned the weighted sum over ranks
+                if self.mpi_rank_weight != 1:
+                    self.grads.mul_(float(self.mpi_rank_weight))
+                self.comm.allreduce_sum_(self.grads)
             if self._train_calls % 100 == 0:          # mpi_adam_optimizer.py:41-43
                 self.comm.check_synced(self.params[:1024].sum().reshape(1))
         one = np.float32(1)
@@ -189,27 +195,27 @@ class Model(object):
                 obs=_lib.ptr(rollout.obs), act=_lib.ptr(rollout.actions), val=_lib.ptr(rollout.values),
                 nlp=_lib.ptr(rollout.neglogpacs), scratch=_lib.ptr(self._scratch), gnorm=_lib.ptr(self._gnorm),
                 T=int(rollout.T), N=int(rollout.N), P=self.params.numel())
-        if self.multi:
+        if self.multi and not self.native_dp:          # collectives through torch.distributed (gloo / MRL_NATIVE_COMM=0)
             self.dm.grad(self.params, rollout.obs, rollout.actions, rollout.returns, rollout.values, rollout.neglogpacs,
                          idx_dev, idx_dev.numel(), rollout.T, rollout.N, cliprange, self.ent_coef, self.vf_coef,
                          self.grads, stats)
             self._apply_gradients(lr)
             return stats
+        if self.multi and self._train_calls % 100 == 0:          # mpi_adam_optimizer.py:41-43
+            self.comm.check_synced(self.params[:1024].sum().reshape(1))
         st = _lib.stream_ptr()
         lib = c['lib']
-        rc = lib.mrl_model_grad(c['h'], c['params'], c['obs'], c['act'], _lib.ptr(rollout.returns), c['val'], c['nlp'],
-                                _lib.ptr(idx_dev), idx_dev.numel(), c['T'], c['N'], float(cliprange), self.ent_coef,
-                                self.vf_coef, c['grads'], _lib.ptr(stats), c['ws'], c['wsn'], c['chunk'], st)
-        if rc:
-            _lib.check(rc, 'mrl_model_grad')
         one = np.float32(1)
         alpha = np.float32(lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
         mgn = -1.0 if self.max_grad_norm is None else float(self.max_grad_norm)
-        rc = lib.mrl_adam_clip_step(c['params'], c['grads'], c['m'], c['v'], c['P'], float(alpha), float(self.beta1),
-                                    float(self.beta2), float(self.epsilon), mgn, float(self.total_weight), c['gnorm'],
-                                    c['scratch'], st)
+        # Model.train as ONE C call: gather -> fwd -> loss -> bwd -> [RCCL all-reduce inside the backward] -> clip -> Adam
+        rc = lib.mrl_model_train_step(c['h'], c['params'], c['grads'], c['m'], c['v'], c['obs'], c['act'],
+                                      _lib.ptr(rollout.returns), c['val'], c['nlp'], _lib.ptr(idx_dev), idx_dev.numel(),
+                                      c['T'], c['N'], float(cliprange), self.ent_coef, self.vf_coef, float(alpha), None,
+                                      float(self.beta1), float(self.beta2), float(self.epsilon), mgn,
+                                      float(self.total_weight), _lib.ptr(stats), c['gnorm'], c['ws'], c['wsn'], c['chunk'], st)
         if rc:
-            _lib.check(rc, 'mrl_adam_clip_step')
+            _lib.check(rc, 'mrl_model_train_step')
         self.beta1_power = np.float32(self.beta1_power * self.beta1)
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
         self._train_calls += 1
@@ -271,17 +277,13 @@ class Model(object):
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             st = _lib.stream_ptr()                         # the capturing stream
             for k in range(M):
-                _lib.check(lib.mrl_model_grad(self.dm.handle, _lib.ptr(self.params), _lib.ptr(rollout.obs),
-                                              _lib.ptr(rollout.actions), _lib.ptr(rollout.returns), _lib.ptr(rollout.values),
-                                              _lib.ptr(rollout.neglogpacs), _lib.ptr(idx[k]), B, int(rollout.T), int(rollout.N),
-                                              float(cliprange), self.ent_coef, self.vf_coef, _lib.ptr(self.grads),
-                                              _lib.ptr(stats[k]), _lib.ptr(self.dm.workspace), self.dm.workspace.numel(),
-                                              self.dm.chunk, st), 'mrl_model_grad')
-                _lib.check(lib.mrl_adam_clip_step_dev(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
-                                                      _lib.ptr(self.adam_v), P, _lib.ptr(alpha[k:k + 1]), float(self.beta1),
-                                                      float(self.beta2), float(self.epsilon), mgn, float(self.total_weight),
-                                                      _lib.ptr(self._gnorm), _lib.ptr(self._scratch), st),
-                           'mrl_adam_clip_step_dev')
+                _lib.check(lib.mrl_model_train_step(
+                    self.dm.handle, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
+                    _lib.ptr(rollout.obs), _lib.ptr(rollout.actions), _lib.ptr(rollout.returns), _lib.ptr(rollout.values),
+                    _lib.ptr(rollout.neglogpacs), _lib.ptr(idx[k]), B, int(rollout.T), int(rollout.N), float(cliprange),
+                    self.ent_coef, self.vf_coef, 0.0, _lib.ptr(alpha[k:k + 1]), float(self.beta1), float(self.beta2),
+                    float(self.epsilon), mgn, float(self.total_weight), _lib.ptr(stats[k]), _lib.ptr(self._gnorm),
+                    _lib.ptr(self.dm.workspace), self.dm.workspace.numel(), self.dm.chunk, st), 'mrl_model_train_step')
         return dict(key=key, graph=graph, idx=idx, alpha=alpha, stats=stats)
 
     def _field(self, x, dtype):

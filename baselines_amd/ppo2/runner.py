@@ -23,6 +23,12 @@ from .. import _lib, ops
 from ..common.runners import AbstractEnvRunner
 
 
+def _defines(obj, name):
+    """True when obj's OWN class (or a base of it) implements `name` -- as opposed to a VecEnvWrapper forwarding the
+    attribute lookup to the env it wraps (`VecEnvWrapper.__getattr__`), which would silently bypass the wrapper."""
+    return any(name in vars(k) for k in type(obj).__mro__)
+
+
 class Rollout(object):
     """Device-resident SoA rollout buffer (time-major)."""
 
@@ -94,7 +100,11 @@ class Runner(AbstractEnvRunner):
         self.return_host = (not self.device_env) if return_host is None else return_host
         self.fast_step = hasattr(model, 'step_into')
         self._dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=self.device)
-        self._bridge = hasattr(env, 'obs_to_device')     # unwrapped ShmemVecEnv: observations already sit in a staging slot
+        # host-env bridge only for an env whose own class provides it (an unwrapped ShmemVecEnv: its observations already
+        # sit in a staging slot); a wrapper stacked on top must see -- and may transform -- the observations itself
+        self._bridge = _defines(env, 'obs_to_device') and not self._onehot
+        # zero-copy device stepping likewise only when the env's own class writes into caller-provided buffers
+        self._env_step_into = _defines(env, 'step_into')
         self._ob_np = ob_np
         self._graph, self._graph_out, self._eager_rollouts = None, None, 0
         self._ob_clip = getattr(getattr(model, 'policy', None), 'ob_clip', None)
@@ -113,8 +123,18 @@ class Runner(AbstractEnvRunner):
             self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
             ro.dones[t].copy_(self._dones_dev)
             obs_out = ro.obs[t + 1] if t + 1 < T else nxt_last
-            _, _, _, info = self.env.step_into(ro.actions[t], obs_out=obs_out, rew_out=ro.rewards[t],
-                                               done_out=self._dones_dev)
+            if self._env_step_into:
+                _, _, _, info = self.env.step_into(ro.actions[t], obs_out=obs_out, rew_out=ro.rewards[t],
+                                                   done_out=self._dones_dev)
+            else:
+                # device-resident env behind wrappers (VecNormalize, VecFrameStack, ...): the wrapper chain runs its own
+                # kernels in step_wait(); its results are copied (device to device) into the rollout slot
+                o, r, d, info = self.env.step(ro.actions[t])
+                obs_out.copy_(o.reshape(obs_out.shape))
+                ro.rewards[t].copy_(r)
+                self._dones_dev.copy_(d.view(torch.uint8) if d.dtype == torch.bool else d)
+                if not isinstance(info, dict) or 'fin_r' not in info:
+                    info = {'fin_r': torch.zeros_like(ro.rewards[t]), 'fin_l': torch.zeros_like(ro.actions[t], dtype=torch.int32).reshape(-1)[:self.nenv]}
             fin_r.append(info['fin_r'])
             fin_l.append(info['fin_l'])
         self.obs = nxt_last
@@ -171,11 +191,11 @@ class Runner(AbstractEnvRunner):
         rewards_host = np.zeros((T, self.nenv), np.float32)
         dones_host = np.zeros((T, self.nenv), np.bool_)
         for t in range(T):
-            if self._bridge:
+            if self._onehot:
+                ro.obs[t].copy_(self.model._to_dev_obs(self.obs))
+            elif self._bridge:
                 # host-env bridge (ShmemVecEnv): asynchronous DMA from the page-locked staging slot the workers wrote
                 self.env.obs_to_device(ro.obs[t])
-            elif self._onehot:
-                ro.obs[t].copy_(self.model._to_dev_obs(self.obs))
             else:
                 obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
                 ro.obs[t].copy_(torch.from_numpy(obs_np))      # runner.py:30 snapshot, straight into HBM

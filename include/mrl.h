@@ -10,8 +10,12 @@
  *   - every pointer is a DEVICE pointer owned by the caller unless marked "host";
  *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous on it;
  *   - return value: 0 ok, >0 hipError_t, <0 argument error (MRL_E*);
- *   - no global state, no hidden allocation on the data path: scratch comes from a
- *     caller-provided workspace whose size is queried first;
+ *   - no hidden allocation on the data path: scratch comes from a caller-provided workspace whose
+ *     size is queried first.  Process-global state is limited to three opt-in tables, all documented
+ *     at the end of this header: the HIP-event profiler (mrl_prof_*), the engine options
+ *     (mrl_set_option / MRL_* environment variables, read once) and the tile-tuning overrides
+ *     (mrl_tune_set).  Calls on ONE mrl_model / mrl_comm must not race; different objects may be used
+ *     from different threads;
  *   - rollout storage is time-major SoA [T][N]; the reference's env-major flat index
  *     i = e*T + t (ppo2/runner.py:69-74 `sf01`) is translated inside the kernels, so sf01's
  *     full copy never happens.
@@ -30,6 +34,7 @@ extern "C" {
 #define MRL_EINVAL   (-1)   /* bad argument / unsupported shape */
 #define MRL_ENOSPC   (-2)   /* workspace too small */
 #define MRL_EUNSUP   (-3)   /* configuration outside the supported hot path */
+#define MRL_ECOMM    (-4)   /* RCCL error / librccl unavailable (text: mrl_comm_last_error()) */
 
 int mrl_version(void);
 const char* mrl_strerror(int code);
@@ -140,6 +145,49 @@ int mrl_adam_clip_step_dev(float* params, float* grads, float* m, float* v, long
                            float beta1, float beta2, float eps, float max_grad_norm,
                            float total_weight, float* gnorm_out, void* scratch, void* stream);
 
+/* ---- Model.train in one call --- ppo2/model.py:133-158 (advs, sess.run of stats + _train_op) with
+ * :97-114 (gradients -> [MpiAdam average] -> clip_by_global_norm -> Adam apply) ------------------
+ * = mrl_model_grad followed by mrl_adam_clip_step on the same stream, with the Adam update fed by the
+ * gradient kernels directly: on a single rank the global-norm partial sums are produced by the
+ * reductions that write the gradient (no second pass over it).  `grads` [P] is left holding the
+ * averaged, clipped gradient (`self.grads`, model.py:112).  alpha_dev != NULL: step size read from
+ * device memory (f32 [1]) so the call can sit in a captured hipGraph; else `alpha` (host f32,
+ * lr*sqrt(1-beta2^t)/(1-beta1^t)).  With a communicator attached (below) the gradient is
+ * all-reduced inside (overlapped with the backward pass); pass total_weight = sum of rank weights. */
+int mrl_model_train_step(const mrl_model* m, float* params, float* grads, float* adam_m, float* adam_v,
+                         const void* obs, const void* actions, const float* returns, const float* values,
+                         const float* neglogpacs, const int64_t* idx, int B, int T, int N, float cliprange,
+                         float ent_coef, float vf_coef, float alpha, const float* alpha_dev, float beta1,
+                         float beta2, float eps, float max_grad_norm, float total_weight, float* stats_out,
+                         float* gnorm_out, void* workspace, size_t workspace_bytes, int chunk, void* stream);
+
+/* ---- C1: data-parallel collectives over RCCL / xGMI --- common/mpi_adam_optimizer.py:18-51
+ * (`flat_grad * mpi_rank_weight` -> Allreduce(SUM) -> / total weight), common/mpi_util.py:15-26
+ * (sync_from_root).  One communicator per process (= per GPU).  Bootstrap like ncclCommInitRank: rank 0
+ * obtains a unique id (host bytes), the host program ships it to the other ranks by any means (a file,
+ * a socket, torch.distributed's store), every rank then calls mrl_comm_create with its current HIP device
+ * set.  librccl is bound lazily (dlopen) on the first of these calls. */
+#define MRL_COMM_ID_BYTES 128
+typedef struct mrl_comm mrl_comm;
+int  mrl_comm_unique_id(void* id_out /* host, MRL_COMM_ID_BYTES */);
+int  mrl_comm_create(const void* id /* host */, int nranks, int rank, mrl_comm** out);
+void mrl_comm_destroy(mrl_comm* c);
+int  mrl_comm_size(const mrl_comm* c);
+int  mrl_comm_rank(const mrl_comm* c);
+const char* mrl_comm_last_error(void);
+/* in-place sum of the flat gradient f32 [P] over all ranks, asynchronous on `stream` (mpi_adam_optimizer.py:39) */
+int mrl_allreduce_grads(mrl_comm* c, float* grads, long P, void* stream);
+/* in-place broadcast of nbytes from `root` (parameters, Adam slots; mpi_util.py:15-26), asynchronous on `stream` */
+int mrl_broadcast_state(mrl_comm* c, void* buf, size_t nbytes, int root, void* stream);
+/* Attach (comm != NULL) / detach (NULL) a communicator: afterwards mrl_model_grad, mrl_model_grad_micro and
+ * mrl_model_train_step return the rank-weighted SUM over ranks of the gradient.  The all-reduce is issued from
+ * inside the backward pass on the communicator's own stream -- the tail of the flat gradient (fc1 + heads, 95 % of
+ * NatureCNN's parameters) as soon as fc1's weight gradient is complete, the rest at the end -- and the compute
+ * stream is made to wait for it before the call returns (stream order; no host synchronisation).  The division by
+ * the total weight happens in the optimizer step (`total_weight`), before the global norm, like
+ * mpi_adam_optimizer.py:40.  Loss statistics stay rank-local like the reference's. */
+int mrl_model_attach_comm(mrl_model* m, mrl_comm* comm, float rank_weight);
+
 /* ---- K13: HBM replay ring --- deepq/replay_buffer.py:24-43 ----------------------------------
  * SoA ring buffers [maxsize][...]: obs_t / obs_tp1 raw bytes (ob_bytes per transition), act int32,
  * rew f32, done f32.  insert: rows (next_idx + j) % maxsize, j < n, from contiguous batches.
@@ -240,10 +288,17 @@ int mrl_tune_set(const char* label, int variant);
 /* Engine options (process-wide; defaults also settable through the environment variable in brackets):
  *   "u8_bf16x3"  [MRL_U8_BF16X3, 1]  first conv layer (uint8 pixels) on the bf16 pipe with an exact 3-way
  *                  bf16 split of the other operand; 0 = fp32 MFMA (bitwise fmaf chain)
+ *   "f32_bf16x6" [MRL_F32_BF16X6, 2]  fp32 x fp32 GEMM sites that run on the bf16 pipe with both operands split
+ *                  exactly into 3 bf16 planes: 2 = eight products per multiply (what is dropped is < 2^-29 of a
+ *                  product, below one fp32 rounding: the default), 1 = six products (< 2^-21), 0 = fp32 MFMA
+ *   "dgrad_x6"   [MRL_DGRAD_X6, 1]  conv data gradients on the tiled split engine (position-major tiles);
+ *                  0 = LDS-resident fp32-MFMA engine
+ *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
- *   "defer_mask" [MRL_DEFER_MASK, 0], "imgres_nacc", "mlp_dbg": experiment knobs
- * Returns MRL_EINVAL for unknown names. */
+ *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg": experiment knobs
+ * Returns MRL_EINVAL for unknown names.  mrl_get_option reports the value in effect. */
 int mrl_set_option(const char* name, int value);
+int mrl_get_option(const char* name, int* value_out);
 
 #ifdef __cplusplus
 }
