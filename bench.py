@@ -6,40 +6,67 @@ reference Atari hyper-parameters (ppo2/defaults.py:15-22: noptepochs=4, nminibat
 ent_coef=0.01, cliprange=0.1, lr=2.5e-4).  BASELINE.json metric; SURVEY.md 8(d) "update-only".
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: launched by torch.distributed.run, one rank per GPU; num_envs is SHARDED over ranks:
-     strong scaling, one RCCL all-reduce of the 6.75 MB flat gradient per minibatch step)
 
-A "step" = one update over num_envs*nsteps env-steps.  Data: synthetic (device-resident counter-hash
-env; rollout filled by one real Runner.run()).  Prints ONE JSON line on rank 0.
+N>1: one rank per GPU over RCCL.  Either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or directly -- without WORLD_SIZE the script re-launches itself through torch.distributed.run with N
+ranks on this node.  num_envs is SHARDED over the ranks (strong scaling); the flat 6.75 MB gradient is all-reduced once
+per minibatch step by libmrl.so itself (mrl_comm, issued from inside the backward pass on a communication stream).
+
+A "step" = one update over num_envs*nsteps env-steps.  Data: synthetic (device-resident counter-hash env; rollout
+filled by real Runner.run() calls).  Prints ONE JSON line on rank 0; with one GPU and default arguments the line also
+carries short measurements of BASELINE.json's other single-GPU configurations under "other_configs".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA
-# kernels that run fp32-class products on the bf16 pipe as N exact bf16 products per multiply (DESIGN.md 3.1):
-# their ceiling in algorithmic (fp32-equivalent) flops is the bf16 peak / N
-SPLIT_PRODUCTS = {'c1.fwd': 3, 'c1.wgrad': 3, 'c2.fwd': 6, 'c3.fwd': 6, 'fc1.fwd': 6, 'fc1.dgrad': 6}
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(kind, cores_hint=None):
+def _relaunch(args):
+    """`python bench.py --gpus N` with no launcher around it: become the launcher (one rank per GPU of this node)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def host_cpu():
+    model = None
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def cpu_baseline(kind):
     """The oracle (CPU port of the reference path: NumPy GAE / shuffle / gather / adv-norm +
     torch-CPU restatement of the TF graph, all host cores like the reference's TF session,
     tf_util.py:58-66) timed on a BOUNDED sample of the same workload: one full update at
     num_envs=128 (Atari) / 256 (MuJoCo-shaped), capped at ~20 s, same nsteps / epochs / minibatches."""
+    import numpy as np
+    import torch
     from oracle import ppo2_numpy as O
     from oracle.ppo2_torch import OracleModel
-    ncpu = os.cpu_count() or 1
+    ncpu, cpu_model = host_cpu()
     if kind == 'atari':
         N, T, E, M = 128, 128, 4, 4
         net = dict(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6,
@@ -89,70 +116,87 @@ def cpu_baseline(kind, cores_hint=None):
     # env-steps/s of a whole update, extrapolated from the minibatch steps that fit in the time budget
     frac = done_steps / float(E * M)
     return {'value': N * T * frac / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'host_cpu_count': ncpu, 'host_cpu_model': cpu_model,
             'sample': 'PPO2 update at num_envs=%d nsteps=%d: GAE + sf01 + %d of its %dx%d minibatch steps (%.1f s of CPU '
                       'work, scaled to a whole update); oracle = reference NumPy path + torch-CPU fp32 restatement '
-                      'of the TF graph, %d torch threads' % (N, T, done_steps, E, M, dt, cores)}
+                      'of the TF graph, %d torch threads (fastest of the counts probed on this %d-thread host)'
+                      % (N, T, done_steps, E, M, dt, cores, ncpu)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='atari', choices=['atari', 'mujoco'])
-    ap.add_argument('--num-envs', type=int, default=None, help='whole-job num_envs (default 4096 atari / 1024 mujoco)')
-    ap.add_argument('--nsteps', type=int, default=128)
-    ap.add_argument('--chunk', type=int, default=None)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-prof', action='store_true', help='do not record HIP events per kernel in the timed region')
-    args = ap.parse_args()
+def arithmetic_mode(_lib):
+    """which arithmetic the GEMM sites of the NatureCNN update run in (engine options in effect, include/mrl.h)"""
+    x3, x6, dg = _lib.get_option('u8_bf16x3'), _lib.get_option('f32_bf16x6'), _lib.get_option('dgrad_x6')
+    nprod = {0: 0, 1: 6, 2: 8}[x6]
+    sites = {}
+    for s in ('c1.fwd', 'c1.wgrad'):
+        sites[s] = 3 if x3 else 0
+    for s in ('c2.fwd', 'c3.fwd', 'fc1.fwd', 'fc1.dgrad'):
+        sites[s] = nprod
+    for s in ('c2.dgrad', 'c3.dgrad'):
+        sites[s] = nprod if dg else 0
+    for s in ('c2.wgrad', 'c3.wgrad', 'fc1.wgrad'):
+        sites[s] = 0
+    text = ('fp32 storage, fp32 accumulation, every product at least as accurate as an IEEE fp32 multiply. '
+            'fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise fmaf chain): %s. '
+            'bf16 MFMA on EXACT operand splits -- uint8 pixels x 3 exact bf16 planes of the other operand (3 products, '
+            'exact): %s; fp32 x fp32 with both operands split into 3 exact bf16 planes, %d of the 9 partial products '
+            'kept (dropped part < 2^-%d of a product; one fp32 rounding is 2^-24): %s.'
+            % (', '.join(k for k, v in sites.items() if v == 0) or '-',
+               ', '.join(k for k, v in sites.items() if v == 3) or '-', nprod, 29 if nprod == 8 else 21,
+               ', '.join(k for k, v in sites.items() if v >= 6) or '-'))
+    short = {0: 'f32-mfma', 1: 'bf16x6-split', 2: 'bf16x8-split'}[x6]
+    return sites, text, short
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # one process per GPU over RCCL ("nccl" on ROCm).  MRL_BENCH_BACKEND=gloo lets the N>1 code path be
-        # smoke-tested on a box with fewer GPUs than ranks (ranks then share devices; not a measurement).
-        backend = os.environ.get('MRL_BENCH_BACKEND', 'nccl')
-        dev = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(dev)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)' % (args.gpus, world)
 
-    from baselines_amd import _lib
+def kernel_rooflines(prof, sites):
+    """per launch site: achieved algorithmic TFLOP/s (or GB/s) over the HIP-event time inside the timed region, against the
+    peak of the pipe THAT kernel ran on"""
+    out = {}
+    for k, v in prof.items():
+        if not v['count'] or v['ms'] <= 0:
+            continue
+        avg_s = v['ms'] / v['count'] * 1e-3
+        if v['flops'] > 0:
+            nprod = sites.get(k, 0)
+            peak = PEAK_BF16_MFMA_TFLOPS / nprod if nprod else PEAK_F32_MFMA_TFLOPS
+            ach = v['flops'] / v['count'] / avg_s / 1e12
+            out[k] = {'bound': 'mfma', 'pipe': ('bf16 MFMA / %d exact products per multiply' % nprod) if nprod else 'fp32 MFMA',
+                      'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'avg_ms': avg_s * 1e3,
+                      'launches': v['count']}
+        elif v['bytes'] > 0:
+            ach = v['bytes'] / v['count'] / avg_s / 1e9
+            out[k] = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
+                      'avg_ms': avg_s * 1e3, 'launches': v['count']}
+    return out
+
+
+def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, want_prof):
+    """-> dict with value / timing / roofline pieces of one PPO2-update measurement"""
+    import numpy as np
+    import torch
+    from baselines_amd import _lib, ops
     from baselines_amd.common import set_global_seeds
-    from baselines_amd.common.dist import default_comm
     from baselines_amd.common.policies import build_policy
     from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
     from baselines_amd.ppo2 import Model, Runner
 
-    if args.workload == 'atari':
-        total_envs = args.num_envs or 4096
+    if workload == 'atari':
         hp = dict(noptepochs=4, nminibatches=4, ent_coef=0.01, lr=2.5e-4, cliprange=0.1, network='cnn', value_network=None)
         flops_per_sample_visit = 49.526e6      # SURVEY.md App. B (fwd+bwd)
     else:
-        total_envs = args.num_envs or 1024
         hp = dict(noptepochs=10, nminibatches=32, ent_coef=0.0, lr=3e-4, cliprange=0.2, network='mlp', value_network='copy')
         flops_per_sample_visit = 248.6e3
     assert total_envs % world == 0
     N = total_envs // world
-    T = args.nsteps
     nbatch = N * T
     nbatch_train = nbatch // hp['nminibatches']
 
     set_global_seeds(0)
-    env = SyntheticVecEnv(args.workload, N, seed=1000 + rank)
+    env = SyntheticVecEnv(workload, N, seed=1000 + rank)
     policy = build_policy(env, hp['network'], value_network=hp['value_network'])
     model = Model(policy=policy, ob_space=env.observation_space, ac_space=env.action_space, nbatch_act=N,
                   nbatch_train=nbatch_train, nsteps=T, ent_coef=hp['ent_coef'], vf_coef=0.5, max_grad_norm=0.5,
-                  comm=default_comm(), chunk=args.chunk)
+                  comm=comm, chunk=chunk)
     runner = Runner(env=env, model=model, nsteps=T, gamma=0.99, lam=0.95, return_host=False)
 
     def sync():
@@ -173,8 +217,6 @@ def main():
     ro = runner.rollout
     last_values = model.value_dev(runner.obs)
 
-    from baselines_amd import ops
-
     def update():
         """the PPO2 update (ppo2.py:142 GAE part + :154-166)"""
         ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
@@ -189,22 +231,22 @@ def main():
     # The launch-bound MLP workload runs each epoch as one replayed hipGraph (Model.train_epoch); HIP events cannot be
     # recorded inside a graph, so there the per-kernel times come from one extra, untimed, eager update after the
     # timed region.  The Atari workload (the metric) launches every kernel individually: events sit inside the timed region.
-    graph_mode = (args.workload == 'mujoco' and world == 1 and os.environ.get('MRL_EPOCH_GRAPH', '1') != '0')
-    for _ in range(args.warmup):
+    graph_mode = (workload == 'mujoco' and world == 1 and os.environ.get('MRL_EPOCH_GRAPH', '1') != '0')
+    for _ in range(warmup):
         update()
     if graph_mode:
         update()                                   # the first update after the eager warm-up captures; keep that out too
-    if not args.no_prof and not graph_mode:
+    if want_prof and not graph_mode:
         _lib.prof_enable(True)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         lossvals = update()
     sync()
     dt = time.perf_counter() - t0
     prof = {}
-    prof_steps = args.steps
-    if not args.no_prof:
+    prof_steps = steps
+    if want_prof:
         if graph_mode:
             _lib.prof_enable(True)
             update()
@@ -219,76 +261,177 @@ def main():
         dt = float(tt.item())
     lossvals = lossvals.cpu().numpy()
     assert np.all(np.isfinite(lossvals)), lossvals
+    res = dict(value=total_envs * T * steps / dt, dt=dt, t_rollout=t_rollout, loss=[float(x) for x in lossvals], prof=prof,
+               prof_steps=prof_steps, hp=hp, N=N, nbatch_train=nbatch_train, chunk=model.dm.chunk, graph_mode=graph_mode,
+               model_tflops=flops_per_sample_visit * total_envs * T * hp['noptepochs'] * steps / dt / 1e12,
+               native_dp=bool(getattr(model, 'native_dp', False)))
+    del runner, model, env, ro
+    torch.cuda.empty_cache()
+    return res
+
+
+def dominant_roofline(res, sites, workload):
+    """roofline object of the kernel with the largest share of the timed region"""
+    prof = res['prof']
+    if not prof:
+        return None, {}
+    per = kernel_rooflines(prof, sites if workload == 'atari' else {})
+    tot_ms = sum(v['ms'] for v in prof.values())
+    dom = max(per, key=lambda k: prof[k]['ms'])
+    roof = dict(per[dom])
+    roof['kernel'] = dom
+    roof['traffic'] = None
+    roof['share_of_kernel_time'] = prof[dom]['ms'] / tot_ms
+    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process; they
+    # come from the committed `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over one epoch of the same shape
+    # (scripts/pmc_epoch.sh -> profiles/*_pmc_hbm.json, gfx950 corrections applied by scripts/pmc_to_json.py)
+    if workload == 'atari' and res['nbatch_train'] == 131072:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')))
+        if cand:
+            with open(cand[-1]) as fh:
+                pm = json.load(fh)
+            if dom in pm.get('per_launch', {}):
+                roof['traffic'] = pm['per_launch'][dom]['hbm_bytes']
+                roof['traffic_source'] = 'profiles/' + os.path.basename(cand[-1])
+    return roof, per
+
+
+def replay_config():
+    """config 5 (DQN slice): scripts/bench_replay.py in a child process (its 56 GB ring is freed with the process)"""
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'bench_replay.py')], capture_output=True,
+                             text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+        r = json.loads(line)
+    except Exception as exc:          # reported, never silently dropped
+        return {'workload': 'deepq replay 1M transitions', 'error': repr(exc)}
+    b = r.get('batch_4096', {})
+    g = b.get('replay_gather', {})
+    return {'workload': 'deepq Pong-shaped replay, 1M transitions resident in HBM, prioritized sampling + TD kernel',
+            'metric': 'sampled transitions/s (learner step: PER sample + gather + TD + priority update, batch 4096)',
+            'value': 4096 / (b['wall_us_per_learner_step'] * 1e-6) if b else None, 'unit': 'transitions/s',
+            'roofline': ({'bound': 'hbm', 'kernel': 'replay_gather', 'achieved': g.get('GB/s'), 'peak': PEAK_HBM_GBS,
+                          'unit': 'GB/s', 'frac': (g.get('GB/s') or 0) / PEAK_HBM_GBS, 'traffic': None} if g else None),
+            'detail': r}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='atari', choices=['atari', 'mujoco'])
+    ap.add_argument('--num-envs', type=int, default=None, help='whole-job num_envs (default 4096 atari / 1024 mujoco)')
+    ap.add_argument('--nsteps', type=int, default=128)
+    ap.add_argument('--chunk', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not record HIP events per kernel in the timed region')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configs')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        _relaunch(args)
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    comm, collective, observed_world = None, None, 1
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # one process per GPU over RCCL ("nccl" on ROCm).  MRL_BENCH_BACKEND=gloo lets the N>1 code path be
+        # smoke-tested on a box with fewer GPUs than ranks (ranks then share devices; not a measurement).
+        backend = os.environ.get('MRL_BENCH_BACKEND', 'nccl')
+        ndev = torch.cuda.device_count()
+        if backend == 'nccl' and ndev < world:
+            raise SystemExit('--gpus %d but only %d HIP devices are visible' % (world, ndev))
+        dev = local_rank % max(1, ndev)
+        torch.cuda.set_device(dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        else:
+            dist.init_process_group(backend)
+        observed_world = dist.get_world_size()
+        from baselines_amd.common.dist import Comm
+        comm = Comm()
+        collective = 'torch.distributed all_reduce (%s), after the backward pass' % backend
+        if backend == 'nccl' and os.environ.get('MRL_NATIVE_COMM', '1') != '0':
+            ok, why = 1, ''
+            try:
+                comm.enable_native()
+            except Exception as exc:           # every rank must take the same path: agree on the outcome below
+                ok, why = 0, repr(exc)
+            flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                collective = ('in-library RCCL (mrl_comm): fc1+heads slice all-reduced on a communication stream while the '
+                              'conv layers are back-propagated, rest at the end; / total weight, clip, Adam replicated')
+            else:
+                comm.native = None
+                collective += ' [in-library RCCL communicator unavailable on some rank: %s]' % why
+    else:
+        torch.cuda.set_device(0)
+
+    from baselines_amd import _lib
+    sites, arith_text, arith_short = arithmetic_mode(_lib)
+    total_envs = args.num_envs or (4096 if args.workload == 'atari' else 1024)
+    T = args.nsteps
+    res = run_ppo2(args.workload, total_envs, T, args.steps, args.warmup, args.chunk, world, rank, comm, not args.no_prof)
 
     if rank == 0:
-        value = total_envs * T * args.steps / dt
-        # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
-        roof = None
-        if prof:
-            tot_ms = sum(v['ms'] for v in prof.values())
-            dom = max(prof, key=lambda k: prof[k]['ms'])
-            d = prof[dom]
-            if d['flops'] > 0:
-                ach = d['flops'] / d['count'] / (d['ms'] / d['count'] * 1e-3) / 1e12
-                nprod = SPLIT_PRODUCTS.get(dom) if args.workload == 'atari' else None
-                peak = PEAK_BF16_MFMA_TFLOPS / nprod if nprod else PEAK_F32_MFMA_TFLOPS
-                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': peak,
-                        'pipe': ('bf16 MFMA, %d exact bf16 products per fp32 multiply' % nprod) if nprod else 'fp32 MFMA',
-                        'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-                        'launches': d['count'], 'avg_ms': d['ms'] / d['count'],
-                        'share_of_kernel_time': d['ms'] / tot_ms}
-            else:
-                ach = d['bytes'] / d['count'] / (d['ms'] / d['count'] * 1e-3) / 1e9
-                roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'launches': d['count'],
-                        'avg_ms': d['ms'] / d['count'], 'share_of_kernel_time': d['ms'] / tot_ms}
-            # HBM-side bytes per launch of the dominant kernel from the committed PMC passes of the same shape
-            # (profiles/*_pmc_hbm.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, gfx950 corrections applied
-            # by scripts/pmc_to_json.py); PMC counters cannot be collected from inside this process
-            if args.workload == 'atari' and N * T // hp['nminibatches'] == 131072:
-                import glob
-                cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_pmc_hbm.json')))
-                if cand:
-                    with open(cand[-1]) as fh:
-                        per = json.load(fh).get('per_launch', {})
-                    if dom in per:
-                        roof['traffic'] = per[dom]['hbm_bytes']
-                        roof['traffic_source'] = 'profiles/' + os.path.basename(cand[-1])
-            gemm_ms = sum(v['ms'] for v in prof.values() if v['flops'] > 0)
-            gemm_fl = sum(v['flops'] for v in prof.values() if v['flops'] > 0)
-            roof['all_gemm_tflops'] = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
-            roof['gemm_share_of_kernel_time'] = gemm_ms / tot_ms
+        hp = res['hp']
+        roof, per = dominant_roofline(res, sites, args.workload)
         out = {
             'metric': 'env-steps/sec (whole node) PPO2 update, num_envs=%d nsteps=%d' % (total_envs, T),
-            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'value': res['value'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': res['dt'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'ppo2 update-only (GAE + %dx%d minibatch steps) %s-shaped %s num_envs=%d nsteps=%d'
                                    % (hp['noptepochs'], hp['nminibatches'], args.workload, hp['network'], total_envs, T),
-                       'envs_per_gpu': N, 'nbatch_train_per_gpu': nbatch_train, 'chunk': model.dm.chunk,
-                       'arithmetic': 'fp32 storage and fp32 accumulation everywhere. Weight gradients of conv2/conv3/fc1 and the conv '
-                                     'data gradients: fp32 MFMA (bitwise fmaf chain). conv1 forward + weight gradient: exact uint8 '
-                                     'pixels x 3-way exact bf16 split of the other operand on the bf16 pipe. conv2/conv3/fc1 forward '
-                                     'and fc1 data gradient: both operands split exactly into 3 bf16 planes, the 6 products >= 2^-16 '
-                                     'kept (dropped terms < 2^-21 of a product worst case, 4e-8 on average = 2x the rounding of one fp32 multiply): fp32-class results, parity tests unchanged; '
-                                     'MRL_F32_BF16X6=0 / MRL_U8_BF16X3=0 select the all-fp32-MFMA paths',
-                       'parallelism': 'dp%d (envs sharded, 1 RCCL all-reduce/minibatch)' % world},
-            'model_tflops': flops_per_sample_visit * total_envs * T * hp['noptepochs'] * args.steps / dt / 1e12,
-            'full_iteration_env_steps_per_s': total_envs * T / (t_rollout + dt / args.steps),
-            'rollout_s': t_rollout,
-            'loss': [float(x) for x in lossvals],
+                       'envs_per_gpu': res['N'], 'nbatch_train_per_gpu': res['nbatch_train'], 'chunk': res['chunk'],
+                       'arithmetic_mode': arith_short, 'arithmetic': arith_text,
+                       'parallelism': 'dp%d (envs sharded, 1 all-reduce of the flat gradient per minibatch step)' % world,
+                       'world_size_observed': observed_world, 'collective': collective},
+            'model_tflops': res['model_tflops'],
+            'full_iteration_env_steps_per_s': total_envs * T / (res['t_rollout'] + res['dt'] / args.steps),
+            'rollout_s': res['t_rollout'],
+            'loss': res['loss'],
             'roofline': roof,
         }
-        if graph_mode:
+        if res['graph_mode']:
             out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps); kernel times from a separate eager update'
-        if prof:
-            out['kernel_ms_per_step'] = {k: round(v['ms'] / prof_steps, 3) for k, v in
-                                         sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
+        if res['prof']:
+            out['kernel_ms_per_step'] = {k: round(v['ms'] / res['prof_steps'], 3) for k, v in
+                                         sorted(res['prof'].items(), key=lambda kv: -kv[1]['ms'])}
+            out['kernel_rooflines'] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                                       for k, v in per.items()}
+        default_run = (world == 1 and args.workload == 'atari' and args.num_envs is None and args.nsteps == 128
+                       and args.chunk is None)
+        if default_run and not args.no_other_configs:
+            # BASELINE.json's other single-GPU configurations, short runs (3 timed updates each), own rooflines
+            others = []
+            for wl, n_envs in (('mujoco', 1024), ('atari', 256)):
+                r = run_ppo2(wl, n_envs, 128, 3, 1, None, 1, 0, None, not args.no_prof)
+                rf, _ = dominant_roofline(r, sites, wl)
+                others.append({'workload': 'ppo2 update-only %s-shaped %s num_envs=%d nsteps=128'
+                                           % (wl, r['hp']['network'], n_envs),
+                               'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['dt'] / 3 * 1e3, 'steps': 3,
+                               'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / 3),
+                               'roofline': rf,
+                               'kernel_ms_per_step': {k: round(v['ms'] / r['prof_steps'], 3) for k, v in
+                                                      sorted(r['prof'].items(), key=lambda kv: -kv[1]['ms'])}})
+            others.append(replay_config())
+            out['other_configs'] = others
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -254,61 +254,72 @@ def test_adam_clip_matches_oracle_many_steps():
 def test_engine_options_agree():
     """The fast engines against their plain counterparts on the same minibatch:
        * first conv layer on the bf16 pipe (exact u8 x 3-way bf16 split) vs the fp32 MFMA path,
-       * conv2/conv3/fc1 forward and fc1 data gradient on the bf16 pipe (both operands split into 3 exact bf16 planes,
-         6 products) vs the fp32 MFMA paths (batch >= 1024 so that the tiled split engine takes the fc layer),
+       * conv2/conv3/fc1 forward and the conv2/conv3/fc1 data gradients on the bf16 pipe (both operands split into 3 exact
+         bf16 planes, 8 or 6 products per multiply) vs the fp32 MFMA paths (batch >= 1024 so that the tiled split engine
+         takes the fc layer),
+       * conv data gradients on the position-major tiled engine vs the LDS-resident fp32-MFMA engine,
        * fused whole-step MLP kernel vs layer-wise launches.
-    Gradients agree to fp32 round-off (the split products are exact; only the summation order and the
-    folded 1/255 scale differ), well inside the 1e-5 loss-parity bar."""
+    Gradients agree to fp32 round-off on EVERY entry (the split products are exact; only the summation order and the
+    folded 1/255 scale differ).  The large-batch case runs on a minibatch screened by the fp64 oracle for ReLU margins
+    (tests/test_gpu_large_batch.py): with a thousand samples a few pre-activations otherwise land within round-off of
+    the kink and switch on in one engine and off in the other, which is a property of ReLU, not of an engine."""
     from baselines_amd import _lib as L
     from baselines_amd import ops
-    rng = np.random.RandomState(0)
+    from tests.test_gpu_large_batch import _problem
 
-    def grads(network, ob_shape, ob_dtype, pd_kind, nact, value_copy, B, opt, val):
-        L.set_option(opt, val)
+    def grads(network, ob_shape, ob_dtype, pd_kind, nact, value_copy, B, opts, screened=None):
+        for o, v in opts.items():
+            L.set_option(o, v)
         dm = ops.DeviceModel(network=network, ob_shape=ob_shape, ob_dtype=ob_dtype, pd_kind=pd_kind, nact=nact,
                              value_copy=value_copy, chunk=B)
         r = np.random.RandomState(1)
-        params = torch.from_numpy((r.randn(dm.P) * 0.05).astype(np.float32)).cuda()
-        if ob_dtype == np.uint8:
-            obs = torch.from_numpy(r.randint(0, 256, (B,) + ob_shape).astype(np.uint8)).cuda()
+        if screened is not None:
+            om, _, mb = screened
+            params = dev(om.flat_params().astype(np.float32))
+            obs, act = dev(mb['obs']), dev(mb['actions'].astype(np.int32))
+            ret, val_, nlp = dev(mb['returns']), dev(mb['values']), dev(mb['neglogpacs'])
         else:
-            obs = torch.from_numpy(r.randn(B, *ob_shape).astype(np.float32)).cuda()
-        if pd_kind == 'categorical':
-            act = torch.from_numpy(r.randint(0, nact, B).astype(np.int32)).cuda()
-        else:
-            act = torch.from_numpy(r.randn(B, nact).astype(np.float32)).cuda()
-        ret, val_, nlp = (torch.from_numpy(r.randn(B).astype(np.float32)).cuda() for _ in range(3))
-        nlp = nlp.abs() + 1.0
+            params = torch.from_numpy((r.randn(dm.P) * 0.05).astype(np.float32)).cuda()
+            if ob_dtype == np.uint8:
+                obs = torch.from_numpy(r.randint(0, 256, (B,) + ob_shape).astype(np.uint8)).cuda()
+            else:
+                obs = torch.from_numpy(r.randn(B, *ob_shape).astype(np.float32)).cuda()
+            if pd_kind == 'categorical':
+                act = torch.from_numpy(r.randint(0, nact, B).astype(np.int32)).cuda()
+            else:
+                act = torch.from_numpy(r.randn(B, nact).astype(np.float32)).cuda()
+            ret, val_, nlp = (torch.from_numpy(r.randn(B).astype(np.float32)).cuda() for _ in range(3))
+            nlp = nlp.abs() + 1.0
         g = torch.empty(dm.P, dtype=torch.float32, device='cuda')
         st = torch.empty(5, dtype=torch.float32, device='cuda')
         dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
         return g.cpu().numpy(), st.cpu().numpy()
 
+    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6')}
+    assert defaults['f32_bf16x6'] == 2, 'the default arithmetic of the split engines is the 8-product mode'
     try:
-        for net, shp, dt, pd, na, vc, B, opt in [('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False, 160, 'u8_bf16x3'),
-                                                 ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False, 1152, 'f32_bf16x6'),
-                                                 ('mlp', (376,), np.float32, 'gaussian', 17, True, 200, 'mlp_fused'),
-                                                 ('mlp', (4,), np.float32, 'categorical', 2, False, 96, 'mlp_fused')]:
-            for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused'):
-                L.set_option(o, 1)                      # every case starts from the defaults
-            g1, s1 = grads(net, shp, dt, pd, na, vc, B, opt, 1)
-            g0, s0 = grads(net, shp, dt, pd, na, vc, B, opt, 0)
-            if opt == 'f32_bf16x6':                     # value 2: eight products per multiply (x1w2, x2w1 kept too)
-                g2, s2 = grads(net, shp, dt, pd, na, vc, B, opt, 2)
-                assert np.percentile(np.abs(g2 - g0), 99.0) <= 1e-5 * np.abs(g0).max() + 1e-9
-                np.testing.assert_allclose(s2, s0, rtol=1e-5, atol=1e-6)
+        cnn = ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False)
+        # ---- small batches: plain random data
+        for cfg, B, opt in [(cnn, 160, 'u8_bf16x3'), (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused'),
+                            (('mlp', (4,), np.float32, 'categorical', 2, False), 96, 'mlp_fused')]:
+            g1, s1 = grads(*cfg, B, dict(defaults, **{opt: 1}))
+            g0, s0 = grads(*cfg, B, dict(defaults, **{opt: 0}))
             scale = np.abs(g0).max()
-            diff = np.abs(g1 - g0)
-            if B < 1000:
-                assert diff.max() <= 2e-6 * scale + 1e-9, (opt, diff.max(), scale)
-            else:
-                # a thousand samples put a few pre-activations within round-off of the ReLU kink: the unit switches on in
-                # one engine and off in the other (measured: 1 of 590k fc1 units), which moves that sample's gradient
-                # rows by ~1e-4 of the scale and, through the conv weight gradients (sums over all samples), everything a little.
-                assert np.percentile(diff, 99.0) <= 1e-5 * scale + 1e-9, (opt, np.percentile(diff, 99.0), scale)
-                assert np.linalg.norm(g1 - g0) <= 1e-3 * np.linalg.norm(g0), (opt, np.linalg.norm(g1 - g0), np.linalg.norm(g0))
+            assert np.abs(g1 - g0).max() <= 2e-6 * scale + 1e-9, (opt, np.abs(g1 - g0).max(), scale)
+            np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
+        # ---- B = 1152 (tiled split engines everywhere they apply), screened minibatch: every entry
+        B = 1152
+        scr = _problem(B, 21)
+        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0)                 # all fp32 x fp32 sites on the fp32 MFMA pipe
+        g0, s0 = grads(*cnn, B, ref_opts, scr)
+        scale = np.abs(g0).max()
+        for name, opts, tol in [('8 products (default)', dict(defaults), 3e-6),
+                                ('6 products', dict(defaults, f32_bf16x6=1), 6e-6),
+                                ('8 products, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6)]:
+            g1, s1 = grads(*cnn, B, opts, scr)
+            d = np.abs(g1 - g0)
+            assert d.max() <= tol * scale + 1e-9, (name, d.max(), scale, int(d.argmax()))
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
     finally:
-        L.set_option('u8_bf16x3', 1)
-        L.set_option('f32_bf16x6', 1)
-        L.set_option('mlp_fused', 1)
+        for o, v in defaults.items():
+            L.set_option(o, v)

@@ -1,0 +1,174 @@
+"""Pins of the TF half of the oracle (oracle/ppo2_torch.py) by the only statements of that mathematics the
+reference itself holds outside TensorFlow:
+
+  * the NumPy Adam of common/mpi_adam.py:38-41, which the reference's own `test_MpiAdam` (:64-99) proves equal to
+    tf.train.AdamOptimizer over 10 steps within 1e-4 -- restated verbatim below and run against
+    `OracleModel.apply_flat_grad` on the very problem of that test (a [3] and a [2,5] variable,
+    loss = sum(a^2) + sum(sin(b)), stepsize 1e-2);
+  * the statistical identities of common/distributions.py:320-348 `validate_probtype` on the fixed pdparams of
+    `test_probtypes` (:303-311): entropy == -E[log p] and KL[p,q] == -H[p] - E_p[log q], N = 100,000, 3 sigma --
+    run against the oracle's `_neglogp` / `_entropy` (the formulas its loss uses) and the reference's kl() formulas.
+
+(The same identities are checked on the GPU kernels in tests/test_gpu_probtypes.py.)
+"""
+import math
+
+import numpy as np
+import torch
+
+from oracle.ppo2_torch import OracleModel
+
+
+# ---- common/mpi_adam.py:26-42, comm=None branch, verbatim arithmetic (float32 state, python-float hyper-parameters)
+class _RefNumpyAdam(object):
+    def __init__(self, size, beta1=0.9, beta2=0.999, epsilon=1e-08):
+        self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
+        self.m = np.zeros(size, 'float32')
+        self.v = np.zeros(size, 'float32')
+        self.t = 0
+
+    def update(self, theta, localg, stepsize):
+        localg = localg.astype('float32')
+        globalg = np.copy(localg)
+        self.t += 1
+        a = stepsize * np.sqrt(1 - self.beta2 ** self.t) / (1 - self.beta1 ** self.t)
+        self.m = self.beta1 * self.m + (1 - self.beta1) * globalg
+        self.v = self.beta2 * self.v + (1 - self.beta2) * (globalg * globalg)
+        step = (- a) * self.m / (np.sqrt(self.v) + self.epsilon)
+        return theta + step
+
+
+def _tiny_oracle():
+    """an OracleModel whose optimizer state is hijacked onto the two variables of test_MpiAdam"""
+    om = OracleModel(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind='categorical', nact=2, max_grad_norm=None)
+    np.random.seed(0)
+    a = np.random.randn(3).astype('float32')
+    b = np.random.randn(2, 5).astype('float32')
+    om.names = ['a', 'b']
+    om.p = {'a': torch.tensor(a, requires_grad=True), 'b': torch.tensor(b, requires_grad=True)}
+    om.m = {k: torch.zeros_like(v) for k, v in om.p.items()}
+    om.v = {k: torch.zeros_like(v) for k, v in om.p.items()}
+    om.eps = np.float32(1e-8)                       # tf.train.AdamOptimizer default of that test (ppo2 passes 1e-5)
+    return om, a, b
+
+
+def test_oracle_adam_equals_reference_numpy_adam_on_the_reference_test_problem():
+    om, a, b = _tiny_oracle()
+    stepsize = 1e-2
+    ref = _RefNumpyAdam(a.size + b.size)
+    theta = np.concatenate([a.reshape(-1), b.reshape(-1)])
+    losses_ref, losses_om = [], []
+    for i in range(10):
+        # reference side: loss and flat gradient of sum(a^2) + sum(sin(b)) at theta
+        ta, tb = theta[:3], theta[3:]
+        losses_ref.append(float(np.sum(np.square(ta)) + np.sum(np.sin(tb))))
+        g = np.concatenate([2 * ta, np.cos(tb)]).astype('float32')
+        theta = ref.update(theta, g, stepsize).astype('float32')
+        # oracle side: autograd gradient of the same loss, then its TF-1 ApplyAdam restatement
+        for t in om.p.values():
+            t.grad = None
+        loss = (om.p['a'] ** 2).sum() + torch.sin(om.p['b']).sum()
+        loss.backward()
+        losses_om.append(float(loss.detach()))
+        flat = torch.cat([om.p['a'].grad.reshape(-1), om.p['b'].grad.reshape(-1)])
+        om.apply_flat_grad(stepsize, flat)
+    # the reference's own bar (mpi_adam.py:99) ...
+    np.testing.assert_allclose(np.array(losses_ref), np.array(losses_om), atol=1e-4)
+    # ... and far tighter: same formula, float32 round-off only
+    np.testing.assert_allclose(om.flat_params(), theta, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(torch.cat([om.m['a'].reshape(-1), om.m['b'].reshape(-1)]).numpy(), ref.m, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(torch.cat([om.v['a'].reshape(-1), om.v['b'].reshape(-1)]).numpy(), ref.v, rtol=5e-5, atol=1e-9)      # TF holds beta2 in float32: 1 - f32(0.999) is 1.3e-5 off 1e-3
+    assert losses_ref[-1] < losses_ref[0]
+
+
+def test_oracle_adam_with_ppo2_epsilon_differs_from_default_epsilon():
+    """guards the pin above against vacuity: epsilon is where TF's Adam and torch.optim.Adam differ (not bias-corrected)"""
+    om, a, b = _tiny_oracle()
+    om2, _, _ = _tiny_oracle()
+    om2.eps = np.float32(1e-2)
+    g = torch.tensor(np.linspace(-1e-3, 1e-3, 13).astype('float32'))
+    om.apply_flat_grad(1e-2, g.clone())
+    om2.apply_flat_grad(1e-2, g.clone())
+    assert np.abs(om.flat_params() - om2.flat_params()).max() > 1e-4
+
+
+# ---- distributions.py:184-192, 242-244: the reference's kl() formulas (torch float64)
+def _kl_categorical(l0, l1):
+    a0 = l0 - l0.max(dim=-1, keepdim=True)[0]
+    a1 = l1 - l1.max(dim=-1, keepdim=True)[0]
+    ea0, ea1 = torch.exp(a0), torch.exp(a1)
+    z0, z1 = ea0.sum(-1, keepdim=True), ea1.sum(-1, keepdim=True)
+    p0 = ea0 / z0
+    return (p0 * (a0 - torch.log(z0) - a1 + torch.log(z1))).sum(-1)
+
+
+def _kl_gaussian(m0, ls0, m1, ls1):
+    s0, s1 = torch.exp(ls0), torch.exp(ls1)
+    return (ls1 - ls0 + (s0 ** 2 + (m0 - m1) ** 2) / (2.0 * s1 ** 2) - 0.5).sum(-1)
+
+
+PDPARAM_DIAG_GAUSS = np.array([-.2, .3, .4, -.5, .1, -.5, .1, 0.8])     # distributions.py:303
+PDPARAM_CATEGORICAL = np.array([-.2, .3, .5])                             # distributions.py:307
+N_SAMPLES = 100000
+
+
+def _oracle_for(pd_kind, nact):
+    return OracleModel(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind=pd_kind, nact=nact, dtype=torch.float64)
+
+
+def _validate(neglogp, entropy, kl, sample, pdparam, q):
+    """distributions.py:320-348 with the oracle's functions in the place of the TF graph"""
+    N = N_SAMPLES
+    X = sample(pdparam, N)
+    logliks = -neglogp(pdparam, X)
+    entval_ll = -logliks.mean()
+    entval_ll_stderr = logliks.std() / np.sqrt(N)
+    entval = entropy(pdparam, N).mean()
+    assert np.abs(entval - entval_ll) < 3 * entval_ll_stderr
+    klval = kl(pdparam, q, N).mean()
+    logliks = -neglogp(q, X)
+    klval_ll = -entval - logliks.mean()
+    klval_ll_stderr = logliks.std() / np.sqrt(N)
+    assert np.abs(klval - klval_ll) < 3 * klval_ll_stderr
+
+
+def test_validate_probtype_diag_gaussian_on_oracle():
+    np.random.seed(0)
+    nact = PDPARAM_DIAG_GAUSS.size // 2
+    om = _oracle_for('gaussian', nact)
+    rep = lambda v, n: torch.tensor(np.repeat(v[None, :], n, axis=0))
+
+    def with_logstd(pdparam):
+        om.p['ppo2_model/pi/logstd'] = torch.tensor(pdparam[None, nact:])
+        return rep(pdparam[:nact], N_SAMPLES)
+
+    def sample(pdparam, n):
+        mean = with_logstd(pdparam)
+        return mean + torch.exp(om.p['ppo2_model/pi/logstd']) * torch.tensor(np.random.randn(n, nact))
+
+    q = PDPARAM_DIAG_GAUSS + np.random.randn(PDPARAM_DIAG_GAUSS.size) * 0.1
+    _validate(neglogp=lambda pdp, X: om._neglogp(with_logstd(pdp), X).numpy(),
+              entropy=lambda pdp, n: om._entropy(with_logstd(pdp)).numpy(),
+              kl=lambda p, q_, n: _kl_gaussian(rep(p[:nact], n), rep(p[nact:], n), rep(q_[:nact], n), rep(q_[nact:], n)).numpy(),
+              sample=sample, pdparam=PDPARAM_DIAG_GAUSS, q=q)
+
+
+def test_validate_probtype_categorical_on_oracle():
+    np.random.seed(0)
+    nact = PDPARAM_CATEGORICAL.size
+    om = _oracle_for('categorical', nact)
+    rep = lambda v, n: torch.tensor(np.repeat(v[None, :], n, axis=0))
+
+    def sample(pdparam, n):                 # distributions.py:199-201 (Gumbel-max), as in OracleModel.step
+        u = torch.tensor(np.random.rand(n, nact))
+        return torch.argmax(rep(pdparam, n) - torch.log(-torch.log(u)), dim=-1)
+
+    q = PDPARAM_CATEGORICAL + np.random.randn(nact) * 0.1
+    _validate(neglogp=lambda pdp, X: om._neglogp(rep(pdp, N_SAMPLES), X).numpy(),
+              entropy=lambda pdp, n: om._entropy(rep(pdp, n)).numpy(),
+              kl=lambda p, q_, n: _kl_categorical(rep(p, n), rep(q_, n)).numpy(),
+              sample=sample, pdparam=PDPARAM_CATEGORICAL, q=q)
+    # known answer: H = -sum p log p of softmax(pdparam)
+    p = np.exp(PDPARAM_CATEGORICAL) / np.exp(PDPARAM_CATEGORICAL).sum()
+    assert abs(float(om._entropy(rep(PDPARAM_CATEGORICAL, 1))[0]) - float(-(p * np.log(p)).sum())) < 1e-12
+    assert abs(float(om._neglogp(rep(PDPARAM_CATEGORICAL, 1), torch.tensor([2]))[0]) + math.log(p[2])) < 1e-12
