@@ -1,0 +1,269 @@
+// Conv data-gradient on the split-bf16 matrix pipe, position-major tiles (gfx950).  Sixth GEMM engine of libmrl.
+// Replaces the gradient of tf.nn.conv2d w.r.t. its input inside `tf.gradients(loss, params)` (ppo2/model.py:102-103)
+// for the hidden conv layers of NatureCNN (common/models.py:21-22 via a2c/utils.py:37-56).
+//
+// Gather form, as in ldsdgrad.hip.h: input pixel (iy, ix) = (S*yy + py, S*xx + px) of stride-parity class (py, px) receives
+//   dX[b, iy, ix, c] = sum_{a, b2 < TAPS} sum_n dz[b, yy - a, xx - b2, n] * W[py + S*a, px + S*b2, c, n]
+// Two observations turn this into a dense GEMM without waste:
+//   1. the dz pixels a class-grid position (yy, xx) reads do NOT depend on the class -- only the filter taps do.  All
+//      S*S classes are therefore columns of ONE GEMM: A[row][k = (a, b2, n)] (im2col of dz over the class grid),
+//      B[col = (class, c)][k] (filter taps re-ordered once per call into split bf16 planes), N = S*S*C columns
+//      (conv2: 128 instead of four 32-column problems that each re-stage A), and the epilogue scatters column (class, c)
+//      of row (b, yy, xx) to its unique destination pixel (deterministic, no atomics);
+//   2. which taps fall outside the dz map depends only on the POSITION (yy, xx).  A workgroup tile is BM images of one
+//      position, so the validity of a tap is uniform over the tile and out-of-map taps are skipped instead of being
+//      multiplied by zeros: only useful MACs are executed (the LDS-resident fp32 engine spends 19 % (conv2) / 40 %
+//      (conv3) of its matrix time on border zeros).
+// Arithmetic, staging and tile shape are those of gemmx6.hip.h: both operands split exactly into 3 bf16 planes, 8 (or 6)
+// partial products per multiply accumulated in fp32 by v_mfma_f32_32x32x16_bf16, A split while it is staged into LDS,
+// 4 waves x (64 x 64) per workgroup, two workgroups per CU.  Tiles of one image group (all positions) take consecutive
+// slots of ONE XCD so that the TAPS^2-fold re-reads of dz pixels by neighbouring positions hit that XCD's L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemmx6.hip.h"
+
+namespace mrl {
+
+template <int H, int W, int C, int RF, int S, int NF>
+struct DgX6Geom {
+    static constexpr int OH = (H - RF) / S + 1, OW = (W - RF) / S + 1;
+    static constexpr int TAPS = (RF + S - 1) / S;
+    static constexpr int HY = (H + S - 1) / S, WX = (W + S - 1) / S;
+    static constexpr int NPOS = HY * WX;
+    static constexpr int NCLS = S * S;
+    static constexpr int N = NCLS * C;                    // GEMM columns (class, c)
+    static constexpr int K = TAPS * TAPS * NF;            // GEMM k (a, b2, n)
+    static constexpr int KT_PER_TAP = NF / X6_BK;
+    static constexpr int NKT = K / X6_BK;
+    static_assert(NF % X6_BK == 0, "a k tile lies inside one tap");
+};
+
+// B planes [plane][col = cls*C + c][k = (a*TAPS + b2)*NF + n] = split(W[py + S*a][px + S*b2][c][n]) (0 for taps beyond RF)
+template <int H, int W, int C, int RF, int S, int NF>
+__global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ out) {
+    using G = DgX6Geom<H, W, C, RF, S, NF>;
+    const int total = G::N * G::K;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int col = e / G::K, k = e - col * G::K;
+        const int cls = col / C, c = col - cls * C;
+        const int py = cls / S, px = cls - py * S;
+        const int tap = k / NF, n = k - tap * NF;
+        const int a = tap / G::TAPS, b2 = tap - a * G::TAPS;
+        const int ky = py + S * a, kx = px + S * b2;
+        const float v = (ky < RF && kx < RF) ? w[((long)(ky * RF + kx) * C + c) * NF + n] : 0.f;
+        const uint32_t u = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u & 0xffff0000u);
+        const uint32_t u1 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        out[0 * total + e] = (uint16_t)(u >> 16);
+        out[1 * total + e] = (uint16_t)(u1 >> 16);
+        out[2 * total + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+}
+
+template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8>
+__global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
+                                                       const float* __restrict__ hmask, float* __restrict__ dx, int act,
+                                                       int B, int btiles, long tiles_per_xcd, long total_tiles) {
+    using G = DgX6Geom<H, W, C, RF, S, NF>;
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = WM * 64, BN = WN * 64;
+    static_assert(G::N % BN == 0 || G::N < BN, "column tiles");
+    constexpr int NTN = (G::N + BN - 1) / BN;             // column tiles
+    constexpr int NA = BM / 32, NQ = BN / 64;
+    constexpr int OH = G::OH, OW = G::OW, TAPS = G::TAPS;
+    extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
+    // logical tile order: (image group, position, column tile) with the column tile fastest; XCD x owns a contiguous run
+    const int xcd = blockIdx.x & 7;
+    const long slot = blockIdx.x >> 3;
+    if (slot >= tiles_per_xcd) return;
+    const long lt = (long)xcd * tiles_per_xcd + slot;
+    if (lt >= total_tiles) return;
+    const int nt_i = (int)(lt % NTN);
+    const long rest = lt / NTN;
+    const int pos = (int)(rest % G::NPOS);
+    const int bt = (int)(rest / G::NPOS);
+    const int yy = pos / G::WX, xx = pos - yy * G::WX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int b0 = bt * BM, n0 = nt_i * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // A rows = images b0 + p*32 + tid/8 at dz pixel (yy, xx); a tap moves the pointer by a row-independent offset
+    const float* ap[NA];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+        const int b = min(b0 + p * 32 + (tid >> 3), B - 1);
+        ap[p] = dz + ((long)(b * OH + yy) * OW + xx) * NF + (tid & 7) * 4;
+    }
+    const uint16_t* bp[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = q * 256 + tid;
+        bp[q] = Bp + (long)min(n0 + (c >> 2), G::N - 1) * G::K + (c & 3) * 8;
+    }
+    constexpr long bplane = (long)G::N * G::K;
+    // k tiles whose tap reads inside the dz map at this position (uniform over the workgroup)
+    auto kvalid = [&](int t) {
+        const int tap = t / G::KT_PER_TAP;
+        const int a = tap / TAPS, b2 = tap - a * TAPS;
+        return (unsigned)(yy - a) < (unsigned)OH && (unsigned)(xx - b2) < (unsigned)OW;
+    };
+    auto next_valid = [&](int t) {
+        while (t < G::NKT && !kvalid(t)) ++t;
+        return t;
+    };
+    float4 ra0[NA];
+    u32x4v rb0[3 * NQ];
+    auto fetch = [&](float4 (&ra)[NA], u32x4v (&rb)[3 * NQ], int tt) {      // tt: a VALID k tile
+        const int tap = tt / G::KT_PER_TAP, kin = (tt - tap * G::KT_PER_TAP) * X6_BK;
+        const int a = tap / TAPS, b2 = tap - a * TAPS;
+        const long ko = (long)kin - (long)(a * OW + b2) * NF;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + tt * X6_BK);
+    };
+    auto swrite = [&](const float4 (&ra)[NA], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
+        uint16_t* Bs = As + 3 * BM * X6_LDK;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+            split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
+            split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
+            uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+            *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
+            *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = q * 256 + tid;
+                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
+            }
+    };
+    auto mfma_block = [&](const uint16_t* As) {
+        const uint16_t* Bs = As + 3 * BM * X6_LDK;
+#pragma unroll
+        for (int kb = 0; kb < X6_BK / 16; ++kb) {
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + (wm * 2 + a) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[b][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * 2 + b) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {       // small terms first
+                    if (X8) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][2], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+    uint16_t* L0 = x6s;
+    int t = next_valid(0);
+    fetch(ra0, rb0, t);
+    while (t < G::NKT) {
+        __syncthreads();                       // previous tile's fragment reads are done
+        swrite(ra0, rb0, L0);
+        __syncthreads();
+        const int tn = next_valid(t + 1);
+        fetch(ra0, rb0, tn < G::NKT ? tn : t);  // next valid tile in flight during the MFMA block (past the end: re-read, never consumed)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(L0);
+        __builtin_amdgcn_sched_barrier(0);
+        t = tn;
+    }
+    // epilogue: column (class, c) of row (image, position) -> its destination pixel, masked by act'(h) of the layer below
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + (wn * 2 + b) * 32 + i;
+            const int cls = col / C, c = col - cls * C;
+            const int py = cls / S, px = cls - py * S;
+            const int iy = yy * S + py, ix = xx * S + px;
+            const bool colok = col < G::N && iy < H && ix < W;
+            const long pix = colok ? ((long)iy * W + ix) * C + c : 0;
+            long o[16];
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bimg = b0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[r] = (colok && bimg < B) ? (long)bimg * (H * W * C) + pix : -1;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = hmask ? hmask[o[r] < 0 ? 0 : o[r]] : 1.f;       // all loads first
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (o[r] >= 0) dx[o[r]] = hmask ? acc[a][b][r] * act_bwd_from_out(x[r], act) : acc[a][b][r];
+        }
+}
+
+template <int H, int W, int C, int RF, int S, int NF>
+inline size_t dgrad_x6_plane_bytes() {
+    using G = DgX6Geom<H, W, C, RF, S, NF>;
+    return (size_t)3 * G::N * G::K * sizeof(uint16_t);
+}
+
+template <int H, int W, int C, int RF, int S, int NF, int WM, int WN>
+inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* hmask, float* dx, int act, int B,
+                                  uint16_t* planes, bool x8, hipStream_t stream) {
+    using G = DgX6Geom<H, W, C, RF, S, NF>;
+    if (B <= 0) return hipSuccess;
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int NTN = (G::N + BN - 1) / BN;
+    hipLaunchKernelGGL((dgx6_split_planes_kernel<H, W, C, RF, S, NF>), dim3((G::N * G::K + 255) / 256), dim3(256), 0, stream,
+                       w, planes);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int btiles = (B + BM - 1) / BM;
+    const long total = (long)btiles * G::NPOS * NTN;
+    const long per_xcd = (total + 7) / 8;
+    if (per_xcd * 8 > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
+    auto launch = [&](auto kern) {
+        static bool raised = false;                // per instantiation (one lambda instantiation per kernel type)
+        if (!raised) {
+            hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (er != hipSuccess) return er;
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, dx,
+                           act, B, btiles, per_xcd, total);
+        return hipGetLastError();
+    };
+    if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);
+    return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, false>);
+}
+
+}  // namespace mrl

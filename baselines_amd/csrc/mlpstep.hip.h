@@ -31,6 +31,11 @@ struct MlpStepArgs {
     const void* actions; const float* returns; const float* values; const float* neglogp;
     const float* advstat; float cliprange, ent_coef, vf_coef, invB;
     int B;
+    // advstat == nullptr: every workgroup computes the minibatch advantage statistics itself (model.py:136-139) over
+    // the Bstat samples stat_idx[0..Bstat) (env-major indices; nullptr: rows 0..Bstat-1) of stat_ret / stat_val, in the
+    // same fixed order everywhere -- identical results in all workgroups, two launches fewer per step.
+    // tile_idx != nullptr (with advstat == nullptr): env-major indices of THIS call's samples, translated here.
+    const float* stat_ret; const float* stat_val; const int64_t* stat_idx; const int64_t* tile_idx; int Bstat, T, N;
     float* part;           // [ntiles][P]
     double* spart;         // [ntiles][5]
     long long* dbg;        // optional [8] phase timestamps of workgroup 0 (s_memtime), nullptr normally
@@ -79,7 +84,36 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
     // ---- P0: rows + observation tile
     if (tid < 32) {
         const int b = s0 + tid;
-        row_s[tid] = b < a.B ? (a.srow ? (long)a.srow[b] : (long)b) : -1;
+        long r = -1;
+        if (b < a.B) r = a.tile_idx ? envmajor_to_row(a.tile_idx[b], a.T, a.N) : (a.srow ? (long)a.srow[b] : (long)b);
+        row_s[tid] = r;
+    }
+    // ---- P0': advantage statistics of the whole minibatch (f64 accumulation, fixed order)
+    float adv_mean, adv_sd;
+    if (!a.advstat) {
+        double* red = reinterpret_cast<double*>(pi_s);       // LDS scratch; pi_s is first written in P3a
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = tid; b < a.Bstat; b += 256) {
+            const long r = a.stat_idx ? envmajor_to_row(a.stat_idx[b], a.T, a.N) : (long)b;
+            const float x = __fsub_rn(a.stat_ret[r], a.stat_val[r]);
+            s1 += (double)x;
+            s2 += (double)x * (double)x;
+        }
+        const double t1 = block_sum_256(s1, red);
+        const double t2 = block_sum_256(s2, red + 4);
+        if (tid == 0) {
+            const double mean = t1 / a.Bstat;
+            double var = t2 / a.Bstat - mean * mean;
+            if (var < 0) var = 0;
+            red[8] = (double)(float)mean;
+            red[9] = (double)(float)sqrt(var);
+        }
+        __syncthreads();
+        adv_mean = (float)red[8];
+        adv_sd = (float)red[9] + 1e-8f;
+    } else {
+        adv_mean = a.advstat[0];
+        adv_sd = a.advstat[1] + 1e-8f;
     }
     __syncthreads();
     // one wave per SIMD: every memory latency is exposed, so loads are issued in batches of 8 before use
@@ -231,7 +265,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
         float* dpi = dpi_s + s * 32;
         float* dls = dls_s + s * 32;
         if (r >= 0) {
-            const float mean = a.advstat[0], sd = a.advstat[1] + 1e-8f;
+            const float mean = adv_mean, sd = adv_sd;
             const float eps = a.cliprange, ce = a.ent_coef * a.invB;
             const float R = a.returns[r], oldv = a.values[r], oldnlp = a.neglogp[r];
             const float adv = ((R - oldv) - mean) / sd;

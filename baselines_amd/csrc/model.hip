@@ -22,6 +22,7 @@
 #include "imgres.hip.h"
 #include "ldsdgrad.hip.h"
 #include "gemmx6.hip.h"
+#include "dgradx6.hip.h"
 #include "mlpstep.hip.h"
 #include "comm.hip.h"
 
@@ -318,7 +319,13 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     {   // scratch for the split weight planes of the largest hidden layer (first layers read observations: own engines)
         size_t pb = 0;
         for (const Net* net : {&m->pi, &m->vf})
-            for (size_t i = 1; i < net->L.size(); ++i) pb = std::max(pb, gemm_x6_plane_bytes(net->L[i].N, net->L[i].K));
+            for (size_t i = 1; i < net->L.size(); ++i) {
+                pb = std::max(pb, gemm_x6_plane_bytes(net->L[i].N, net->L[i].K));
+                if (net->L[i].kind == 0)       // data-gradient planes: S*S*C columns x taps^2*NF (dgradx6.hip.h)
+                    pb = std::max(pb, gemm_x6_plane_bytes((long)net->L[i].stride * net->L[i].stride * net->L[i].C,
+                                                          (long)((net->L[i].rf + net->L[i].stride - 1) / net->L[i].stride) *
+                                                              ((net->L[i].rf + net->L[i].stride - 1) / net->L[i].stride) * net->L[i].NF));
+            }
         ws.pi.planes = ws.vf.planes = pb ? (uint16_t*)take(pb) : nullptr;
     }
     if (m->d.network == MRL_NET_MLP)
@@ -364,7 +371,8 @@ struct StepCtx {
 // out of the pass that produces the gradient instead of a second pass over it.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, long slab, int nz,
                                                            float* __restrict__ out, long n, int accumulate,
-                                                           double* __restrict__ sq) {
+                                                           double* __restrict__ sq, const double* __restrict__ spart,
+                                                           int nsp, float invB, float* __restrict__ stats_out) {
     __shared__ float sh[4][64];
     __shared__ double shd[4];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -396,9 +404,16 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         const double r = block_sum_256(ssq, shd);
         if (threadIdx.x == 0) sq[blockIdx.x] = r;
     }
+    // rider: the 5 loss statistics of the step, stats_out[j] = (sum_blk spart[blk][j]) * invB (fixed order)
+    if (stats_out && blockIdx.x == 0 && threadIdx.x < 5) {
+        double t = 0.0;
+        for (int b = 0; b < nsp; ++b) t += spart[b * 5 + threadIdx.x];
+        stats_out[threadIdx.x] = (float)(t * (double)invB);
+    }
 }
 static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st,
-                        StepCtx* ctx = nullptr) {
+                        StepCtx* ctx = nullptr, const double* spart = nullptr, int nsp = 0, float invB = 0.f,
+                        float* stats_out = nullptr) {
     int blocks = (int)std::min<long>((n + 63) / 64, 8192);
     double* sq = nullptr;
     if (ctx && ctx->sqpart) {
@@ -408,7 +423,8 @@ static int reduce_slabs(const float* part, long slab, int nz, float* out, long n
         ctx->sqn += blocks;
     }
     ProfScope ps("reduce_slabs", 0.0, 4.0 * n * (nz + 1 + (accumulate ? 1 : 0)), st);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate, sq);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, part, slab, nz, out, n, accumulate, sq, spart, nsp,
+                       invB, stats_out);
     MRL_LAUNCH_CHECK();
     return 0;
 }
@@ -869,15 +885,6 @@ __global__ void heads_stats_reduce_kernel(const double* __restrict__ spart, int 
         acc[j] = s;
     }
 }
-// both steps in one launch: out[j] = (sum_blk spart[blk][j]) * invB
-__global__ void stats_reduce_finalize_kernel(const double* __restrict__ spart, int nblk, float invB, float* __restrict__ out) {
-    int j = threadIdx.x;
-    if (j < 5) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += spart[b * 5 + j];
-        out[j] = (float)(s * (double)invB);
-    }
-}
 __global__ void stats_finalize_kernel(const double* __restrict__ acc, float invB, float* __restrict__ out) {
     int j = threadIdx.x;
     if (j < 5) out[j] = (float)(acc[j] * (double)invB);
@@ -1244,6 +1251,16 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 const int lk = ldsdgrad_kind(l, dz);
                 const bool overridden = tune_table().find(std::string(l.name) + ".dgrad") != tune_table().end();
                 int dv = pick_variant(l.name, "dgrad", Md, l.C, false);
+                if (lk && !overridden && nw.planes && f32_split_mode() && get_option("dgrad_x6", "MRL_DGRAD_X6", 1)) {
+                    // position-major tiles on the split-bf16 pipe (dgradx6.hip.h): only useful MACs, all parity classes in one GEMM
+                    char label[40];
+                    if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
+                    ProfScope ps(label, fl, 0.0, st);
+                    const bool x8 = f32_split_mode() == 2;
+                    hipError_t e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st)
+                                           : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st);
+                    rc = (int)e;
+                } else
                 if (lk && (dv == V_LDSDGRAD || !overridden)) {
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
@@ -1410,15 +1427,28 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
     double* advpart = ws.dscratch;
     double* spart = ws.dscratch + ADV_G * 2;
     double* stats_acc = spart + SPART_MAX * 5;
+    // fused whole-step kernel for the 2 x 64 tanh MLP (mlpstep.hip.h)?  It computes the advantage statistics itself.
+    const int B0 = mbn;
+    const bool mlp_fused = [&] {
+        const mrl_model_desc& d = m->d;
+        const int K0 = (int)m->ob_elems, nets = m->vf_copy ? 2 : 1, ntiles = (B0 + 31) / 32;
+        return get_option("mlp_fused", "MRL_MLP_FUSED", 1) && d.network == MRL_NET_MLP && d.num_layers == 2 &&
+               d.num_hidden == MLP_NH && d.activation == MRL_ACT_TANH && m->has_pi_head && d.nact <= 32 && K0 % 4 == 0 &&
+               B0 <= chunk && ntiles <= MLP_MAX_TILES && mlp_step_lds_bytes(K0, nets) <= 160 * 1024 &&
+               (size_t)ntiles * m->P <= ws.part_floats && (uintptr_t)params % 16 == 0 && (uintptr_t)obs % 16 == 0;
+    }();
+    const float* stat_ret = returns; const float* stat_val = values; const int64_t* stat_idx = idx;
     // minibatch advantage statistics (model.py:136-139)
-    int G = std::min(ADV_G, (Bstat + 255) / 256);
-    ProfScope* psadv = new ProfScope("adv_stats", 0.0, (idx ? 16.0 : 8.0) * Bstat, st);
-    hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, Bstat, T, N, advpart,
-                       whole ? ws.srow : nullptr, chunk);
-    MRL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, Bstat, ws.advstat, stats_acc);
-    delete psadv;
-    MRL_LAUNCH_CHECK();
+    if (!mlp_fused) {
+        int G = std::min(ADV_G, (Bstat + 255) / 256);
+        ProfScope* psadv = new ProfScope("adv_stats", 0.0, (idx ? 16.0 : 8.0) * Bstat, st);
+        hipLaunchKernelGGL(advstat_part_kernel, dim3(G), dim3(256), 0, st, returns, values, idx, Bstat, T, N, advpart,
+                           whole ? ws.srow : nullptr, chunk);
+        MRL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(advstat_final_kernel, dim3(1), dim3(256), 0, st, advpart, G, Bstat, ws.advstat, stats_acc);
+        delete psadv;
+        MRL_LAUNCH_CHECK();
+    }
     const size_t ob_bytes = (size_t)m->ob_elems * (m->d.ob_dtype == MRL_OB_U8 ? 1 : 4);
     if (!whole) {                                   // the slice starts at sample mb0 of the minibatch
         if (idx) {
@@ -1431,64 +1461,54 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         }
     }
     const float invB = 1.f / (float)B;
-    // ---- fused whole-step kernel for the 2 x 64 tanh MLP (mlpstep.hip.h)
-    {
-        const int fused = get_option("mlp_fused", "MRL_MLP_FUSED", 1);
+    // ---- fused whole-step kernel for the 2 x 64 tanh MLP (mlpstep.hip.h): 3 launches per step
+    //      (step kernel incl. advantage statistics and index translation; slab reduction incl. the global-norm partials
+    //      and the loss statistics; [clip +] Adam in mrl_model_train_step)
+    if (mlp_fused) {
         const mrl_model_desc& d = m->d;
         const int ntiles = (B + 31) / 32;
         const int K0 = (int)m->ob_elems;
         const int nets = m->vf_copy ? 2 : 1;
-        if (fused && d.network == MRL_NET_MLP && d.num_layers == 2 && d.num_hidden == MLP_NH && d.activation == MRL_ACT_TANH &&
-            m->has_pi_head && d.nact <= 32 && K0 % 4 == 0 && B <= chunk && ntiles <= MLP_MAX_TILES &&
-            mlp_step_lds_bytes(K0, nets) <= 160 * 1024 && (size_t)ntiles * m->P <= ws.part_floats &&
-            (uintptr_t)params % 16 == 0 && (uintptr_t)obs % 16 == 0) {
-            MlpStepArgs a;
-            memset(&a, 0, sizeof a);
-            for (int n = 0; n < nets; ++n) {
-                const Net& net = n == 0 ? m->pi : m->vf;
-                a.w0[n] = net.L[0].w_off; a.b0[n] = net.L[0].b_off; a.w1[n] = net.L[1].w_off; a.b1[n] = net.L[1].b_off;
-            }
-            a.wpi = m->pi_w; a.bpi = m->pi_b; a.logstd = m->logstd; a.wvf = m->vf_w; a.bvf = m->vf_b;
-            a.K0 = K0; a.nact = d.nact; a.nets = nets; a.pd_kind = d.pd_kind; a.P = m->P;
-            a.params = params; a.obs = (const float*)obs; a.actions = actions; a.returns = returns; a.values = values;
-            a.neglogp = neglogpacs; a.advstat = ws.advstat; a.cliprange = cliprange; a.ent_coef = ent_coef;
-            a.vf_coef = vf_coef; a.invB = invB; a.B = B; a.part = ws.part; a.spart = spart;
-            {   // MRL_MLP_DBG=1: phase timestamps of workgroup 0 land in the last 64 bytes of the zero page
-                const int dbgon = get_option("mlp_dbg", "MRL_MLP_DBG", 0);
-                a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
-            }
-            if (idx) {
-                if (!whole) {
-                    hipLaunchKernelGGL(translate_idx_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, T, N, ws.srow);
-                    MRL_LAUNCH_CHECK();
-                }
-                a.srow = ws.srow;                            // else filled by advstat_part_kernel (B <= chunk here)
-            }
-            const size_t lds = mlp_step_lds_bytes(K0, nets);
-            static bool raised = false;
-            if (!raised) {
-                MRL_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                raised = true;
-            }
-            {
-                // algorithmic flops: fwd + bwd of both nets on B samples
-                double fl = 0.0;
-                for (int n = 0; n < nets; ++n) fl += 2.0 * B * ((double)K0 * 64 * 2 + 64.0 * 64 * 3);
-                ProfScope ps("mlp_step", fl, 0.0, st);
-                hipLaunchKernelGGL(mlp_step_kernel, dim3(ntiles), dim3(256), lds, st, a);
-            }
-            MRL_LAUNCH_CHECK();
-            int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st, &ctx);
-            if (rc) return rc;
-            hipLaunchKernelGGL(stats_reduce_finalize_kernel, dim3(1), dim3(64), 0, st, spart, ntiles, invB, stats_out);
-            MRL_LAUNCH_CHECK();
-            if (ctx.comm) {
-                if ((rc = comm_allreduce_async(ctx.comm, grads_out, m->P, ctx.rank_weight, st))) return rc;
-                if ((rc = comm_join(ctx.comm, st))) return rc;
-            }
-            if (sqn_out) *sqn_out = ctx.sqn;
-            return 0;
+        MlpStepArgs a;
+        memset(&a, 0, sizeof a);
+        for (int n = 0; n < nets; ++n) {
+            const Net& net = n == 0 ? m->pi : m->vf;
+            a.w0[n] = net.L[0].w_off; a.b0[n] = net.L[0].b_off; a.w1[n] = net.L[1].w_off; a.b1[n] = net.L[1].b_off;
         }
+        a.wpi = m->pi_w; a.bpi = m->pi_b; a.logstd = m->logstd; a.wvf = m->vf_w; a.bvf = m->vf_b;
+        a.K0 = K0; a.nact = d.nact; a.nets = nets; a.pd_kind = d.pd_kind; a.P = m->P;
+        a.params = params; a.obs = (const float*)obs; a.actions = actions; a.returns = returns; a.values = values;
+        a.neglogp = neglogpacs; a.advstat = nullptr; a.cliprange = cliprange; a.ent_coef = ent_coef;
+        a.vf_coef = vf_coef; a.invB = invB; a.B = B; a.part = ws.part; a.spart = spart;
+        a.stat_ret = stat_ret; a.stat_val = stat_val; a.stat_idx = stat_idx; a.Bstat = Bstat; a.T = T; a.N = N;
+        a.tile_idx = idx;                               // already advanced to the slice (nullptr: direct rows)
+        a.srow = nullptr;
+        {   // MRL_MLP_DBG=1: phase timestamps of workgroup 0 land in the last 64 bytes of the zero page
+            const int dbgon = get_option("mlp_dbg", "MRL_MLP_DBG", 0);
+            a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
+        }
+        const size_t lds = mlp_step_lds_bytes(K0, nets);
+        static bool raised = false;
+        if (!raised) {
+            MRL_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        {
+            // algorithmic flops: fwd + bwd of both nets on B samples
+            double fl = 0.0;
+            for (int n = 0; n < nets; ++n) fl += 2.0 * B * ((double)K0 * 64 * 2 + 64.0 * 64 * 3);
+            ProfScope ps("mlp_step", fl, 0.0, st);
+            hipLaunchKernelGGL(mlp_step_kernel, dim3(ntiles), dim3(256), lds, st, a);
+        }
+        MRL_LAUNCH_CHECK();
+        int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st, &ctx, spart, ntiles, invB, stats_out);
+        if (rc) return rc;
+        if (ctx.comm) {
+            if ((rc = comm_allreduce_async(ctx.comm, grads_out, m->P, ctx.rank_weight, st))) return rc;
+            if ((rc = comm_join(ctx.comm, st))) return rc;
+        }
+        if (sqn_out) *sqn_out = ctx.sqn;
+        return 0;
     }
     for (int c0 = 0; c0 < B; c0 += chunk) {
         const int Bc = std::min(chunk, B - c0);
