@@ -17,10 +17,10 @@ class ModelDesc(ctypes.Structure):
     """mirror of mrl_model_desc (include/mrl.h)"""
     _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
                 ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('value_copy', c_int),
-                ('pd_kind', c_int), ('nact', c_int)]
+                ('pd_kind', c_int), ('nact', c_int), ('nlstm', c_int)]
 
 
-NET_MLP, NET_NATURE_CNN = 0, 1
+NET_MLP, NET_NATURE_CNN, NET_LSTM, NET_CNN_LSTM = 0, 1, 2, 3
 PD_CATEGORICAL, PD_DIAG_GAUSSIAN = 0, 1
 OB_F32, OB_U8 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
@@ -46,6 +46,11 @@ SIGNATURES = {
     'mrl_model_grad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                c_size_t, c_int, c_void_p]),
+    'mrl_model_state_size': (c_int, [c_void_p]),
+    'mrl_model_act_rnn': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_model_grad_rnn': (c_int, [c_void_p] * 9 + [c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
+                                                    c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_model_grad_micro': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_int, c_void_p]),

@@ -1,8 +1,9 @@
 """Network registry with the reference's surface (common/models.py:7-13, 257-275): builders are
 looked up by name and called with the user's **network_kwargs.  A builder here returns a
 *description* that the HIP model layout (csrc/model.hip) understands, instead of a TF graph
-function.  Supported on the hot path: 'mlp' (models.py:74-103) and 'cnn' = NatureCNN
-(models.py:15-26); every other name raises like get_network_builder does (models.py:275)."""
+function.  Supported on the hot path: 'mlp' (models.py:74-103), 'cnn' = NatureCNN
+(models.py:15-26), 'lstm' and 'cnn_lstm' (models.py:132-206); every other name raises like get_network_builder does
+(models.py:275)."""
 
 mapping = {}
 
@@ -51,6 +52,24 @@ def cnn(**conv_kwargs):
     if conv_kwargs:
         raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(conv_kwargs)))
     return NetworkDesc('cnn')
+
+
+@register('lstm')
+def lstm(nlstm=128, layer_norm=False):
+    """common/models.py:132-176: flatten -> LSTM cell over the steps of a rollout, state managed outside the policy"""
+    if layer_norm:
+        raise NotImplementedError('layer-normalised LSTM (lnlstm) is outside the supported hot path')
+    return NetworkDesc('lstm', nlstm=int(nlstm))
+
+
+@register('cnn_lstm')
+def cnn_lstm(nlstm=128, layer_norm=False, **conv_kwargs):
+    """common/models.py:179-206: NatureCNN features -> LSTM cell"""
+    if layer_norm:
+        raise NotImplementedError('layer-normalised LSTM (lnlstm) is outside the supported hot path')
+    if conv_kwargs:
+        raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(conv_kwargs)))
+    return NetworkDesc('cnn_lstm', nlstm=int(nlstm))
 
 
 def get_network_builder(name):

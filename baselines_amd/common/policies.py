@@ -14,6 +14,11 @@ class PolicySpec(object):
         if value_network not in (None, 'shared', 'copy'):
             raise NotImplementedError("value_network must be None, 'shared' or 'copy' on the HIP path")
         self.value_copy = (value_network == 'copy')
+        self.recurrent = network.kind in ('lstm', 'cnn_lstm')
+        self.nlstm = int(network.kw.get('nlstm', 0)) if self.recurrent else 0
+        if self.recurrent and self.value_copy:
+            # policies.py:162-165 "recurrent architectures are not supported with value_network=copy yet"
+            raise NotImplementedError('recurrent architectures are not supported with value_network=copy')
         if is_discrete(ac_space):
             self.pd_kind, self.nact = 'categorical', int(ac_space.n)
         elif is_box(ac_space):

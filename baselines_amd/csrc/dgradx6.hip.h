@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
 template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8>
 __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
                                                        const float* __restrict__ hmask, float* __restrict__ dx, int act,
-                                                       int B, int btiles, long tiles_per_xcd, long total_tiles) {
+                                                       int B, int btiles, long tiles_per_xcd, long total_tiles, int dbg) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -188,9 +188,11 @@ __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__
                 }
         }
     };
+    // dbg (timing experiments, MRL_DGX6_DBG): 1 = no mask loads, 2 = no stores (epilogue off), 4 = main loop off
+    if (dbg & 1) hmask = nullptr;
     uint16_t* L0 = x6s;
-    int t = next_valid(0);
-    fetch(ra0, rb0, t);
+    int t = (dbg & 4) ? G::NKT : next_valid(0);
+    if (t < G::NKT) fetch(ra0, rb0, t);
     while (t < G::NKT) {
         __syncthreads();                       // previous tile's fragment reads are done
         swrite(ra0, rb0, L0);
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) x[r] = hmask ? hmask[o[r] < 0 ? 0 : o[r]] : 1.f;       // all loads first
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (o[r] >= 0) dx[o[r]] = hmask ? acc[a][b][r] * act_bwd_from_out(x[r], act) : acc[a][b][r];
+                if (o[r] >= 0 && (!(dbg & 2) || acc[a][b][r] == 12345.678f))
+                    dx[o[r]] = hmask ? acc[a][b][r] * act_bwd_from_out(x[r], act) : acc[a][b][r];
         }
 }
 
@@ -237,7 +240,7 @@ inline size_t dgrad_x6_plane_bytes() {
 
 template <int H, int W, int C, int RF, int S, int NF, int WM, int WN>
 inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* hmask, float* dx, int act, int B,
-                                  uint16_t* planes, bool x8, hipStream_t stream) {
+                                  uint16_t* planes, bool x8, hipStream_t stream, int dbg = 0) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     if (B <= 0) return hipSuccess;
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -259,7 +262,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
             raised = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, dx,
-                           act, B, btiles, per_xcd, total);
+                           act, B, btiles, per_xcd, total, dbg);
         return hipGetLastError();
     };
     if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);

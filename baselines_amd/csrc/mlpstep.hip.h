@@ -93,11 +93,29 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
     if (!a.advstat) {
         double* red = reinterpret_cast<double*>(pi_s);       // LDS scratch; pi_s is first written in P3a
         double s1 = 0.0, s2 = 0.0;
-        for (int b = tid; b < a.Bstat; b += 256) {
-            const long r = a.stat_idx ? envmajor_to_row(a.stat_idx[b], a.T, a.N) : (long)b;
-            const float x = __fsub_rn(a.stat_ret[r], a.stat_val[r]);
-            s1 += (double)x;
-            s2 += (double)x * (double)x;
+        // batches of 8 samples per thread: all index loads, then all gathers in flight together (one wave per SIMD here:
+        // every dependent load would otherwise expose its full latency, 2 per sample)
+        for (int b0 = tid; b0 < a.Bstat; b0 += 8 * 256) {
+            long r[8];
+            float rv[8], vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = min(b0 + u * 256, a.Bstat - 1);
+                r[u] = a.stat_idx ? (long)a.stat_idx[b] : (long)b;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (a.stat_idx) r[u] = envmajor_to_row(r[u], a.T, a.N);
+                rv[u] = a.stat_ret[r[u]];
+                vv[u] = a.stat_val[r[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b0 + u * 256 < a.Bstat) {
+                    const float x = __fsub_rn(rv[u], vv[u]);
+                    s1 += (double)x;
+                    s2 += (double)x * (double)x;
+                }
         }
         const double t1 = block_sum_256(s1, red);
         const double t2 = block_sum_256(s2, red + 4);

@@ -25,6 +25,7 @@
 #include "dgradx6.hip.h"
 #include "mlpstep.hip.h"
 #include "comm.hip.h"
+#include "lstm.hip.h"
 
 using namespace mrl;
 
@@ -42,9 +43,12 @@ struct Layer {
 };
 
 struct Net {
-    std::vector<Layer> L;
+    std::vector<Layer> L;                  // feature layers (conv / fc); empty for the plain `lstm` network
     int nlat;
     int lat_act;
+    bool lstm = false;                     // recurrent cell on top of the features (a2c/utils.py:81-102)
+    int lstm_nin = 0, nh = 0;
+    long wx_off = -1, wh_off = -1, lb_off = -1;
 };
 
 struct TensorInfo {
@@ -89,6 +93,29 @@ static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> s
 static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
     const mrl_model_desc& d = m->d;
     const double s2 = sqrt(2.0);   // a2c/utils.py callers pass init_scale=np.sqrt(2) (f64)
+    if (d.network == MRL_NET_LSTM || d.network == MRL_NET_CNN_LSTM) {
+        // common/models.py:132-210: [nature_cnn ->] utils.lstm(scope='lstm', nh=nlstm, init_scale=1.0)
+        if (!lstm_nh_ok(d.nlstm)) return MRL_EUNSUP;
+        int nin;
+        if (d.network == MRL_NET_CNN_LSTM) {
+            mrl_model_desc dc = d;
+            dc.network = MRL_NET_NATURE_CNN;
+            m->d = dc;
+            int rc = build_net(m, net, prefix);
+            m->d = d;
+            if (rc) return rc;
+            nin = net.nlat;
+        } else {
+            if (d.ob_dtype != MRL_OB_F32 || m->ob_elems % 4 != 0) return MRL_EUNSUP;    // tf.layers.flatten(X)
+            nin = (int)m->ob_elems;
+        }
+        net.lstm = true; net.lstm_nin = nin; net.nh = d.nlstm;
+        net.wx_off = add_tensor(m, prefix + "/lstm/wx", {nin, 4 * d.nlstm}, 1.0);
+        net.wh_off = add_tensor(m, prefix + "/lstm/wh", {d.nlstm, 4 * d.nlstm}, 1.0);
+        net.lb_off = add_tensor(m, prefix + "/lstm/b", {4 * d.nlstm}, -1.0);
+        net.nlat = d.nlstm; net.lat_act = ACT_NONE;
+        return 0;
+    }
     if (d.network == MRL_NET_NATURE_CNN) {
         if (d.ob_ndim != 3 || d.ob_dtype != MRL_OB_U8 || d.ob_shape[2] % 4 != 0) return MRL_EUNSUP;
         int H = d.ob_shape[0], W = d.ob_shape[1], C = d.ob_shape[2];
@@ -148,6 +175,8 @@ extern "C" int mrl_model_create(const mrl_model_desc* desc, mrl_model** out) {
     m->ob_elems = 1;
     for (int i = 0; i < desc->ob_ndim; ++i) m->ob_elems *= desc->ob_shape[i];
     m->vf_copy = desc->value_copy != 0;
+    // policies.py:162-165: "recurrent architectures are not supported with value_network=copy yet"
+    if (m->vf_copy && (desc->network == MRL_NET_LSTM || desc->network == MRL_NET_CNN_LSTM)) { delete m; return MRL_EUNSUP; }
     int rc = build_net(m, m->pi, "ppo2_model/pi");
     if (rc == 0 && m->vf_copy) rc = build_net(m, m->vf, "ppo2_model/vf");
     if (rc) { delete m; return rc; }
@@ -168,6 +197,7 @@ extern "C" int mrl_model_create(const mrl_model_desc* desc, mrl_model** out) {
 }
 
 extern "C" void mrl_model_destroy(mrl_model* m) { delete m; }
+extern "C" int mrl_model_state_size(const mrl_model* m) { return (m && m->pi.lstm) ? 2 * m->pi.nh : 0; }
 extern "C" long mrl_model_num_params(const mrl_model* m) { return m ? m->P : 0; }
 extern "C" int mrl_model_num_tensors(const mrl_model* m) { return m ? (int)m->tensors.size() : 0; }
 
@@ -191,6 +221,11 @@ struct NetWs {
     std::vector<float*> h, dz;
     uint16_t* planes;    // bf16 x 3 image of one weight matrix (gemmx6.hip.h), shared by both nets
     long long* dbg;      // timing-experiment stamps (behind the zero page)
+    // recurrent cell (lstm.hip.h): x@wx, stored gates / masked state / tanh(c), cell output = policy latent, gradients
+    float *zx = nullptr, *gates = nullptr, *cm = nullptr, *hm = nullptr, *tc = nullptr, *hout = nullptr, *dhout = nullptr,
+          *dzg = nullptr;
+    float* lat() const { return hout ? hout : h.back(); }
+    float* dlat() const { return dhout ? dhout : dz.back(); }
 };
 struct Ws {
     NetWs pi, vf;
@@ -243,8 +278,8 @@ static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -316,6 +351,16 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     };
     do_net(m->pi, ws.pi);
     if (m->vf_copy) do_net(m->vf, ws.vf);
+    if (m->pi.lstm) {
+        const Net& n = m->pi;
+        NetWs& nw = ws.pi;
+        const size_t g4 = (size_t)chunk * 4 * n.nh * 4, g1 = (size_t)chunk * n.nh * 4;
+        nw.zx = (float*)take(g4); nw.gates = (float*)take(g4); nw.dzg = (float*)take(g4);
+        nw.cm = (float*)take(g1); nw.hm = (float*)take(g1); nw.tc = (float*)take(g1); nw.hout = (float*)take(g1);
+        nw.dhout = (float*)take(g1);
+        part_floats = std::max(part_floats, (size_t)max_split_floats(n.lstm_nin, 4 * n.nh, chunk));
+        part_floats = std::max(part_floats, (size_t)max_split_floats(n.nh, 4 * n.nh, chunk));
+    }
     {   // scratch for the split weight planes of the largest hidden layer (first layers read observations: own engines)
         size_t pb = 0;
         for (const Net* net : {&m->pi, &m->vf})
@@ -405,10 +450,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         if (threadIdx.x == 0) sq[blockIdx.x] = r;
     }
     // rider: the 5 loss statistics of the step, stats_out[j] = (sum_blk spart[blk][j]) * invB (fixed order)
-    if (stats_out && blockIdx.x == 0 && threadIdx.x < 5) {
-        double t = 0.0;
-        for (int b = 0; b < nsp; ++b) t += spart[b * 5 + threadIdx.x];
-        stats_out[threadIdx.x] = (float)(t * (double)invB);
+    if (stats_out && blockIdx.x == 0) {          // wave w sums statistic w (then 4): lanes stride the blocks, fixed shuffle tree
+        const int lane = threadIdx.x & 63;
+        for (int j = threadIdx.x >> 6; j < 5; j += 4) {
+            double t = 0.0;
+            for (int b = lane; b < nsp; b += 64) t += spart[b * 5 + j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) stats_out[j] = (float)(t * (double)invB);
+        }
     }
 }
 static int reduce_slabs(const float* part, long slab, int nz, float* out, long n, int accumulate, hipStream_t st,
@@ -1257,8 +1307,9 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
                     ProfScope ps(label, fl, 0.0, st);
                     const bool x8 = f32_split_mode() == 2;
-                    hipError_t e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st)
-                                           : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st);
+                    const int dbg = get_option("dgx6_dbg", "MRL_DGX6_DBG", 0);
+                    hipError_t e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st, dbg)
+                                           : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st, dbg);
                     rc = (int)e;
                 } else
                 if (lk && (dv == V_LDSDGRAD || !overridden)) {
@@ -1321,11 +1372,101 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
     return 0;
 }
 
+
+// ============================================================================================
+// recurrent cell: x@wx GEMM + scans (lstm.hip.h) + weight / input gradients as GEMMs over all steps
+// ============================================================================================
+static int lstm_forward(const Net& net, const In& in, const float* params, NetWs& nw, int nseq, int T, const float* s0,
+                        const uint8_t* mask, const int32_t* msrow, float* s_out, bool train, hipStream_t st) {
+    const int B = nseq * T, nh = net.nh, N4 = 4 * nh, K = net.lstm_nin;
+    const float* wx = params + net.wx_off;
+    RowMC bf{wx, N4, N4, K, is_vec(wx, N4), nullptr};
+    EpiMaskAct ef{nw.zx, N4, nullptr, ACT_NONE};                 // plain product: the bias joins inside the scan
+    const int var = pick_variant("lstm", "fwd", B, N4);
+    int rc;
+    if (net.L.empty()) {                                          // tf.layers.flatten(X): observations, gathered in place
+        RowKC af{(const float*)in.obs, K, B, K, is_vec(in.obs, K), in.srow};
+        rc = gemm_dispatch("lstm", "fwd", var, af, bf, ef, B, N4, K, 1, K, st);
+    } else {
+        const float* x = nw.h.back();
+        RowKC af{x, K, B, K, is_vec(x, K), nullptr};
+        rc = gemm_dispatch("lstm", "fwd", var, af, bf, ef, B, N4, K, 1, K, st);
+    }
+    if (rc) return rc;
+    LstmFwdArgs a;
+    a.zx = nw.zx; a.wh = params + net.wh_off; a.bias = params + net.lb_off; a.s0 = s0; a.mask = mask; a.srow = msrow;
+    a.nenv = nseq; a.T = T;
+    a.gates = train ? nw.gates : nullptr; a.cm = train ? nw.cm : nullptr; a.hm = train ? nw.hm : nullptr;
+    a.tc = train ? nw.tc : nullptr; a.hout = nw.hout; a.s_out = s_out;
+    ProfScope ps("lstm.scan_fwd", 2.0 * B * (double)nh * N4, 0.0, st);
+    return (int)launch_lstm_fwd(a, nh, num_cus(), st);
+}
+
+// nw.dhout holds dL/dh_t (written by the heads kernel).  Leaves dL/d(features) in nw.dz.back() (cnn_lstm).
+static int lstm_backward(const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws, float* grads, int nseq, int T,
+                         const uint8_t* mask, const int32_t* msrow, hipStream_t st, StepCtx& ctx) {
+    const int B = nseq * T, nh = net.nh, N4 = 4 * nh, K = net.lstm_nin;
+    {
+        LstmBwdArgs a;
+        a.dhout = nw.dhout; a.wh = params + net.wh_off; a.gates = nw.gates; a.cm = nw.cm; a.tc = nw.tc; a.mask = mask;
+        a.srow = msrow; a.nenv = nseq; a.T = T; a.dzg = nw.dzg;
+        ProfScope ps("lstm.scan_bwd", 2.0 * B * (double)nh * N4, 0.0, st);
+        hipError_t e = launch_lstm_bwd(a, nh, num_cus(), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    RowMC bfm{nw.dzg, N4, N4, B, is_vec(nw.dzg, N4), nullptr};
+    // dwx[k][n] = sum_b x[b][k] dz[b][n],  db[n] = sum_b dz[b][n] (column sums ride on the B operand)
+    {
+        int var = pick_variant("lstm", "wgrad", K, N4);
+        if (var >= V_WRES16) var = V_128x128;
+        const long slab = (long)K * N4 + N4;
+        const Split sp = pick_split(var, K, N4, B);
+        if ((size_t)sp.nsplit * slab > ws.part_floats) return MRL_ENOSPC;
+        EpiPartial ep{ws.part, slab, N4, (long)K * N4};
+        int rc;
+        if (net.L.empty()) {
+            RowMC af{(const float*)in.obs, K, K, B, is_vec(in.obs, K), in.srow};
+            rc = gemm_dispatch("lstm", "wgrad", var, af, bfm, ep, K, N4, B, sp.nsplit, sp.ksplit, st);
+        } else {
+            const float* x = nw.h.back();
+            RowMC af{x, K, K, B, is_vec(x, K), nullptr};
+            rc = gemm_dispatch("lstm", "wgrad", var, af, bfm, ep, K, N4, B, sp.nsplit, sp.ksplit, st);
+        }
+        if (rc) return rc;
+        if ((rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + net.wx_off, (long)K * N4, 0, st, &ctx))) return rc;
+        if ((rc = reduce_slabs(ws.part + (long)K * N4, slab, sp.nsplit, grads + net.lb_off, N4, 0, st, &ctx))) return rc;
+    }
+    // dwh[k][n] = sum_b hm[b][k] dz[b][n]   (hm: the masked previous h the cell actually multiplied)
+    {
+        int var = pick_variant("lstm_h", "wgrad", nh, N4);
+        if (var >= V_WRES16) var = V_128x128;
+        const long slab = (long)nh * N4 + N4;
+        const Split sp = pick_split(var, nh, N4, B);
+        if ((size_t)sp.nsplit * slab > ws.part_floats) return MRL_ENOSPC;
+        EpiPartial ep{ws.part, slab, N4, (long)nh * N4};
+        RowMC af{nw.hm, nh, nh, B, is_vec(nw.hm, nh), nullptr};
+        int rc = gemm_dispatch("lstm_h", "wgrad", var, af, bfm, ep, nh, N4, B, sp.nsplit, sp.ksplit, st);
+        if (rc) return rc;
+        if ((rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + net.wh_off, (long)nh * N4, 0, st, &ctx))) return rc;
+    }
+    // input gradient into the feature net: dfeat[b][k] = (sum_n dz[b][n] wx[k][n]) * act'(feat)
+    if (!net.L.empty()) {
+        const float* wx = params + net.wx_off;
+        RowKC af{nw.dzg, N4, B, N4, is_vec(nw.dzg, N4), nullptr};
+        RowKC bf{wx, N4, K, N4, is_vec(wx, N4), nullptr};
+        EpiMaskAct ef{nw.dz.back(), K, nw.h.back(), net.L.back().act};
+        const int dv = pick_variant("lstm", "dgrad", B, K);
+        int rc = gemm_dispatch("lstm", "dgrad", dv, af, bf, ef, B, K, N4, 1, N4, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static void fill_head_args(const mrl_model* m, const float* params, const Ws& ws, HeadArgs& a) {
     memset(&a, 0, sizeof a);
     const Net& pn = m->pi;
     a.nlat = pn.nlat; a.lat_act = pn.lat_act;
-    a.lat = ws.pi.h.back();
+    a.lat = ws.pi.lat();
     if (m->vf_copy) {
         a.shared = 0; a.nlatv = m->vf.nlat; a.vlat_act = m->vf.lat_act; a.vlat = ws.vf.h.back();
     } else {
@@ -1351,10 +1492,12 @@ static int pick_ts(HeadArgs& a, bool train) {
 // ============================================================================================
 // public entry points
 // ============================================================================================
-extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void* obs, const float* noise, int n,
-                             void* actions_out, float* values_out, float* neglogp_out, float* pdparam_out,
-                             void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+static int model_act_impl(const mrl_model* m, const float* params, const void* obs, const float* noise, int n,
+                          const float* state_in, const uint8_t* mask, float* state_out,
+                          void* actions_out, float* values_out, float* neglogp_out, float* pdparam_out,
+                          void* workspace, size_t workspace_bytes, int chunk, void* stream) {
     if (!m || !params || !obs || n <= 0 || chunk <= 0 || !workspace) return MRL_EINVAL;
+    if (m->pi.lstm && (!mask || !state_out)) return MRL_EINVAL;      // recurrent policies: mrl_model_act_rnn
     if ((actions_out != nullptr) != (neglogp_out != nullptr)) return MRL_EINVAL;
     if (actions_out && !noise) return MRL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -1367,6 +1510,12 @@ extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void
         In in{(const char*)obs + (size_t)c0 * ob_bytes, nullptr};
         int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
         if (rc) return rc;
+        if (m->pi.lstm) {      // one step of Bc independent sequences (policies.py:77-96 with S, M fed; act model nsteps = 1)
+            const int ss = 2 * m->pi.nh;
+            rc = lstm_forward(m->pi, in, params, ws.pi, Bc, 1, state_in ? state_in + (size_t)c0 * ss : nullptr, mask + c0,
+                              nullptr, state_out + (size_t)c0 * ss, false, st);
+            if (rc) return rc;
+        }
         if (m->vf_copy) {
             rc = net_forward(m, m->vf, in, params, ws.vf, Bc, st);
             if (rc) return rc;
@@ -1392,6 +1541,24 @@ extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void
     return 0;
 }
 
+extern "C" int mrl_model_act(const mrl_model* m, const float* params, const void* obs, const float* noise, int n,
+                             void* actions_out, float* values_out, float* neglogp_out, float* pdparam_out,
+                             void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+    if (m && m->pi.lstm) return MRL_EINVAL;
+    return model_act_impl(m, params, obs, noise, n, nullptr, nullptr, nullptr, actions_out, values_out, neglogp_out,
+                          pdparam_out, workspace, workspace_bytes, chunk, stream);
+}
+extern "C" int mrl_model_act_rnn(const mrl_model* m, const float* params, const void* obs, const float* noise, int n,
+                                 const float* state_in, const uint8_t* mask, float* state_out, void* actions_out,
+                                 float* values_out, float* neglogp_out, float* pdparam_out, void* workspace,
+                                 size_t workspace_bytes, int chunk, void* stream) {
+    if (!m || !m->pi.lstm || !mask || !state_out) return MRL_EINVAL;
+    return model_act_impl(m, params, obs, noise, n, state_in, mask, state_out, actions_out, values_out, neglogp_out,
+                          pdparam_out, workspace, workspace_bytes, chunk, stream);
+}
+
+struct RnnIn { const float* states; const uint8_t* masks; int nseq; };    // recurrent inputs of a minibatch (model.py:153-155)
+
 // Gradient of the loss over samples [mb0, mb0+mbn) of a minibatch of Bstat samples whose advantage statistics
 // span the WHOLE minibatch: mb0 = 0, mbn = Bstat is Model.train (model.py:133-158); a proper sub-range is one
 // MicrobatchedModel step (microbatched_model.py:40-60: normalise once, then per-slice losses with means over the slice).
@@ -1399,8 +1566,14 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
                             const float* returns, const float* values, const float* neglogpacs,
                             const int64_t* idx, int Bstat, int mb0, int mbn, int T, int N, float cliprange, float ent_coef,
                             float vf_coef, float* grads_out, float* stats_out, void* workspace,
-                            size_t workspace_bytes, int chunk, void* stream, bool want_sq = false, int* sqn_out = nullptr) {
+                            size_t workspace_bytes, int chunk, void* stream, bool want_sq = false, int* sqn_out = nullptr,
+                            const RnnIn* rnn = nullptr) {
     if (sqn_out) *sqn_out = 0;
+    if (m && m->pi.lstm) {
+        // recurrent policies: whole minibatch of nseq trajectories of B/nseq steps each, sample b = seq*steps + t, one chunk
+        if (!rnn || !rnn->masks || rnn->nseq <= 0 || mb0 != 0 || mbn != Bstat || Bstat % rnn->nseq != 0) return MRL_EINVAL;
+        if (Bstat > chunk) return MRL_EUNSUP;
+    } else if (rnn) return MRL_EINVAL;
     if (!m || !params || !obs || !actions || !returns || !values || !neglogpacs || !grads_out || !stats_out ||
         !workspace || Bstat <= 0 || chunk <= 0 || mb0 < 0 || mbn <= 0 || mb0 + mbn > Bstat)
         return MRL_EINVAL;
@@ -1526,6 +1699,9 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         }
         int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
         if (rc) return rc;
+        if (m->pi.lstm && (rc = lstm_forward(m->pi, in, params, ws.pi, rnn->nseq, Bc / rnn->nseq, rnn->states, rnn->masks,
+                                             in.srow, nullptr, true, st)))
+            return rc;
         if (m->vf_copy && (rc = net_forward(m, m->vf, in, params, ws.vf, Bc, st))) return rc;
         HeadArgs a;
         fill_head_args(m, params, ws, a);
@@ -1534,7 +1710,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         a.actions = actions; a.returns = returns; a.values = values; a.neglogp = neglogpacs;
         a.idx = idx ? idx + c0 : nullptr; a.T = T; a.N = N;
         a.advstat = ws.advstat; a.cliprange = cliprange; a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.invB = invB;
-        a.dz_pi = ws.pi.dz.back();
+        a.dz_pi = ws.pi.dlat();
         a.dz_vf = m->vf_copy ? ws.vf.dz.back() : nullptr;
         a.hpart = ws.part; a.spart = spart;
         HeadLds L;
@@ -1572,6 +1748,9 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st, &ctx))) return rc;
         hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, nblk, stats_acc);
         MRL_LAUNCH_CHECK();
+        if (m->pi.lstm && (rc = lstm_backward(m->pi, in, params, ws.pi, ws, grads_out, rnn->nseq, Bc / rnn->nseq, rnn->masks,
+                                              in.srow, st, ctx)))
+            return rc;
         if ((rc = net_backward(m, m->pi, in, params, ws.pi, ws, grads_out, Bc, accumulate, st, ctx, true))) return rc;
         if (m->vf_copy && (rc = net_backward(m, m->vf, in, params, ws.vf, ws, grads_out, Bc, accumulate, st, ctx, false)))
             return rc;
@@ -1632,4 +1811,16 @@ extern "C" int mrl_model_train_step(const mrl_model* m, float* params, float* gr
     carve(m, chunk, (char*)workspace, ws);
     return adam_clip_apply(params, grads, adam_m, adam_v, m->P, alpha, alpha_dev, beta1, beta2, eps, max_grad_norm,
                            total_weight, gnorm_out, ws.sqpart, sqn > 0 ? ws.sqpart : nullptr, sqn, (hipStream_t)stream);
+}
+
+// ---- recurrent policies --- ppo2/model.py:153-155, ppo2/ppo2.py:167-180 -----------------------------
+extern "C" int mrl_model_grad_rnn(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                                  const float* returns, const float* values, const float* neglogpacs,
+                                  const uint8_t* masks, const float* states, int nseq, const int64_t* idx, int B, int T,
+                                  int N, float cliprange, float ent_coef, float vf_coef, float* grads_out, float* stats_out,
+                                  void* workspace, size_t workspace_bytes, int chunk, void* stream) {
+    if (!m || !m->pi.lstm) return MRL_EINVAL;
+    RnnIn r{states, masks, nseq};
+    return model_grad_range(m, params, obs, actions, returns, values, neglogpacs, idx, B, 0, B, T, N, cliprange, ent_coef,
+                            vf_coef, grads_out, stats_out, workspace, workspace_bytes, chunk, stream, false, nullptr, &r);
 }

@@ -82,14 +82,16 @@ class DeviceModel(object):
     """Handle on an `mrl_model` layout object + the device buffers it works on."""
 
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_copy=False, num_layers=2,
-                 num_hidden=64, activation='tanh', chunk=None, device=None):
+                 num_hidden=64, activation='tanh', nlstm=128, chunk=None, device=None):
         _lib.require_gpu()
         lib = _lib.load()
         d = _lib.ModelDesc()
-        d.network = {'mlp': _lib.NET_MLP, 'cnn': _lib.NET_NATURE_CNN}[network]
+        d.network = {'mlp': _lib.NET_MLP, 'cnn': _lib.NET_NATURE_CNN, 'lstm': _lib.NET_LSTM,
+                     'cnn_lstm': _lib.NET_CNN_LSTM}[network]
         ob_shape = tuple(int(s) for s in ob_shape)
-        if d.network == _lib.NET_MLP:
+        if d.network in (_lib.NET_MLP, _lib.NET_LSTM):
             ob_shape = (int(np.prod(ob_shape)),)
+        d.nlstm = int(nlstm)
         d.ob_ndim = len(ob_shape)
         for i, s in enumerate(ob_shape):
             d.ob_shape[i] = s
@@ -111,6 +113,8 @@ class DeviceModel(object):
         self.ob_shape, self.ob_dtype = ob_shape, ob_dtype
         self.torch_ob_dtype = torch.uint8 if d.ob_dtype == _lib.OB_U8 else torch.float32
         self.P = int(lib.mrl_model_num_params(h))
+        self.state_size = int(lib.mrl_model_state_size(h))          # 2*nlstm for recurrent networks, else 0
+        self.recurrent = self.state_size > 0
         self.tensors = []
         name = ctypes.create_string_buffer(128)
         for i in range(lib.mrl_model_num_tensors(h)):
@@ -164,6 +168,23 @@ class DeviceModel(object):
             pdparam = torch.empty((n, self.nact), dtype=torch.float32, device=dev)
         self.act_into(params, obs, noise, actions, values, neglogp, pdparam)
         return actions, values, neglogp, pdparam
+
+    def act_rnn_into(self, params, obs, noise, state_in, mask, state_out, actions, values, neglogp, pdparam=None):
+        """recurrent policies: one step of n sequences (state_in may alias state_out)"""
+        n = obs.shape[0]
+        check(self.lib.mrl_model_act_rnn(self.handle, ptr(params), ptr(obs), ptr(noise), n, ptr(state_in), ptr(mask),
+                                         ptr(state_out), ptr(actions), ptr(values), ptr(neglogp), ptr(pdparam),
+                                         ptr(self.workspace), self.workspace.numel(), self.chunk, stream_ptr()),
+              'mrl_model_act_rnn')
+
+    def grad_rnn(self, params, obs, actions, returns, values, neglogpacs, masks, states, nseq, idx, B, T, N, cliprange,
+                 ent_coef, vf_coef, grads_out, stats_out):
+        """recurrent policies: gradient over a minibatch of nseq whole trajectories (back-propagation through time)"""
+        check(self.lib.mrl_model_grad_rnn(self.handle, ptr(params), ptr(obs), ptr(actions), ptr(returns), ptr(values),
+                                          ptr(neglogpacs), ptr(masks), ptr(states), int(nseq), ptr(idx), int(B), int(T),
+                                          int(N), float(cliprange), float(ent_coef), float(vf_coef), ptr(grads_out),
+                                          ptr(stats_out), ptr(self.workspace), self.workspace.numel(), self.chunk,
+                                          stream_ptr()), 'mrl_model_grad_rnn')
 
     def act_into(self, params, obs, noise, actions, values, neglogp, pdparam=None):
         n = obs.shape[0]

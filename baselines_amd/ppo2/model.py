@@ -81,7 +81,10 @@ class Model(object):
         # tf.train.AdamOptimizer(learning_rate=LR, epsilon=1e-5) (model.py:98-100): f32 slot variables
         self.beta1, self.beta2, self.epsilon = np.float32(0.9), np.float32(0.999), np.float32(1e-5)
         self.beta1_power, self.beta2_power = np.float32(0.9), np.float32(0.999)
-        self.initial_state = None
+        # recurrent policies: the LSTM state is managed outside the policy (common/models.py:132-176); initial_state is
+        # np.zeros([nenv, 2*nlstm], dtype=float) of the act model (models.py:171)
+        self.recurrent = self.dm.recurrent
+        self.initial_state = np.zeros((nbatch_act, self.dm.state_size), dtype=float) if self.recurrent else None
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(torch.initial_seed()) & 0x7fffffff)
         self._train_calls = 0
@@ -127,34 +130,74 @@ class Model(object):
             return torch.rand((n, self.nact), generator=self._gen, device=self.device, dtype=torch.float32)
         return torch.randn((n, self.nact), generator=self._gen, device=self.device, dtype=torch.float32)
 
-    def step_into(self, obs_dev, actions_out, values_out, neglogp_out, noise=None):
+    def _dev_state(self, S, n):
+        """S of the reference's feed (host [n, 2*nlstm], float64 zeros initially) -> contiguous f32 device tensor"""
+        if isinstance(S, torch.Tensor):
+            t = S.to(self.device, torch.float32)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(S, dtype=np.float32))).to(self.device)
+        return t.reshape(n, self.dm.state_size).contiguous()
+
+    def _dev_mask(self, M, n):
+        """M: done flags entering the step (bools / 0-1 floats / uint8) -> u8 device tensor [n]"""
+        if isinstance(M, torch.Tensor):
+            t = M.to(self.device)
+            t = t.view(torch.uint8) if t.dtype == torch.bool else (t != 0).to(torch.uint8)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(M).astype(np.bool_)).view(np.uint8)).to(self.device)
+        return t.reshape(n).contiguous()
+
+    def step_into(self, obs_dev, actions_out, values_out, neglogp_out, noise=None, states=None, masks=None):
         """Device fast path: obs [n, ...] device tensor; results written into the given device
-        buffers (e.g. slot t of the rollout SoA) -- K1 'rollout store' is therefore zero-copy."""
+        buffers (e.g. slot t of the rollout SoA) -- K1 'rollout store' is therefore zero-copy.
+        Recurrent policies: `states` (f32 device [n, 2*nlstm]) is advanced IN PLACE, `masks` u8 device [n]."""
         if noise is None:
             noise = self.make_noise(obs_dev.shape[0])
-        self.dm.act_into(self.params, obs_dev, noise, actions_out, values_out, neglogp_out)
+        if self.recurrent:
+            self.dm.act_rnn_into(self.params, obs_dev, noise, states, masks, states, actions_out, values_out, neglogp_out)
+        else:
+            self.dm.act_into(self.params, obs_dev, noise, actions_out, values_out, neglogp_out)
 
     def step(self, observation, S=None, M=None, noise=None, **_):
         """policies.py:77-96: returns host arrays (actions int64 [n] | f32 [n, nact], values f32,
-        None, neglogpacs f32)."""
+        next state f32 [n, 2*nlstm] | None, neglogpacs f32)."""
         obs = self._to_dev_obs(observation)
+        n = obs.shape[0]
         if noise is None:
-            noise = self.make_noise(obs.shape[0])
+            noise = self.make_noise(n)
         elif not isinstance(noise, torch.Tensor):
             noise = torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float32)).to(self.device)
-        a, v, nlp, _ = self.dm.act(self.params, obs, noise)
+        state = None
+        if self.recurrent:
+            assert S is not None and M is not None, 'recurrent policy: step(obs, S=states, M=dones)'
+            st = self._dev_state(S, n).clone()
+            a = (torch.empty(n, dtype=torch.int32, device=self.device) if self.pd_kind == 'categorical'
+                 else torch.empty((n, self.nact), dtype=torch.float32, device=self.device))
+            v = torch.empty(n, dtype=torch.float32, device=self.device)
+            nlp = torch.empty(n, dtype=torch.float32, device=self.device)
+            self.dm.act_rnn_into(self.params, obs, noise.contiguous(), st, self._dev_mask(M, n), st, a, v, nlp)
+            state = st.cpu().numpy()
+        else:
+            a, v, nlp, _ = self.dm.act(self.params, obs, noise)
         a = a.cpu().numpy()
         if self.pd_kind == 'categorical':
             a = a.astype(np.int64)       # tf.argmax dtype
-        return a, v.cpu().numpy(), None, nlp.cpu().numpy()
+        return a, v.cpu().numpy(), state, nlp.cpu().numpy()
 
-    def value(self, ob, *args, **kwargs):
+    def value(self, ob, *args, S=None, M=None, **kwargs):
         obs = self._to_dev_obs(ob)
+        if self.recurrent:
+            assert S is not None and M is not None, 'recurrent policy: value(obs, S=states, M=dones)'
+            return self.value_dev(obs, self._dev_state(S, obs.shape[0]), self._dev_mask(M, obs.shape[0])).cpu().numpy()
         return self.dm.act(self.params, obs, None, want_actions=False)[1].cpu().numpy()
 
-    def value_dev(self, obs_dev):
+    def value_dev(self, obs_dev, states=None, masks=None):
         if self.policy.ob_clip:
             obs_dev = obs_dev.clamp(-self.policy.ob_clip, self.policy.ob_clip)
+        if self.recurrent:
+            v = torch.empty(obs_dev.shape[0], dtype=torch.float32, device=self.device)
+            self.dm.act_rnn_into(self.params, obs_dev, None, states, masks, torch.empty_like(states), None, v, None)
+            return v
         return self.dm.act(self.params, obs_dev, None, want_actions=False)[1]
 
     # ------------------------------------------------------------------ learner
@@ -176,7 +219,7 @@ class Model(object):
         self.beta2_power = np.float32(self.beta2_power * self.beta2)
         self._train_calls += 1
 
-    def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None):
+    def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None, states=None):
         """One minibatch step reading the device rollout in place: `idx_dev` (int64 device tensor) holds
         the reference's env-major flat indices (ppo2.py:160-162); the gather is fused into the
         first-layer loaders.  Returns a device tensor [5] (no host sync).
@@ -184,6 +227,15 @@ class Model(object):
         This is the per-step host path of the launch-bound MLP configs (320 steps per update), so the
         device pointers of the long-lived buffers are cached and the two C calls are made directly."""
         stats = stats_out if stats_out is not None else torch.empty(5, dtype=torch.float32, device=self.device)
+        if self.recurrent:
+            # env-wise minibatch (ppo2.py:167-180): idx_dev = whole trajectories of the chosen envs (flat index e*T + t, env
+            # after env), states f32 device [nseq, 2*nlstm] = their states when the rollout started; masks = rollout.dones
+            assert states is not None, 'recurrent policy: train_indexed(..., states=mbstates)'
+            self.dm.grad_rnn(self.params, rollout.obs, rollout.actions, rollout.returns, rollout.values, rollout.neglogpacs,
+                             rollout.dones, states.contiguous(), states.shape[0], idx_dev, idx_dev.numel(), rollout.T,
+                             rollout.N, cliprange, self.ent_coef, self.vf_coef, self.grads, stats)
+            self._apply_gradients(lr)
+            return stats
         c = self._fast
         if c is None or c['ro'] is not rollout or c['obs_ptr'] != rollout.obs.data_ptr():
             vp = _lib.c_void_p
@@ -294,14 +346,20 @@ class Model(object):
     def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
         """Reference signature (model.py:133-158): arrays of one already-gathered minibatch (host
         NumPy or device tensors).  Returns the 5 stats as Python floats."""
-        assert states is None, 'recurrent policies are outside the supported hot path'
         obs = self._to_dev_obs(obs)
         B = obs.shape[0]
         act = self._field(actions, torch.int32 if self.pd_kind == 'categorical' else torch.float32)
         ret, val, nlp = (self._field(x, torch.float32) for x in (returns, values, neglogpacs))
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
-        self.dm.grad(self.params, obs, act, ret, val, nlp, None, B, 1, 1, cliprange, self.ent_coef, self.vf_coef,
-                     self.grads, stats)
+        if self.recurrent:             # model.py:153-155: td_map[S] = states, td_map[M] = masks
+            assert states is not None, 'recurrent policy: train(..., states=mbstates)'
+            nseq = np.asarray(states).shape[0] if not isinstance(states, torch.Tensor) else states.shape[0]
+            self.dm.grad_rnn(self.params, obs, act, ret, val, nlp, self._dev_mask(masks, B), self._dev_state(states, nseq),
+                             nseq, None, B, 1, 1, cliprange, self.ent_coef, self.vf_coef, self.grads, stats)
+        else:
+            assert states is None, 'states given to a non-recurrent policy'
+            self.dm.grad(self.params, obs, act, ret, val, nlp, None, B, 1, 1, cliprange, self.ent_coef, self.vf_coef,
+                         self.grads, stats)
         self._apply_gradients(lr)
         return [float(x) for x in stats.cpu().numpy()]
 

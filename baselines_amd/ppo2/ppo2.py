@@ -132,12 +132,30 @@ def learn(*, network, env, total_timesteps, eval_env=None, seed=None, nsteps=204
             book.eval_eps.extend(eval_runner.run()[-1])
         if chatty and root:
             logger.info('Done.')
-        assert states is None, 'recurrent policies are outside the supported hot path (SURVEY.md 8 f4)'
+        step_stats = []
+        if states is not None:
+            # recurrent version (ppo2.py:167-180): minibatches are made of whole env trajectories -- the ENV indices are
+            # shuffled (global NumPy stream), every minibatch takes nenvs // nminibatches envs with all their steps in order
+            assert nenvs % nminibatches == 0
+            envsperbatch = nenvs // nminibatches
+            envinds = np.arange(nenvs)
+            flatinds = np.arange(nenvs * nsteps).reshape(nenvs, nsteps)
+            for _ in range(noptepochs):
+                np.random.shuffle(envinds)
+                for start in range(0, nenvs, envsperbatch):
+                    mbenvinds = envinds[start:start + envsperbatch]
+                    mbflatinds = flatinds[mbenvinds].ravel()
+                    if fast:
+                        mbstates = states[torch.from_numpy(mbenvinds).to(states.device)]
+                        step_stats.append(model.train_indexed(lrnow, cliprangenow, runner.rollout,
+                                                              torch.from_numpy(mbflatinds).to(model.device), states=mbstates))
+                    else:
+                        slices = (arr[mbflatinds] for arr in (obs, returns, masks, actions, values, neglogpacs))
+                        step_stats.append(model.train(lrnow, cliprangenow, *slices, states[mbenvinds]))
 
         # noptepochs x nminibatches steps; permutations from the global NumPy stream (ppo2.py:157-160)
-        step_stats = []
         inds = np.arange(nbatch)
-        for _ in range(noptepochs):
+        for _ in range(noptepochs if states is None else 0):
             np.random.shuffle(inds)
             if fast:
                 inds_dev = torch.from_numpy(inds).to(model.device)

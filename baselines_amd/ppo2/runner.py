@@ -107,6 +107,12 @@ class Runner(AbstractEnvRunner):
         self._env_step_into = _defines(env, 'step_into')
         self._ob_np = ob_np
         self._graph, self._graph_out, self._eager_rollouts = None, None, 0
+        # recurrent policies (runner.py:23,28): the LSTM state travels with the env cursor; on the device for our Model
+        self.recurrent = self.states is not None
+        self._states_dev = None
+        if self.recurrent and self.fast_step:
+            self._states_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.states, dtype=np.float32))).to(self.device)
+        self._mb_states = None
         self._ob_clip = getattr(getattr(model, 'policy', None), 'ob_clip', None)
 
     # ------------------------------------------------------------------
@@ -117,10 +123,16 @@ class Runner(AbstractEnvRunner):
         fin_r, fin_l = [], []
         ro.obs[0].copy_(self.obs)                      # cursor -> slot 0
         nxt_last = self.obs                            # reused as the landing buffer of the last step
+        if self.recurrent:
+            self._mb_states = self._states_dev.clone()     # runner.py:23 mb_states = self.states (state BEFORE the rollout)
         for t in range(T):
             if self._ob_clip:                          # normalize_observations: the rollout holds the clipped observations
                 ro.obs[t].clamp_(-self._ob_clip, self._ob_clip)
-            self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
+            if self.recurrent:                         # runner.py:28 step(obs, S=self.states, M=self.dones)
+                self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t], states=self._states_dev,
+                                     masks=self._dones_dev)
+            else:
+                self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
             ro.dones[t].copy_(self._dones_dev)
             obs_out = ro.obs[t + 1] if t + 1 < T else nxt_last
             if self._env_step_into:
@@ -138,6 +150,8 @@ class Runner(AbstractEnvRunner):
             fin_r.append(info['fin_r'])
             fin_l.append(info['fin_l'])
         self.obs = nxt_last
+        if self.recurrent:                             # runner.py:50 value(obs, S=self.states, M=self.dones)
+            return self.model.value_dev(self.obs, self._states_dev, self._dones_dev), torch.stack(fin_r), torch.stack(fin_l)
         return self.model.value_dev(self.obs), torch.stack(fin_r), torch.stack(fin_l)
 
     def _graphable(self):
@@ -147,7 +161,8 @@ class Runner(AbstractEnvRunner):
         process talk to the runtime while we would be capturing) keep the eager loop."""
         from .model import Model
         from ..common.vec_env.synthetic_vec_env import SyntheticVecEnv
-        return (type(self.model) is Model and not self.model.multi and type(self.env) is SyntheticVecEnv and not _lib.prof_enabled()
+        return (type(self.model) is Model and not self.model.multi and not self.recurrent
+                and type(self.env) is SyntheticVecEnv and not _lib.prof_enabled()
                 and os.environ.get('MRL_ROLLOUT_GRAPH', '1') != '0' and self._graph is not False)
 
     def _run_device_env(self, ro):
@@ -190,6 +205,8 @@ class Runner(AbstractEnvRunner):
         epinfos = []
         rewards_host = np.zeros((T, self.nenv), np.float32)
         dones_host = np.zeros((T, self.nenv), np.bool_)
+        if self.recurrent:
+            self._mb_states = self._states_dev.clone() if self._states_dev is not None else np.array(self.states, copy=True)
         for t in range(T):
             if self._onehot:
                 ro.obs[t].copy_(self.model._to_dev_obs(self.obs))
@@ -202,7 +219,12 @@ class Runner(AbstractEnvRunner):
             if self._ob_clip:
                 ro.obs[t].clamp_(-self._ob_clip, self._ob_clip)
             if self.fast_step:
-                self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
+                if self.recurrent:
+                    m8 = torch.from_numpy(np.ascontiguousarray(np.asarray(self.dones, np.bool_)).view(np.uint8)).to(self.device)
+                    self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t], states=self._states_dev,
+                                         masks=m8)
+                else:
+                    self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
                 actions = ro.actions[t].cpu().numpy()
                 if ro.pd_kind == 'categorical':
                     actions = actions.astype(np.int64)
@@ -221,7 +243,9 @@ class Runner(AbstractEnvRunner):
         ro.rewards.copy_(torch.from_numpy(rewards_host))
         ro.dones.copy_(torch.from_numpy(dones_host.view(np.uint8)))
         self._dones_dev.copy_(torch.from_numpy(np.asarray(self.dones, np.bool_).view(np.uint8)))
-        if hasattr(self.model, 'value_dev') and self._onehot:
+        if self.recurrent and self._states_dev is not None:
+            last_values = self.model.value_dev(self.model._to_dev_obs(self.obs), self._states_dev, self._dones_dev)
+        elif hasattr(self.model, 'value_dev') and self._onehot:
             last_values = self.model.value_dev(self.model._to_dev_obs(self.obs))
         elif hasattr(self.model, 'value_dev'):
             obs_np = self.obs.view(np.uint8) if self.obs.dtype == np.int8 else self.obs
@@ -246,7 +270,12 @@ class Runner(AbstractEnvRunner):
                   RolloutField(ro.values, T, N, np.float32), RolloutField(ro.neglogpacs, T, N, np.float32))
         if self.return_host:
             fields = tuple(f.to_numpy() for f in fields)
-        return (*fields, self.states, epinfos)
+        states = self._mb_states if self.recurrent else self.states
+        if self.recurrent and self._states_dev is not None:
+            self.states = self._states_dev                 # the cursor's live state (device)
+            if self.return_host:
+                states = states.cpu().numpy()
+        return (*fields, states, epinfos)
 
 
 def sf01(arr):

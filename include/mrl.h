@@ -57,7 +57,7 @@ int mrl_gather_rows(const void* src, const int64_t* idx, void* dst, int B, int T
 int mrl_sf01(const void* src, void* dst, int T, int N, int row_bytes, void* stream);
 
 /* ---- model description --- common/policies.py:121-179, common/models.py:15-26,74-103 ------ */
-enum { MRL_NET_MLP = 0, MRL_NET_NATURE_CNN = 1 };
+enum { MRL_NET_MLP = 0, MRL_NET_NATURE_CNN = 1, MRL_NET_LSTM = 2, MRL_NET_CNN_LSTM = 3 };   /* models.py:74-210 */
 enum { MRL_PD_CATEGORICAL = 0, MRL_PD_DIAG_GAUSSIAN = 1 };
 enum { MRL_OB_F32 = 0, MRL_OB_U8 = 1 };
 enum { MRL_ACT_NONE = 0, MRL_ACT_RELU = 1, MRL_ACT_TANH = 2 };
@@ -73,6 +73,7 @@ typedef struct mrl_model_desc {
     int value_copy;       /* policies.py:154-166: 0 = shared latent, 1 = value_network='copy' */
     int pd_kind;          /* MRL_PD_*  (distributions.py:278-290) */
     int nact;             /* Discrete.n or Box.shape[0] */
+    int nlstm;            /* lstm / cnn_lstm: hidden state size (models.py:132, default 128; 32, 64 or 128 here) */
 } mrl_model_desc;
 
 typedef struct mrl_model mrl_model;   /* host-side layout object; owns no device memory */
@@ -98,6 +99,25 @@ int mrl_model_act(const mrl_model* m, const float* params, const void* obs, cons
                   int n, void* actions_out, float* values_out, float* neglogp_out,
                   float* pdparam_out /* [n][nact] logits or mean, may be NULL */,
                   void* workspace, size_t workspace_bytes, int chunk, void* stream);
+
+/* ---- recurrent policies --- common/models.py:132-210 (`lstm`, `cnn_lstm`), a2c/utils.py:81-102 ----------
+ * State of one environment: f32 [2*nlstm] = (c | h) (utils.py:87,101); mrl_model_state_size = 2*nlstm (0: not recurrent).
+ * act: one step of n independent sequences -- state_in (NULL: zeros) and mask u8 [n] (done flag entering the step: the
+ * state is zeroed where it is set) in, state_out out; otherwise as mrl_model_act (which rejects recurrent models).
+ * grad: a minibatch of nseq WHOLE trajectories (ppo2/ppo2.py:167-180): B = nseq * steps samples in env-major order
+ * b = seq*steps + t, given directly (idx == NULL) or as env-major flat indices into the time-major rollout (then masks
+ * is the rollout's done array like the other fields); states f32 [nseq][2*nlstm] = state of each sequence BEFORE its
+ * first step (model.py:153-155: S = states, M = masks); back-propagation through all steps of the minibatch. */
+int mrl_model_state_size(const mrl_model* m);
+int mrl_model_act_rnn(const mrl_model* m, const float* params, const void* obs, const float* noise, int n,
+                      const float* state_in, const uint8_t* mask, float* state_out, void* actions_out,
+                      float* values_out, float* neglogp_out, float* pdparam_out, void* workspace,
+                      size_t workspace_bytes, int chunk, void* stream);
+int mrl_model_grad_rnn(const mrl_model* m, const float* params, const void* obs, const void* actions,
+                       const float* returns, const float* values, const float* neglogpacs, const uint8_t* masks,
+                       const float* states, int nseq, const int64_t* idx, int B, int T, int N, float cliprange,
+                       float ent_coef, float vf_coef, float* grads_out, float* stats_out, void* workspace,
+                       size_t workspace_bytes, int chunk, void* stream);
 
 /* ---- K4+K5+K6+K7: gradient of the PPO2 loss on one minibatch --- ppo2/model.py:57-91,133-158
  * Rollout fields are time-major [T*N] (obs [T*N][ob...]); idx int64 [B] are the reference's

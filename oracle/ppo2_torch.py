@@ -27,7 +27,7 @@ from .ppo2_numpy import ortho_init
 
 
 def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
-                      num_layers=2, num_hidden=64):
+                      num_layers=2, num_hidden=64, nlstm=128):
     """Ordered (name, shape, init_scale|None) list in TF variable-creation order
     (SURVEY.md App. A.6): policy net -> value net copy -> pi head -> [logstd] -> vf head."""
     specs = []
@@ -48,6 +48,28 @@ def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
             specs.append((prefix + '/fc1/w', (h3 * w3 * 64, 512), math.sqrt(2)))
             specs.append((prefix + '/fc1/b', (512,), None))
             return 512
+        elif network in ('lstm', 'cnn_lstm'):
+            # common/models.py:132-210: [nature_cnn ->] a2c/utils.py:81-102 lstm(scope='lstm', init_scale=1.0):
+            # wx [nin, 4nh], wh [nh, 4nh] orthogonal, b [4nh] zeros; created in that order after the conv stack
+            if network == 'cnn_lstm':
+                h, w, c = ob_shape
+                specs.append((prefix + '/c1/w', (8, 8, c, 32), math.sqrt(2)))
+                specs.append((prefix + '/c1/b', (1, 32, 1, 1), None))
+                specs.append((prefix + '/c2/w', (4, 4, 32, 64), math.sqrt(2)))
+                specs.append((prefix + '/c2/b', (1, 64, 1, 1), None))
+                specs.append((prefix + '/c3/w', (3, 3, 64, 64), math.sqrt(2)))
+                specs.append((prefix + '/c3/b', (1, 64, 1, 1), None))
+                h1, w1 = (h - 8) // 4 + 1, (w - 8) // 4 + 1
+                h2, w2 = (h1 - 4) // 2 + 1, (w1 - 4) // 2 + 1
+                specs.append((prefix + '/fc1/w', ((h2 - 2) * (w2 - 2) * 64, 512), math.sqrt(2)))
+                specs.append((prefix + '/fc1/b', (512,), None))
+                nin = 512
+            else:
+                nin = int(np.prod(ob_shape))
+            specs.append((prefix + '/lstm/wx', (nin, 4 * nlstm), 1.0))
+            specs.append((prefix + '/lstm/wh', (nlstm, 4 * nlstm), 1.0))
+            specs.append((prefix + '/lstm/b', (4 * nlstm,), None))
+            return nlstm
         elif network == 'mlp':
             nin = int(np.prod(ob_shape))
             for i in range(num_layers):
@@ -60,6 +82,8 @@ def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
     nlat = net('ppo2_model/pi')
     nlat_v = nlat
     if value_network == 'copy':
+        # policies.py:162-165: "recurrent architectures are not supported with value_network=copy yet"
+        assert network not in ('lstm', 'cnn_lstm')
         nlat_v = net('ppo2_model/vf')
     # distributions.py:351-355 _matching_fc: no head when latent width == size
     has_pi_head = (nlat != nact)
@@ -96,14 +120,15 @@ class OracleModel(object):
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_network=None,
                  ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float32,
                  params=None, num_layers=2, num_hidden=64, total_weight=1.0, rank_weight=1.0,
-                 allreduce=None):
+                 allreduce=None, nlstm=128):
         self.network, self.ob_shape, self.ob_dtype = network, tuple(ob_shape), np.dtype(ob_dtype)
         self.pd_kind, self.nact, self.value_network = pd_kind, nact, value_network
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.dtype = dtype
-        self.num_layers, self.num_hidden = num_layers, num_hidden
+        self.num_layers, self.num_hidden, self.nlstm = num_layers, num_hidden, nlstm
+        self.recurrent = network in ('lstm', 'cnn_lstm')
         self.specs, self.has_pi_head = build_param_specs(network, ob_shape, pd_kind, nact, value_network,
-                                                         num_layers, num_hidden)
+                                                         num_layers, num_hidden, nlstm)
         if params is None:
             params = init_params(self.specs)
         self.names = [s[0] for s in self.specs]
@@ -116,13 +141,38 @@ class OracleModel(object):
         self.beta1_power, self.beta2_power = npdt(0.9), npdt(0.999)
         self.npdt = npdt
         self.rank_weight, self.total_weight, self.allreduce = rank_weight, total_weight, allreduce
+        # common/models.py:171: initial_state = np.zeros([nenv, 2*nlstm]) of the act model (sized by the caller)
         self.initial_state = None
         self.last_grads = None
 
     # ---- networks ---------------------------------------------------------
+    def _lstm(self, feat, S, M, nenv, prefix):
+        """common/models.py:158-170 + a2c/utils.py:65-102: feat [nenv*nsteps, nin] in ENV-MAJOR order (batch_to_seq
+        reshapes to [nenv, nsteps, -1]), S [nenv, 2nh] (c | h), M [nenv*nsteps] -> (h [nenv*nsteps, nh], snew)"""
+        p = self.p
+        nh = self.nlstm
+        nsteps = feat.shape[0] // nenv
+        xs = feat.reshape(nenv, nsteps, -1)
+        ms = torch.as_tensor(np.asarray(M, dtype=np.float64)).to(self.dtype).reshape(nenv, nsteps)
+        S = torch.as_tensor(np.asarray(S)).to(self.dtype)
+        c, h = S[:, :nh], S[:, nh:]
+        wx, wh, b = p[prefix + '/lstm/wx'], p[prefix + '/lstm/wh'], p[prefix + '/lstm/b']
+        out = []
+        for t in range(nsteps):
+            m = ms[:, t:t + 1]
+            c = c * (1 - m)
+            h = h * (1 - m)
+            z = xs[:, t] @ wx + h @ wh + b
+            i, f, o, u = torch.sigmoid(z[:, :nh]), torch.sigmoid(z[:, nh:2 * nh]), torch.sigmoid(z[:, 2 * nh:3 * nh]), \
+                torch.tanh(z[:, 3 * nh:])
+            c = f * c + i * u
+            h = o * torch.tanh(c)
+            out.append(h)
+        return torch.stack(out, dim=1).reshape(nenv * nsteps, nh), torch.cat([c, h], dim=1)
+
     def _net(self, x, prefix):
         p = self.p
-        if self.network == 'cnn':
+        if self.network in ('cnn', 'cnn_lstm'):
             # models.py:19: tf.cast(float32) / 255.
             h = x.to(self.dtype) / 255.
             h = h.permute(0, 3, 1, 2)
@@ -132,15 +182,21 @@ class OracleModel(object):
                 h = F.relu(F.conv2d(h, w, b, stride=stride))
             h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)  # conv_to_fc on NHWC
             return F.relu(h @ p[prefix + '/fc1/w'] + p[prefix + '/fc1/b'])
+        elif self.network == 'lstm':
+            return x.to(self.dtype).reshape(x.shape[0], -1)       # tf.layers.flatten (models.py:150)
         else:
             h = x.to(self.dtype).reshape(x.shape[0], -1)
             for i in range(self.num_layers):
                 h = torch.tanh(h @ p[prefix + '/mlp_fc%d/w' % i] + p[prefix + '/mlp_fc%d/b' % i])
             return h
 
-    def forward(self, obs):
+    def forward(self, obs, S=None, M=None, nenv=None):
+        """recurrent networks: obs rows in env-major order, S [nenv, 2nh], M [nenv*nsteps]; the new state is left in
+        self.last_state (PolicyWithValue.state, policies.py:77-96)"""
         x = torch.as_tensor(np.asarray(obs))
         lat = self._net(x, 'ppo2_model/pi')
+        if self.recurrent:
+            lat, self.last_state = self._lstm(lat, S, M, nenv if nenv is not None else x.shape[0], 'ppo2_model/pi')
         vlat = self._net(x, 'ppo2_model/vf') if self.value_network == 'copy' else lat
         if self.has_pi_head:
             pi = lat @ self.p['ppo2_model/pi/w'] + self.p['ppo2_model/pi/b']
@@ -173,9 +229,9 @@ class OracleModel(object):
         return (logstd_b + .5 * math.log(2.0 * math.pi * math.e)).sum(-1)
 
     # ---- act side ---------------------------------------------------------
-    def step(self, obs, noise, **_):
+    def step(self, obs, noise, S=None, M=None, **_):
         with torch.no_grad():
-            pi, vf = self.forward(obs)
+            pi, vf = self.forward(obs, S, M)
             nz = torch.as_tensor(np.asarray(noise)).to(self.dtype)
             if self.pd_kind == 'categorical':
                 a = torch.argmax(pi - torch.log(-torch.log(nz)), dim=-1)
@@ -183,14 +239,15 @@ class OracleModel(object):
                 a = pi + torch.exp(pi * 0.0 + self.p['ppo2_model/pi/logstd']) * nz
             nlp = self._neglogp(pi, a)
         a_np = a.numpy().astype(np.int64) if self.pd_kind == 'categorical' else a.numpy().astype(np.float32)
-        return a_np, vf.numpy().astype(np.float32), None, nlp.numpy().astype(np.float32)
+        state = self.last_state.numpy().astype(np.float32) if self.recurrent else None
+        return a_np, vf.numpy().astype(np.float32), state, nlp.numpy().astype(np.float32)
 
-    def value(self, obs, **_):
+    def value(self, obs, S=None, M=None, **_):
         with torch.no_grad():
-            return self.forward(obs)[1].numpy().astype(np.float32)
+            return self.forward(obs, S, M)[1].numpy().astype(np.float32)
 
     # ---- learner ------------------------------------------------------------
-    def loss_and_stats(self, obs, returns, actions, values, neglogpacs, cliprange, advs):
+    def loss_and_stats(self, obs, returns, actions, values, neglogpacs, cliprange, advs, states=None, masks=None):
         dt = self.dtype
         R = torch.as_tensor(np.asarray(returns)).to(dt)
         OLDV = torch.as_tensor(np.asarray(values)).to(dt)
@@ -199,7 +256,10 @@ class OracleModel(object):
         A = torch.as_tensor(np.asarray(actions))
         if self.pd_kind != 'categorical':
             A = A.to(dt)
-        pi, vpred = self.forward(obs)
+        if self.recurrent:      # model.py:153-155: S = states, M = masks; train model built with nsteps (model.py:40-43)
+            pi, vpred = self.forward(obs, states, masks, nenv=np.asarray(states).shape[0])
+        else:
+            pi, vpred = self.forward(obs)
         neglogpac = self._neglogp(pi, A)
         entropy = self._entropy(pi).mean()
         vpredclipped = OLDV + torch.clamp(vpred - OLDV, -cliprange, cliprange)
@@ -223,7 +283,7 @@ class OracleModel(object):
         advs = returns - values
         return (advs - advs.mean()) / (advs.std() + 1e-8)
 
-    def compute_grads(self, cliprange, obs, returns, actions, values, neglogpacs, advs=None):
+    def compute_grads(self, cliprange, obs, returns, actions, values, neglogpacs, advs=None, states=None, masks=None):
         """model.py:136-139 + graph gradients.  Returns (stats, flat unclipped grad ndarray).
         `advs` given: already normalised (the MicrobatchedModel slices, microbatched_model.py:40-56)."""
         returns = np.asarray(returns)
@@ -232,7 +292,7 @@ class OracleModel(object):
             advs = self._normalised_advs(returns, values)
         for t in self.p.values():
             t.grad = None
-        loss, stats = self.loss_and_stats(obs, returns, actions, values, neglogpacs, cliprange, advs)
+        loss, stats = self.loss_and_stats(obs, returns, actions, values, neglogpacs, cliprange, advs, states, masks)
         loss.backward()
         grads = []
         for k in self.names:
@@ -276,7 +336,7 @@ class OracleModel(object):
         self.beta2_power = self.npdt(self.beta2_power * self.beta2)
 
     def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
-        stats, flat = self.compute_grads(cliprange, obs, returns, actions, values, neglogpacs)
+        stats, flat = self.compute_grads(cliprange, obs, returns, actions, values, neglogpacs, states=states, masks=masks)
         self.apply_flat_grad(lr, flat)
         return stats
 
