@@ -218,8 +218,10 @@ def test_total_timesteps_zero_builds_model_only():
     model = ppo2.learn(network='mlp', env=env, total_timesteps=0, seed=1, nsteps=8)
     a, v, s, nlp = model.step(np.zeros((4, 4), np.float32))
     assert a.shape == (4,) and a.dtype == np.int64 and v.shape == (4,) and s is None and nlp.shape == (4,)
-    with pytest.raises(ValueError):
-        ppo2.learn(network='lstm', env=env, total_timesteps=0)
+    with pytest.raises(ValueError):                       # common/models.py:275 'Unknown network type'
+        ppo2.learn(network='impala_cnn', env=env, total_timesteps=0)
+    rec = ppo2.learn(network='lstm', env=env, total_timesteps=0, nlstm=32)     # recurrent policies build too
+    assert rec.initial_state.shape == (4, 64)
 
 
 @pytest.mark.parametrize('kind', ['cartpole', 'mujoco'])
