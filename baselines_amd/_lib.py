@@ -20,7 +20,15 @@ class ModelDesc(ctypes.Structure):
                 ('pd_kind', c_int), ('nact', c_int), ('nlstm', c_int)]
 
 
-NET_MLP, NET_NATURE_CNN, NET_LSTM, NET_CNN_LSTM = 0, 1, 2, 3
+NET_MLP, NET_NATURE_CNN, NET_LSTM, NET_CNN_LSTM, NET_CONV_ONLY = 0, 1, 2, 3, 4
+
+
+class QNetDesc(ctypes.Structure):
+    """mirror of mrl_qnet_desc (include/mrl.h)"""
+    _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
+                ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('nconv', c_int),
+                ('convs', (c_int * 3) * 4), ('nhidden', c_int), ('hiddens', c_int * 4), ('dueling', c_int), ('nact', c_int)]
+
 PD_CATEGORICAL, PD_DIAG_GAUSSIAN = 0, 1
 OB_F32, OB_U8 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
@@ -60,6 +68,18 @@ SIGNATURES = {
                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'mrl_adam_clip_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float,
                                        c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'mrl_qnet_create': (c_int, [ctypes.POINTER(QNetDesc), ctypes.POINTER(c_void_p)]),
+    'mrl_qnet_destroy': (None, [c_void_p]),
+    'mrl_qnet_num_params': (c_long, [c_void_p]),
+    'mrl_qnet_num_tensors': (c_int, [c_void_p]),
+    'mrl_qnet_tensor_info': (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int * 4),
+                                     ctypes.POINTER(c_long), ctypes.POINTER(c_int), ctypes.POINTER(c_double)]),
+    'mrl_qnet_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'mrl_qnet_values': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_qnet_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_qnet_td_grad': (c_int, [c_void_p] * 9 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    'mrl_qnet_adam_step': (c_int, [c_void_p] * 5 + [c_float] * 5 + [c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_synth_env_obs': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

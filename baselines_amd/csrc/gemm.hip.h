@@ -167,11 +167,16 @@ struct ConvGeom {
     const void* p; int H, W, C, rf, stride, OH, OW; int npix; int kconv;   // npix = B*OH*OW, kconv = rf*rf*C
     int rowk;                                                              // rf*C
     const int32_t* srow;
-    FastDiv d_ohw, d_ow, d_rowk;
+    // zero padding above / left of the image (SAME convolutions of the DQN `conv_only` net, common/models.py:222-249;
+    // taps below / right of the image are out of range too); 0 for the VALID convolutions of NatureCNN.  Only the generic
+    // tiled engine (ConvPatchKC / ConvPatchMC) honours it.
+    int pad_t = 0, pad_l = 0;
+    FastDiv d_ohw, d_ow, d_rowk, d_c;
     void finish() {
         rowk = rf * C;
-        d_ohw = FastDiv::make(OH * OW); d_ow = FastDiv::make(OW); d_rowk = FastDiv::make(rowk);
+        d_ohw = FastDiv::make(OH * OW); d_ow = FastDiv::make(OW); d_rowk = FastDiv::make(rowk); d_c = FastDiv::make(C);
     }
+    __host__ __device__ bool padded() const { return (pad_t | pad_l) != 0 || (OH - 1) * stride + rf > H || (OW - 1) * stride + rf > W; }
 };
 template <bool U8> __device__ __forceinline__ float4 conv_ld(const void* p, long off) {
     if (U8) {
@@ -188,7 +193,7 @@ template <bool U8> __device__ __forceinline__ float4 conv_ld(const void* p, long
 }
 template <bool U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixel, GEMM k = conv-k
     static constexpr bool KC = true;
-    template <int NV> struct State { long base[NV]; int k, ky, kr; };
+    template <int NV> struct State { long base[NV]; int iy0[NV], ix0[NV]; int k, ky, kr; };
     template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
         s.k = k0 + (tid & 7) * 4;
         s.ky = (int)d_rowk.div((uint32_t)s.k);
@@ -200,12 +205,21 @@ template <bool U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixe
             int b = (int)d_ohw.div((uint32_t)m), r = m - b * ohw;
             int oy = (int)d_ow.div((uint32_t)r), ox = r - oy * OW;
             long img = srow ? (long)srow[b] : (long)b;
-            s.base[i] = ((img * H + oy * stride) * W + ox * stride) * C;
+            s.iy0[i] = oy * stride - pad_t;
+            s.ix0[i] = ox * stride - pad_l;
+            s.base[i] = ((img * H + s.iy0[i]) * W + s.ix0[i]) * C;
         }
     }
     template <int NV> __device__ __forceinline__ void fetch(State<NV>& s, float4 (&v)[NV]) const {
         const long koff = (long)s.ky * W * C + s.kr;
-        if (s.k < kconv) {
+        if (s.k < kconv && padded()) {                   // taps outside the image read zeros
+            const int kx = (int)d_c.div((uint32_t)s.kr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const bool ok = (unsigned)(s.iy0[i] + s.ky) < (unsigned)H && (unsigned)(s.ix0[i] + kx) < (unsigned)W;
+                v[i] = ok ? conv_ld<U8>(p, s.base[i] + koff) : f4zero();
+            }
+        } else if (s.k < kconv) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = conv_ld<U8>(p, s.base[i] + koff);
         } else {
@@ -219,7 +233,7 @@ template <bool U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixe
 };
 template <bool U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k, GEMM k = pixel
     static constexpr bool KC = false;
-    template <int NV> struct State { long koff; int m; int b[NV]; int r[NV]; bool rvalid; };
+    template <int NV> struct State { long koff; int m; int b[NV]; int r[NV]; bool rvalid; int ky, kx; };
     template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
         constexpr int V4 = NV * 8, LPP = 32 / NV;
         int row = r0 + (tid % V4) * 4;
@@ -227,6 +241,8 @@ template <bool U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k
         int rc = min(row, kconv - 4);
         int ky = (int)d_rowk.div((uint32_t)rc), kr = rc - ky * rowk;
         s.koff = (long)ky * W * C + kr;
+        s.ky = ky;
+        s.kx = (int)d_c.div((uint32_t)kr);
         s.m = k0 + tid / V4;
         const int ohw = OH * OW;
 #pragma unroll
@@ -245,7 +261,9 @@ template <bool U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k
             if (s.rvalid && s.m + i * LPP < npix) {
                 int oy = (int)d_ow.div((uint32_t)s.r[i]), ox = s.r[i] - oy * OW;
                 long img = srow ? (long)srow[s.b[i]] : (long)s.b[i];
-                v[i] = conv_ld<U8>(p, ((img * H + oy * stride) * W + ox * stride) * C + s.koff);
+                const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
+                if ((unsigned)(iy0 + s.ky) < (unsigned)H && (unsigned)(ix0 + s.kx) < (unsigned)W)
+                    v[i] = conv_ld<U8>(p, ((img * H + iy0) * W + ix0) * C + s.koff);
             }
             s.r[i] += GEMM_BK;
             while (s.r[i] >= ohw) { s.r[i] -= ohw; ++s.b[i]; }
@@ -258,6 +276,9 @@ template <bool U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k
 // parity class z = py*stride + px: row -> (b, yy, xx) with iy = yy*stride + py.  GEMM k = (tap, n),
 // tap = (a, b2), contributing output pixel (yy - a, xx - b2) and filter tap (py + stride*a, px + stride*b2).
 struct DgradGeom {
+    // H, W: extent of the (zero-padded) input the class grid enumerates; Hr, Wr: the real image, which starts at
+    // (pad_t, pad_l) of the padded one (SAME convolutions; pad = 0 and Hr = H for VALID)
+    int Hr = 0, Wr = 0, pad_t = 0, pad_l = 0;
     int H, W, C, rf, stride, OH, OW, NF, taps;   // taps per dim = ceil(rf/stride)
     int HY, WX;                                   // class grid extents: ceil(H/stride), ceil(W/stride)
     int B;
@@ -371,9 +392,10 @@ struct EpiDgradConv : DgradGeom {   // scatter rows of class z back to NHWC, mas
         int b = (int)d_per.div((uint32_t)m), r = m - b * per;
         int yy = (int)d_wx.div((uint32_t)r), xx = r - yy * WX;
         int py = z / stride, px = z - py * stride;
-        int iy = yy * stride + py, ix = xx * stride + px;
-        if (iy >= H || ix >= W) return -1;
-        return ((long)(b * H + iy) * W + ix) * C + n;
+        int iy = yy * stride + py - pad_t, ix = xx * stride + px - pad_l;
+        const int hr = Hr ? Hr : H, wr = Wr ? Wr : W;
+        if ((unsigned)iy >= (unsigned)hr || (unsigned)ix >= (unsigned)wr) return -1;
+        return ((long)(b * hr + iy) * wr + ix) * C + n;
     }
     __device__ __forceinline__ float aux(long o, int) const { return h ? h[o] : 1.f; }
     __device__ __forceinline__ void put(long o, float acc, float hv) const { out[o] = h ? acc * act_bwd_from_out(hv, act) : acc; }

@@ -35,6 +35,7 @@ using namespace mrl;
 struct Layer {
     int kind;   // 0 conv, 1 fc
     int H, W, C, rf, stride, OH, OW, NF;   // conv
+    int pad_t, pad_l;                      // conv: zero padding above / left (SAME convolutions of `conv_only`; 0 = VALID)
     int K, N;                              // fc (and conv: K = rf*rf*C, N = NF)
     int act;
     long w_off, b_off;
@@ -1034,8 +1035,12 @@ static inline int is_vec(const void* p, long ld) { return (ld % 4 == 0) && ((uin
 
 static void fill_conv(ConvGeom& g, const Layer& l, const void* p, int npix, const int32_t* srow) {
     g.p = p; g.H = l.H; g.W = l.W; g.C = l.C; g.rf = l.rf; g.stride = l.stride; g.OH = l.OH; g.OW = l.OW;
-    g.npix = npix; g.kconv = l.K; g.srow = srow;
+    g.npix = npix; g.kconv = l.K; g.srow = srow; g.pad_t = l.pad_t; g.pad_l = l.pad_l;
     g.finish();
+}
+// SAME-padded layers (taps outside the image) run on the generic tiled engine only
+static bool layer_padded(const Layer& l) {
+    return l.kind == 0 && (l.pad_t || l.pad_l || (l.OH - 1) * l.stride + l.rf > l.H || (l.OW - 1) * l.stride + l.rf > l.W);
 }
 
 static int num_cus() {
@@ -1052,14 +1057,14 @@ static int num_cus() {
 // can the weights-resident engine run this conv layer's forward / data-gradient?
 constexpr int WRES_PF = 8;
 static bool wres_fwd_ok(const Layer& l, bool u8, const void* src) {
-    if (l.kind != 0 || l.NF > 64 || wres_lds_bytes(1, l.NF, l.K) > 160 * 1024) return false;
+    if (l.kind != 0 || layer_padded(l) || l.NF > 64 || wres_lds_bytes(1, l.NF, l.K) > 160 * 1024) return false;
     const int rowk = l.rf * l.C;
     if (u8) return (l.stride * l.C) % 16 == 0 && (l.W * l.C) % 16 == 0 && ((long)l.H * l.W * l.C) % 16 == 0 &&
                    rowk == 32 && l.rf % WRES_PF == 0 && (uintptr_t)src % 16 == 0;
     return l.C % 4 == 0 && rowk % (8 * WRES_PF) == 0 && (uintptr_t)src % 16 == 0;
 }
 static bool wres_dgrad_ok(const Layer& l) {
-    if (l.kind != 0 || l.C > 64 || l.NF != 8 * WRES_PF) return false;
+    if (l.kind != 0 || layer_padded(l) || l.C > 64 || l.NF != 8 * WRES_PF) return false;
     const int taps = (l.rf + l.stride - 1) / l.stride;
     return wres_lds_bytes(l.stride * l.stride, l.C, taps * taps * l.NF) <= 160 * 1024;
 }
@@ -1084,7 +1089,7 @@ static int wres_dispatch(const char* lname, const char* pass, int variant, int n
 // image-resident weight gradient: compiled for the NatureCNN geometries (imgres.hip.h is templated on
 // the layer shape so that all im2col addressing folds into instruction immediates)
 static int imgres_kind(const Layer& l, bool u8, const void* src) {
-    if (l.kind != 0 || (uintptr_t)src % 16 != 0) return 0;
+    if (l.kind != 0 || layer_padded(l) || (uintptr_t)src % 16 != 0) return 0;
     if (u8 && l.H == 84 && l.W == 84 && l.C == 4 && l.rf == 8 && l.stride == 4 && l.NF == 32) return 1;
     if (!u8 && l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2 && l.NF == 64) return 2;
     if (!u8 && l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1 && l.NF == 64) return 3;
@@ -1211,7 +1216,7 @@ static int net_forward(const mrl_model* m, const Net& net, const In& in, const f
 
 static inline const float* hprev_of(const NetWs& nw, int i) { return i ? nw.h[i - 1] : nullptr; }
 static int ldsdgrad_kind(const Layer& l, const float* dz) {
-    if (l.kind != 0 || (uintptr_t)dz % 16 != 0) return 0;
+    if (l.kind != 0 || layer_padded(l) || (uintptr_t)dz % 16 != 0) return 0;
     if (l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2 && l.NF == 64) return 1;
     if (l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1 && l.NF == 64) return 2;
     return 0;
@@ -1289,8 +1294,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             if (l.kind == 0) {
                 DgradGeom g;
                 g.H = l.H; g.W = l.W; g.C = l.C; g.rf = l.rf; g.stride = l.stride; g.OH = l.OH; g.OW = l.OW;
+                if (layer_padded(l)) {      // enumerate the zero-padded input; the epilogue maps back and drops the border
+                    g.Hr = l.H; g.Wr = l.W; g.pad_t = l.pad_t; g.pad_l = l.pad_l;
+                    g.H = (l.OH - 1) * l.stride + l.rf; g.W = (l.OW - 1) * l.stride + l.rf;
+                }
                 g.NF = l.NF; g.taps = (l.rf + l.stride - 1) / l.stride;
-                g.HY = (l.H + l.stride - 1) / l.stride; g.WX = (l.W + l.stride - 1) / l.stride; g.B = B;
+                g.HY = (g.H + l.stride - 1) / l.stride; g.WX = (g.W + l.stride - 1) / l.stride; g.B = B;
                 g.finish();
                 if (l.NF % 4 != 0 || (long)B * g.HY * g.WX > 0x7fffffffL) return MRL_EUNSUP;
                 int Kd = g.taps * g.taps * l.NF;
@@ -1824,3 +1833,5 @@ extern "C" int mrl_model_grad_rnn(const mrl_model* m, const float* params, const
     return model_grad_range(m, params, obs, actions, returns, values, neglogpacs, idx, B, 0, B, T, N, cliprange, ent_coef,
                             vf_coef, grads_out, stats_out, workspace, workspace_bytes, chunk, stream, false, nullptr, &r);
 }
+
+#include "qnet.hip.h"

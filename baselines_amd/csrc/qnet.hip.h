@@ -1,0 +1,395 @@
+// DQN Q-network on gfx950: layout + forward / TD-gradient orchestration + per-variable gradient
+// clipping and Adam.  Included at the end of model.hip: it re-uses that file's layer machinery (Layer / Net / NetWs,
+// layer_forward, net_backward, the GEMM engines and the deterministic slab reductions).
+//
+// Reference map (paths relative to baselines/):
+//   q_func            deepq/models.py:5-45 `build_q_func(network, hiddens=[256], dueling=True)`:
+//                       latent = network(X) -> flatten -> action_value: [fc(h) -> relu]* -> fc(num_actions)
+//                       [dueling] state_value: [fc(h) -> relu]* -> fc(1);  q = V + (A - mean_a A)
+//   networks          common/models.py:74-103 `mlp`, :15-26 `nature_cnn` ('cnn'), :222-249 `conv_only`
+//                       (tf.contrib.layers.convolution2d: SAME padding, ReLU, xavier-uniform weights, zero biases;
+//                       heads: tf.contrib.layers.fully_connected, same defaults)
+//   TD graph          deepq/build_graph.py:380-421: q_t online on obs_t; q_tp1 TARGET net on obs_tp1; double-Q argmax
+//                       from the ONLINE net on obs_tp1; Huber(td) weighted mean (mrl_dqn_td, replay.hip);
+//                       gradients w.r.t. the online variables only, each clipped by its OWN norm (tf.clip_by_norm, 10)
+//   act               deepq/build_graph.py:146-199: argmax_a q, replaced by a uniform random action with probability eps
+#pragma once
+
+struct mrl_qnet {
+    mrl_qnet_desc qd;
+    mrl_model base;                 // tensor table / P / ob_elems; base.pi = the feature network
+    Net av, sv;                     // action_value / state_value heads (fc layers on the flattened latent)
+    int nlat, lat_act;
+    bool dueling;
+    std::vector<int> init_kind;     // per tensor: 0 zeros, 1 orthogonal (scale in base.tensors), 2 xavier uniform
+};
+
+static long q_add_tensor(mrl_qnet* q, const std::string& name, std::vector<int> shape, int kind, double scale) {
+    long off = add_tensor(&q->base, name, shape, scale);
+    q->init_kind.push_back(kind);
+    return off;
+}
+
+static int q_build_heads(mrl_qnet* q, Net& net, const std::string& scope, int nout) {
+    int nin = q->nlat;
+    for (int i = 0; i <= q->qd.nhidden; ++i) {
+        const bool last = i == q->qd.nhidden;
+        Layer f{};
+        f.kind = 1; f.K = nin; f.N = last ? nout : q->qd.hiddens[i]; f.act = last ? ACT_NONE : ACT_RELU;
+        if (f.N < 1) return MRL_EINVAL;
+        // tf.contrib.layers.fully_connected names: fully_connected, fully_connected_1, ... inside the scope
+        std::string nm = scope + (i ? "/fully_connected_" + std::to_string(i) : std::string("/fully_connected"));
+        f.w_off = q_add_tensor(q, nm + "/weights", {f.K, f.N}, 2, 1.0);
+        f.b_off = q_add_tensor(q, nm + "/biases", {f.N}, 0, -1.0);
+        f.out_elems = f.N;
+        snprintf(f.name, sizeof f.name, "%s%d", scope.find("action") != std::string::npos ? "av" : "sv", i);
+        net.L.push_back(f);
+        nin = f.N;
+    }
+    net.nlat = nin; net.lat_act = ACT_NONE;
+    return 0;
+}
+
+extern "C" int mrl_qnet_create(const mrl_qnet_desc* d, mrl_qnet** out) {
+    if (!d || !out || d->nact < 1 || d->ob_ndim < 1 || d->ob_ndim > 3 || d->nhidden < 0 || d->nhidden > 4) return MRL_EINVAL;
+    mrl_qnet* q = new mrl_qnet();
+    q->qd = *d;
+    q->dueling = d->dueling != 0;
+    mrl_model& m = q->base;
+    m.P = 0; m.ob_elems = 1;
+    for (int i = 0; i < d->ob_ndim; ++i) m.ob_elems *= d->ob_shape[i];
+    memset(&m.d, 0, sizeof m.d);
+    m.d.network = d->network; m.d.ob_ndim = d->ob_ndim; m.d.ob_dtype = d->ob_dtype;
+    for (int i = 0; i < 3; ++i) m.d.ob_shape[i] = d->ob_shape[i];
+    m.d.num_layers = d->num_layers; m.d.num_hidden = d->num_hidden; m.d.activation = d->activation;
+    m.d.nact = d->nact; m.d.pd_kind = MRL_PD_CATEGORICAL;
+    m.vf_copy = false; m.has_pi_head = false; m.HP = 0;
+    const std::string scope = "deepq/q_func";
+    int rc = 0;
+    if (d->network == MRL_NET_CONV_ONLY) {
+        if (d->ob_ndim != 3 || d->ob_dtype != MRL_OB_U8 || d->ob_shape[2] % 4 != 0 || d->nconv < 1 || d->nconv > 4) rc = MRL_EUNSUP;
+        int H = d->ob_shape[0], W = d->ob_shape[1], C = d->ob_shape[2];
+        for (int i = 0; i < d->nconv && !rc; ++i) {
+            const int nf = d->convs[i][0], rf = d->convs[i][1], st = d->convs[i][2];
+            if (nf < 1 || nf % 4 != 0 || rf < 1 || st < 1) { rc = MRL_EUNSUP; break; }
+            Layer l{};
+            l.kind = 0; l.H = H; l.W = W; l.C = C; l.rf = rf; l.stride = st; l.NF = nf;
+            // SAME: out = ceil(in / stride); total padding = max((out - 1)*stride + rf - in, 0), the smaller half in front
+            l.OH = (H + st - 1) / st; l.OW = (W + st - 1) / st;
+            l.pad_t = std::max((l.OH - 1) * st + rf - H, 0) / 2;
+            l.pad_l = std::max((l.OW - 1) * st + rf - W, 0) / 2;
+            l.K = rf * rf * C; l.N = nf; l.act = ACT_RELU;
+            std::string nm = scope + "/convnet/" + (i ? "Conv_" + std::to_string(i) : std::string("Conv"));
+            l.w_off = q_add_tensor(q, nm + "/weights", {rf, rf, C, nf}, 2, 1.0);
+            l.b_off = q_add_tensor(q, nm + "/biases", {nf}, 0, -1.0);
+            l.out_elems = (long)l.OH * l.OW * nf;
+            snprintf(l.name, sizeof l.name, "qc%d", i + 1);
+            m.pi.L.push_back(l);
+            H = l.OH; W = l.OW; C = nf;
+        }
+        m.pi.nlat = H * W * C; m.pi.lat_act = ACT_RELU;
+    } else if (d->network == MRL_NET_MLP || d->network == MRL_NET_NATURE_CNN) {
+        const size_t before = m.tensors.size();
+        rc = build_net(&m, m.pi, scope);                                   // ortho_init weights (a2c/utils.py:20-35)
+        for (size_t i = before; i < m.tensors.size(); ++i) q->init_kind.push_back(m.tensors[i].scale < 0 ? 0 : 1);
+    } else {
+        rc = MRL_EUNSUP;
+    }
+    if (rc) { delete q; return rc; }
+    q->nlat = m.pi.nlat; q->lat_act = m.pi.lat_act;
+    rc = q_build_heads(q, q->av, scope + "/action_value", d->nact);
+    if (!rc && q->dueling) rc = q_build_heads(q, q->sv, scope + "/state_value", 1);
+    if (rc) { delete q; return rc; }
+    *out = q;
+    return 0;
+}
+extern "C" void mrl_qnet_destroy(mrl_qnet* q) { delete q; }
+extern "C" long mrl_qnet_num_params(const mrl_qnet* q) { return q ? q->base.P : 0; }
+extern "C" int mrl_qnet_num_tensors(const mrl_qnet* q) { return q ? (int)q->base.tensors.size() : 0; }
+extern "C" int mrl_qnet_tensor_info(const mrl_qnet* q, int i, char* name, int name_cap, int* ndim, int shape[4], long* offset,
+                                    int* init_kind, double* init_scale) {
+    if (!q || i < 0 || i >= (int)q->base.tensors.size()) return MRL_EINVAL;
+    if (init_kind) *init_kind = q->init_kind[i];
+    return mrl_model_tensor_info(&q->base, i, name, name_cap, ndim, shape, offset, init_scale);
+}
+
+// ---- workspace ------------------------------------------------------------------------------------------------------
+struct QWs {
+    NetWs feat, av, sv;
+    float *q_t, *q_tp1, *q_tp1_on, *dq, *dlat_tmp;
+    float* part; size_t part_floats;
+    void* td_scratch;
+    double* sqpart;          // per-tensor sum-of-squares partials
+    float* zeros;
+    size_t total;
+};
+constexpr int Q_SQ_BLOCKS = 64;      // partial blocks per tensor
+
+static void q_carve(const mrl_qnet* q, int B, char* base, QWs& ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    size_t part_floats = 1;
+    auto do_net = [&](const Net& net, NetWs& nw) {
+        nw.h.clear(); nw.dz.clear();
+        for (const Layer& l : net.L) {
+            nw.h.push_back((float*)take((size_t)B * l.out_elems * 4));
+            nw.dz.push_back((float*)take((size_t)B * l.out_elems * 4));
+            part_floats = std::max(part_floats, (size_t)max_split_floats(l.K, l.N, layer_rows(l, B)));
+        }
+        nw.planes = nullptr; nw.dbg = nullptr;
+    };
+    do_net(q->base.pi, ws.feat);
+    do_net(q->av, ws.av);
+    if (q->dueling) do_net(q->sv, ws.sv);
+    const size_t qa = (size_t)B * q->qd.nact * 4;
+    ws.q_t = (float*)take(qa); ws.q_tp1 = (float*)take(qa); ws.q_tp1_on = (float*)take(qa); ws.dq = (float*)take(qa);
+    ws.dlat_tmp = (float*)take((size_t)B * q->nlat * 4);
+    ws.part = (float*)take(part_floats * 4);
+    ws.part_floats = part_floats;
+    ws.td_scratch = take(mrl_dqn_td_scratch_bytes(B));
+    ws.sqpart = (double*)take((size_t)q->base.tensors.size() * Q_SQ_BLOCKS * 8);
+    ws.zeros = (float*)take(2048);
+    ws.total = off;
+}
+extern "C" size_t mrl_qnet_workspace_bytes(const mrl_qnet* q, int batch) {
+    if (!q || batch <= 0) return 0;
+    QWs ws;
+    q_carve(q, batch, nullptr, ws);
+    return ws.total;
+}
+
+// ---- small kernels --------------------------------------------------------------------------------------------------
+// q = V + (A - mean_a A)  (deepq/models.py:37-40); sv == nullptr: q = A
+__global__ __launch_bounds__(256) void q_dueling_fwd_kernel(const float* __restrict__ av, const float* __restrict__ sv,
+                                                            float* __restrict__ q, int B, int nA) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* a = av + (long)b * nA;
+    float mean = 0.f;
+    if (sv) {
+        float s = 0.f;
+        for (int j = 0; j < nA; ++j) s += a[j];
+        mean = s / (float)nA;
+    }
+    for (int j = 0; j < nA; ++j) q[(long)b * nA + j] = sv ? sv[b] + (a[j] - mean) : a[j];
+}
+// dA = dq - mean_a dq;  dV = sum_a dq
+__global__ __launch_bounds__(256) void q_dueling_bwd_kernel(const float* __restrict__ dq, float* __restrict__ dav,
+                                                            float* __restrict__ dsv, int B, int nA) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* d = dq + (long)b * nA;
+    float s = 0.f;
+    for (int j = 0; j < nA; ++j) s += d[j];
+    const float mean = s / (float)nA;
+    for (int j = 0; j < nA; ++j) dav[(long)b * nA + j] = dsv ? d[j] - mean : d[j];
+    if (dsv) dsv[b] = s;
+}
+// eps-greedy (build_graph.py:181-190): argmax_a q (first maximum wins, tf.argmax), a random action where u < eps
+__global__ __launch_bounds__(256) void q_act_kernel(const float* __restrict__ q, const float* __restrict__ u,
+                                                    const int32_t* __restrict__ rnd, float eps, int32_t* __restrict__ act,
+                                                    int B, int nA) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* r = q + (long)b * nA;
+    int best = 0;
+    float bv = r[0];
+    for (int j = 1; j < nA; ++j)
+        if (r[j] > bv) { bv = r[j]; best = j; }
+    act[b] = (u && u[b] < eps) ? rnd[b] : best;
+}
+// out = (out_prev + acc) * act'(h): second half of a two-source data gradient
+struct EpiAddMaskAct {
+    static constexpr bool HAS_BIAS = false;
+    float* out; long ld; const float* add; const float* h; int act;
+    __device__ __forceinline__ long addr(int m, int n, int) const { return (long)m * ld + n; }
+    __device__ __forceinline__ float aux(long o, int) const { return add ? add[o] : 0.f; }
+    __device__ __forceinline__ void put(long o, float acc, float a) const {
+        const float v = acc + a;
+        out[o] = h ? v * act_bwd_from_out(h[o], act) : v;
+    }
+};
+
+struct QTensorTable { int n; long off[40]; long size[40]; };
+__global__ __launch_bounds__(256) void q_sumsq_kernel(const float* __restrict__ g, QTensorTable tt, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int t = blockIdx.y;
+    const float* p = g + tt.off[t];
+    double s = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < tt.size[t]; i += (long)gridDim.x * 256L) s += (double)p[i] * (double)p[i];
+    const double r = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[t * gridDim.x + blockIdx.x] = r;
+}
+// per-variable tf.clip_by_norm (build_graph.py:416-421: t * clip / max(||t||, clip)) then TF-1 ApplyAdam
+__global__ __launch_bounds__(256) void q_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, QTensorTable tt, const double* __restrict__ part,
+                                                     int npart, float alpha, float beta1, float beta2, float eps, float clip) {
+    __shared__ float s_scale;
+    const int t = blockIdx.y;
+    if (threadIdx.x == 0) {
+        float scale = 1.f;
+        if (clip > 0.f) {
+            double s = 0.0;
+            for (int i = 0; i < npart; ++i) s += part[t * npart + i];
+            const float nrm = (float)sqrt(s);
+            scale = clip / fmaxf(nrm, clip);
+        }
+        s_scale = scale;
+    }
+    __syncthreads();
+    const float scale = s_scale, omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    const long o = tt.off[t];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < tt.size[t]; i += (long)gridDim.x * 256L) {
+        const float x = g[o + i] * scale;
+        g[o + i] = x;
+        float mi = m[o + i], vi = v[o + i];
+        mi = mi + (x - mi) * omb1;
+        vi = vi + (x * x - vi) * omb2;
+        m[o + i] = mi; v[o + i] = vi;
+        p[o + i] = p[o + i] - (mi * alpha) / (sqrtf(vi) + eps);
+    }
+}
+
+// ---- forward --------------------------------------------------------------------------------------------------------
+static int q_heads_forward(const mrl_qnet* q, const Net& net, const float* lat, const float* params, NetWs& nw, int B,
+                           hipStream_t st) {
+    In in{lat, nullptr};
+    for (size_t i = 0; i < net.L.size(); ++i) {
+        int rc = layer_forward(&q->base, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static int q_forward(const mrl_qnet* q, const float* params, const void* obs, int B, QWs& ws, float* q_out, hipStream_t st) {
+    In in{obs, nullptr};
+    int rc = net_forward(&q->base, q->base.pi, in, params, ws.feat, B, st);
+    if (rc) return rc;
+    const float* lat = ws.feat.h.back();
+    if ((rc = q_heads_forward(q, q->av, lat, params, ws.av, B, st))) return rc;
+    if (q->dueling && (rc = q_heads_forward(q, q->sv, lat, params, ws.sv, B, st))) return rc;
+    hipLaunchKernelGGL(q_dueling_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.av.h.back(),
+                       q->dueling ? ws.sv.h.back() : nullptr, q_out, B, q->qd.nact);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrl_qnet_values(const mrl_qnet* q, const float* params, const void* obs, int n, float* q_out, void* workspace,
+                               size_t workspace_bytes, int batch, void* stream) {
+    if (!q || !params || !obs || !q_out || !workspace || n <= 0 || batch <= 0) return MRL_EINVAL;
+    QWs ws;
+    q_carve(q, batch, (char*)workspace, ws);
+    if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    const size_t ob_bytes = (size_t)q->base.ob_elems * (q->qd.ob_dtype == MRL_OB_U8 ? 1 : 4);
+    for (int c0 = 0; c0 < n; c0 += batch) {
+        const int Bc = std::min(batch, n - c0);
+        int rc = q_forward(q, params, (const char*)obs + (size_t)c0 * ob_bytes, Bc, ws, q_out + (size_t)c0 * q->qd.nact,
+                           (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int mrl_qnet_act(const mrl_qnet* q, const float* params, const void* obs, int n, float eps, const float* uniforms,
+                            const int32_t* rand_actions, int32_t* actions_out, float* q_out, void* workspace,
+                            size_t workspace_bytes, int batch, void* stream) {
+    if (!q || !actions_out || n > batch || (uniforms && !rand_actions)) return MRL_EINVAL;
+    QWs ws;
+    q_carve(q, batch, (char*)workspace, ws);
+    if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    float* qo = q_out ? q_out : ws.q_t;
+    int rc = mrl_qnet_values(q, params, obs, n, qo, workspace, workspace_bytes, batch, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(q_act_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, qo, uniforms, rand_actions, eps,
+                       actions_out, n, q->qd.nact);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- TD gradient --- deepq/build_graph.py:380-421 -------------------------------------------------------------------
+static int q_heads_backward(const mrl_qnet* q, const Net& net, const float* lat, const float* params, NetWs& nw, QWs& qws,
+                            float* grads, float* dlat, bool add, int B, hipStream_t st) {
+    // weight gradients of the head layers + data gradients between them (net_backward treats `in.obs` as the fc input)
+    Ws ws{};
+    ws.part = qws.part; ws.part_floats = qws.part_floats; ws.zeros = qws.zeros;
+    In in{lat, nullptr};
+    StepCtx ctx;
+    int rc = net_backward(&q->base, net, in, params, nw, ws, grads, B, 0, st, ctx, false);
+    if (rc) return rc;
+    // into the latent: dlat (+)= dz0 @ W0^T, masked by act'(latent) when it is the last contribution
+    const Layer& l0 = net.L[0];
+    const float* dz = nw.dz[0];
+    const float* W = params + l0.w_off;
+    RowKC af{dz, l0.N, B, l0.N, is_vec(dz, l0.N), nullptr};
+    RowKC bf{W, l0.N, l0.K, l0.N, is_vec(W, l0.N), nullptr};
+    const int dv = pick_variant(l0.name, "dgrad", B, l0.K);
+    const float* hm = q->base.pi.L.empty() ? nullptr : qws.feat.h.back();
+    if (add) {
+        EpiAddMaskAct ef{dlat, l0.K, qws.dlat_tmp, hm, q->lat_act};
+        return gemm_dispatch(l0.name, "dgrad", dv, af, bf, ef, B, l0.K, l0.N, 1, l0.N, st);
+    }
+    EpiMaskAct ef{q->dueling ? qws.dlat_tmp : dlat, l0.K, q->dueling ? nullptr : hm, q->lat_act};
+    return gemm_dispatch(l0.name, "dgrad", dv, af, bf, ef, B, l0.K, l0.N, 1, l0.N, st);
+}
+
+extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const float* target_params, const void* obs_t,
+                                const int32_t* act, const float* rew, const void* obs_tp1, const float* done,
+                                const float* weights, float gamma, int double_q, int B, float* grads_out, float* td_out,
+                                float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!q || !params || !target_params || !obs_t || !act || !rew || !obs_tp1 || !done || !weights || !grads_out || !td_out ||
+        !loss_out || !workspace || B <= 0)
+        return MRL_EINVAL;
+    if (q->base.pi.L.empty()) return MRL_EUNSUP;
+    hipStream_t st = (hipStream_t)stream;
+    QWs ws;
+    q_carve(q, B, (char*)workspace, ws);
+    if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    const int nA = q->qd.nact;
+    int rc;
+    // the two obs_tp1 passes first (their activations are not needed again), then obs_t whose activations feed the backward
+    if ((rc = q_forward(q, target_params, obs_tp1, B, ws, ws.q_tp1, st))) return rc;
+    if (double_q && (rc = q_forward(q, params, obs_tp1, B, ws, ws.q_tp1_on, st))) return rc;
+    if ((rc = q_forward(q, params, obs_t, B, ws, ws.q_t, st))) return rc;
+    if ((rc = mrl_dqn_td(ws.q_t, ws.q_tp1, double_q ? ws.q_tp1_on : nullptr, act, rew, done, weights, gamma, B, nA, td_out,
+                         loss_out, ws.dq, ws.td_scratch, stream)))
+        return rc;
+    hipLaunchKernelGGL(q_dueling_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.dq, ws.av.dz.back(),
+                       q->dueling ? ws.sv.dz.back() : nullptr, B, nA);
+    MRL_LAUNCH_CHECK();
+    const float* lat = ws.feat.h.back();
+    float* dlat = ws.feat.dz.back();
+    if ((rc = q_heads_backward(q, q->av, lat, params, ws.av, ws, grads_out, dlat, false, B, st))) return rc;
+    if (q->dueling && (rc = q_heads_backward(q, q->sv, lat, params, ws.sv, ws, grads_out, dlat, true, B, st))) return rc;
+    Ws mws{};
+    mws.part = ws.part; mws.part_floats = ws.part_floats; mws.zeros = ws.zeros;
+    In in{obs_t, nullptr};
+    StepCtx ctx;
+    return net_backward(&q->base, q->base.pi, in, params, ws.feat, mws, grads_out, B, 0, st, ctx, false);
+}
+
+// per-variable clip_by_norm + Adam (deepq/deepq.py:205-208: tf.train.AdamOptimizer(lr), grad_norm_clipping=10)
+extern "C" int mrl_qnet_adam_step(const mrl_qnet* q, float* params, float* grads, float* adam_m, float* adam_v, float alpha,
+                                  float beta1, float beta2, float eps, float grad_norm_clipping, void* workspace,
+                                  size_t workspace_bytes, int batch, void* stream) {
+    if (!q || !params || !grads || !adam_m || !adam_v || !workspace) return MRL_EINVAL;
+    QWs ws;
+    q_carve(q, batch, (char*)workspace, ws);
+    if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    QTensorTable tt;
+    tt.n = (int)q->base.tensors.size();
+    if (tt.n > 40) return MRL_EUNSUP;
+    for (int i = 0; i < tt.n; ++i) {
+        const TensorInfo& t = q->base.tensors[i];
+        long n = 1;
+        for (int k = 0; k < t.ndim; ++k) n *= t.shape[k];
+        tt.off[i] = t.off; tt.size[i] = n;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_norm_clipping > 0.f) {
+        hipLaunchKernelGGL(q_sumsq_kernel, dim3(Q_SQ_BLOCKS, tt.n), dim3(256), 0, st, grads, tt, ws.sqpart);
+        MRL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(q_adam_kernel, dim3(Q_SQ_BLOCKS, tt.n), dim3(256), 0, st, params, grads, adam_m, adam_v, tt, ws.sqpart,
+                       Q_SQ_BLOCKS, alpha, beta1, beta2, eps, grad_norm_clipping);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}

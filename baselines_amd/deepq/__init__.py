@@ -1,5 +1,8 @@
-"""DQN replay slice: HBM-resident (prioritized) replay buffer, device
-segment trees, TD-target / Huber kernel and the schedules that drive them.  The training loop
-`deepq.learn` itself (d6) and the Q-network builders (d7) are outside this round's scope."""
+"""DQN on the device: HBM-resident (prioritized) replay buffer, device segment trees,
+TD-target / Huber kernel, the Q-network (build_q_func: mlp / cnn / conv_only features, dueling heads), and the
+reference's `deepq.learn` loop around them."""
 from ..common.schedules import LinearSchedule  # noqa: F401
 from .replay_buffer import PrioritizedReplayBuffer, ReplayBuffer, dqn_td_loss  # noqa: F401
+from .models import build_q_func  # noqa: F401
+from .qmodel import QModel  # noqa: F401
+from .deepq import ActWrapper, learn, load_act  # noqa: F401

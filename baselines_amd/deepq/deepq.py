@@ -1,0 +1,161 @@
+"""`deepq.learn` with the reference's signature and loop (deepq/deepq.py:95-333): one host environment, eps-greedy
+acting, (prioritized) replay in HBM, a train step every `train_freq` steps after `learning_starts`, target-network copy
+every `target_network_update_freq` steps, ActWrapper with save / load.
+
+What runs where: the Q-networks, the TD target / Huber loss / per-variable clip / Adam, the replay ring and the segment
+trees are HIP kernels behind the C ABI (QModel, replay_buffer.py); the loop below is the reference's control flow."""
+import os
+
+import numpy as np
+
+from .. import logger
+from ..common import set_global_seeds
+from ..common.schedules import LinearSchedule
+from .models import build_q_func
+from .qmodel import QModel
+from .replay_buffer import PrioritizedReplayBuffer, ReplayBuffer
+
+
+class ActWrapper(object):
+    """deepq/deepq.py:23-78"""
+
+    def __init__(self, model, act_params):
+        self._model = model
+        self._act_params = act_params
+        self.initial_state = None
+
+    def __call__(self, *args, **kwargs):
+        return self._model.act(*args, **kwargs)
+
+    def step(self, observation, **kwargs):
+        # DQN doesn't use RNNs so we ignore states and masks
+        kwargs.pop('S', None)
+        kwargs.pop('M', None)
+        return self._model.act([observation], **kwargs), None, None, None
+
+    def save(self, path):
+        """tf_util.save_variables: joblib dict {variable name: ndarray}"""
+        import joblib
+        dirname = os.path.dirname(path)
+        if dirname:
+            os.makedirs(dirname, exist_ok=True)
+        joblib.dump(self._model.variables(), path)
+
+    def save_act(self, path=None):
+        """pickle of (variables, act_params) -- the reference zips a TF checkpoint next to the cloudpickled act_params"""
+        import cloudpickle
+        if path is None:
+            path = os.path.join(logger.get_dir(), 'model.pkl')
+        with open(path, 'wb') as f:
+            cloudpickle.dump((self._model.variables(), self._act_params), f)
+
+    @staticmethod
+    def load_act(path):
+        import cloudpickle
+        with open(path, 'rb') as f:
+            variables, act_params = cloudpickle.load(f)
+        model = QModel(**act_params)
+        model.load_variables(variables)
+        return ActWrapper(model, act_params)
+
+
+def load_act(path):
+    return ActWrapper.load_act(path)
+
+
+def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=50000, exploration_fraction=0.1,
+          exploration_final_eps=0.02, train_freq=1, batch_size=32, print_freq=100, checkpoint_freq=10000,
+          checkpoint_path=None, learning_starts=1000, gamma=1.0, target_network_update_freq=500, prioritized_replay=False,
+          prioritized_replay_alpha=0.6, prioritized_replay_beta0=0.4, prioritized_replay_beta_iters=None,
+          prioritized_replay_eps=1e-6, param_noise=False, callback=None, load_path=None, **network_kwargs):
+    if param_noise:
+        raise NotImplementedError('parameter-space noise is outside the supported hot path')
+    set_global_seeds(seed)
+    q_func = build_q_func(network, **network_kwargs)
+    act_params = dict(q_func=q_func, observation_space=env.observation_space, num_actions=env.action_space.n)
+    # deepq.py:205-213: AdamOptimizer(learning_rate=lr) (epsilon 1e-8), gamma, grad_norm_clipping=10, double_q (default)
+    model = QModel(lr=lr, gamma=gamma, grad_norm_clipping=10, max_batch=batch_size, **act_params)
+    act = ActWrapper(model, act_params)
+
+    if prioritized_replay:
+        replay_buffer = PrioritizedReplayBuffer(buffer_size, alpha=prioritized_replay_alpha)
+        if prioritized_replay_beta_iters is None:
+            prioritized_replay_beta_iters = total_timesteps
+        beta_schedule = LinearSchedule(prioritized_replay_beta_iters, initial_p=prioritized_replay_beta0, final_p=1.0)
+    else:
+        replay_buffer = ReplayBuffer(buffer_size)
+        beta_schedule = None
+    exploration = LinearSchedule(schedule_timesteps=int(exploration_fraction * total_timesteps), initial_p=1.0,
+                                 final_p=exploration_final_eps)
+    model.update_target()
+
+    episode_rewards = [0.0]
+    saved_mean_reward = None
+    obs = env.reset()
+    model_file = os.path.join(checkpoint_path, 'model') if checkpoint_path else None
+    model_saved = False
+    saved_variables = None
+    if model_file and os.path.exists(model_file):
+        import joblib
+        model.load_variables(joblib.load(model_file))
+        logger.info('Loaded model from {}'.format(model_file))
+        model_saved = True
+    elif load_path is not None:
+        import joblib
+        model.load_variables(joblib.load(os.path.expanduser(load_path)))
+        logger.info('Loaded model from {}'.format(load_path))
+
+    for t in range(total_timesteps):
+        if callback is not None:
+            if callback(locals(), globals()):
+                break
+        update_eps = exploration.value(t)
+        action = act(np.array(obs)[None], update_eps=update_eps)[0]
+        new_obs, rew, done, _ = env.step(action)
+        replay_buffer.add(obs, action, rew, new_obs, float(done))
+        obs = new_obs
+
+        episode_rewards[-1] += rew
+        if done:
+            obs = env.reset()
+            episode_rewards.append(0.0)
+
+        if t > learning_starts and t % train_freq == 0:
+            if prioritized_replay:
+                experience = replay_buffer.sample(batch_size, beta=beta_schedule.value(t))
+                (obses_t, actions, rewards, obses_tp1, dones, weights, batch_idxes) = experience
+            else:
+                obses_t, actions, rewards, obses_tp1, dones = replay_buffer.sample(batch_size)
+                weights, batch_idxes = np.ones_like(rewards), None
+            td_errors = model.train(obses_t, actions, rewards, obses_tp1, dones, weights)
+            if prioritized_replay:
+                new_priorities = np.abs(td_errors) + prioritized_replay_eps
+                replay_buffer.update_priorities(batch_idxes, new_priorities)
+
+        if t > learning_starts and t % target_network_update_freq == 0:
+            model.update_target()
+
+        mean_100ep_reward = round(np.mean(episode_rewards[-101:-1]), 1) if len(episode_rewards) > 1 else float('nan')
+        num_episodes = len(episode_rewards)
+        if done and print_freq is not None and len(episode_rewards) % print_freq == 0:
+            logger.record_tabular('steps', t)
+            logger.record_tabular('episodes', num_episodes)
+            logger.record_tabular('mean 100 episode reward', mean_100ep_reward)
+            logger.record_tabular('% time spent exploring', int(100 * exploration.value(t)))
+            logger.dump_tabular()
+
+        if checkpoint_freq is not None and t > learning_starts and num_episodes > 100 and t % checkpoint_freq == 0:
+            if saved_mean_reward is None or mean_100ep_reward > saved_mean_reward:
+                if print_freq is not None:
+                    logger.info('Saving model due to mean reward increase: {} -> {}'.format(saved_mean_reward,
+                                                                                           mean_100ep_reward))
+                saved_variables = model.variables()
+                if model_file:
+                    act.save(model_file)
+                model_saved = True
+                saved_mean_reward = mean_100ep_reward
+    if model_saved and saved_variables is not None:
+        if print_freq is not None:
+            logger.info('Restored model with mean reward: {}'.format(saved_mean_reward))
+        model.load_variables(saved_variables)
+    return act

@@ -1,0 +1,222 @@
+"""Device Q-network pair (online + target) with the three functions `deepq.build_train` returns
+(deepq/build_graph.py:317-449):
+
+    act(ob, stochastic=True, update_eps=-1)            eps-greedy actions (:146-199)
+    train(obs_t, action, reward, obs_tp1, done, weight) -> td_errors   one Adam step on the weighted Huber TD loss (:380-444)
+    update_target()                                    target <- online (:423-428)
+    debug['q_values'](obs)
+
+Parameters, Adam slots and the target copy are flat fp32 device buffers in TF variable-creation order; the work is done
+by libmrl's C ABI (mrl_qnet_values / mrl_qnet_act / mrl_qnet_td_grad / mrl_qnet_adam_step, include/mrl.h)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import c_void_p, check, ptr, stream_ptr
+from ..ppo2.model import ortho_init
+
+
+class QModel(object):
+    def __init__(self, q_func, observation_space, num_actions, lr=5e-4, gamma=1.0, grad_norm_clipping=10, double_q=True,
+                 max_batch=32, adam_epsilon=1e-8, device=None):
+        _lib.require_gpu()
+        lib = self.lib = _lib.load()
+        self.device = torch.device(device or ('cuda:%d' % torch.cuda.current_device()))
+        self.num_actions, self.gamma, self.double_q = int(num_actions), float(gamma), bool(double_q)
+        self.grad_norm_clipping = -1.0 if grad_norm_clipping is None else float(grad_norm_clipping)
+        self.lr = float(lr)
+        d = _lib.QNetDesc()
+        net = q_func.network
+        d.network = {'mlp': _lib.NET_MLP, 'cnn': _lib.NET_NATURE_CNN, 'conv_only': _lib.NET_CONV_ONLY}[net.kind]
+        # deepq/utils.py ObservationInput -> common/input.py:43-63: Discrete observations are fed one-hot encoded
+        self.ob_onehot = int(observation_space.n) if type(observation_space).__name__ == 'Discrete' else 0
+        if self.ob_onehot:
+            ob_shape, ob_dtype = (self.ob_onehot,), np.dtype(np.float32)
+        else:
+            ob_shape = tuple(int(s) for s in observation_space.shape)
+            ob_dtype = np.dtype(observation_space.dtype)
+        if net.kind == 'mlp':
+            ob_shape = (int(np.prod(ob_shape)),)
+        d.ob_ndim = len(ob_shape)
+        for i, s in enumerate(ob_shape):
+            d.ob_shape[i] = s
+        d.ob_dtype = _lib.OB_U8 if ob_dtype in (np.dtype(np.uint8), np.dtype(np.int8)) else _lib.OB_F32
+        d.num_layers, d.num_hidden = int(net.kw.get('num_layers', 2)), int(net.kw.get('num_hidden', 64))
+        d.activation = {'tanh': _lib.ACT_TANH, 'relu': _lib.ACT_RELU}[net.kw.get('activation', 'tanh')]
+        convs = net.kw.get('convs', ())
+        d.nconv = len(convs)
+        for i, c in enumerate(convs):
+            for k in range(3):
+                d.convs[i][k] = int(c[k])
+        d.nhidden = len(q_func.hiddens)
+        for i, h in enumerate(q_func.hiddens):
+            d.hiddens[i] = int(h)
+        d.dueling = 1 if q_func.dueling else 0
+        d.nact = self.num_actions
+        self.ob_shape, self.torch_ob_dtype = ob_shape, (torch.uint8 if d.ob_dtype == _lib.OB_U8 else torch.float32)
+        h = c_void_p()
+        check(lib.mrl_qnet_create(ctypes.byref(d), ctypes.byref(h)), 'mrl_qnet_create')
+        self.handle = h
+        self.P = int(lib.mrl_qnet_num_params(h))
+        self.tensors = []
+        name = ctypes.create_string_buffer(160)
+        for i in range(lib.mrl_qnet_num_tensors(h)):
+            nd, shp, off, kind, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_int(), ctypes.c_double()
+            check(lib.mrl_qnet_tensor_info(h, i, name, 160, ctypes.byref(nd), ctypes.byref(shp), ctypes.byref(off),
+                                           ctypes.byref(kind), ctypes.byref(sc)), 'mrl_qnet_tensor_info')
+            shape = tuple(shp[k] for k in range(nd.value))
+            self.tensors.append(dict(name=name.value.decode(), shape=shape, offset=off.value, size=int(np.prod(shape)),
+                                     init_kind=kind.value, init_scale=sc.value))
+        self.params = torch.from_numpy(self._initial_parameters()).to(self.device)
+        self.target = self.params.clone()               # deepq.py:236-237 U.initialize(); update_target()
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.beta1, self.beta2, self.epsilon = np.float32(0.9), np.float32(0.999), np.float32(adam_epsilon)
+        self.beta1_power, self.beta2_power = np.float32(0.9), np.float32(0.999)
+        self.eps = 0.0                                   # the graph's `eps` variable (build_graph.py:177)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(torch.initial_seed()) & 0x7fffffff)
+        self.max_batch = 0
+        self._set_batch(max_batch)
+        self._td = torch.empty(self.max_batch, dtype=torch.float32, device=self.device)
+        self._loss = torch.empty(1, dtype=torch.float32, device=self.device)
+
+    def _initial_parameters(self):
+        """common.models networks: orthogonal init from the global NumPy stream like the reference (a2c/utils.py:20-35);
+        tf.contrib layers (conv_only, the Q heads): xavier-uniform weights U(+-sqrt(6 / (fan_in + fan_out))), zero biases.
+        TF draws those from its own generator, which cannot be reproduced: the NumPy global stream stands in."""
+        flat = np.zeros(self.P, np.float32)
+        for t in self.tensors:
+            sl = slice(t['offset'], t['offset'] + t['size'])
+            if t['init_kind'] == 1:
+                flat[sl] = ortho_init(t['shape'], t['init_scale']).reshape(-1)
+            elif t['init_kind'] == 2:
+                shape = t['shape']
+                receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+                fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                flat[sl] = np.random.uniform(-lim, lim, size=t['size']).astype(np.float32)
+        return flat
+
+    def _set_batch(self, n):
+        if n > self.max_batch:
+            self.max_batch = int(n)
+            nbytes = int(self.lib.mrl_qnet_workspace_bytes(self.handle, self.max_batch))
+            self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.mrl_qnet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _obs(self, ob):
+        if self.ob_onehot:
+            t = ob.to(self.device) if isinstance(ob, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(ob))).to(self.device)
+            if t.dim() < 2 or t.shape[-1] != self.ob_onehot or not t.is_floating_point():
+                t = torch.nn.functional.one_hot(t.reshape(-1).long(), self.ob_onehot)
+            return t.to(torch.float32).reshape(-1, self.ob_onehot).contiguous()
+        if isinstance(ob, torch.Tensor):
+            t = ob.to(self.device)
+        else:
+            a = np.asarray(ob)
+            if a.dtype == np.int8:
+                a = a.view(np.uint8)
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if t.dtype != self.torch_ob_dtype:
+            t = t.to(self.torch_ob_dtype)
+        return t.reshape((-1,) + tuple(self.ob_shape)).contiguous()
+
+    # ---- the reference's three functions ----------------------------------------------------------------------------
+    def q_values(self, ob, target=False):
+        obs = self._obs(ob)
+        n = obs.shape[0]
+        self._set_batch(min(n, 4096))
+        out = torch.empty((n, self.num_actions), dtype=torch.float32, device=self.device)
+        check(self.lib.mrl_qnet_values(self.handle, ptr(self.target if target else self.params), ptr(obs), n, ptr(out),
+                                       ptr(self.workspace), self.workspace.numel(), self.max_batch, stream_ptr()),
+              'mrl_qnet_values')
+        return out.cpu().numpy()
+
+    def act(self, ob, stochastic=True, update_eps=-1):
+        """build_graph.py:146-199; returns int64 actions [n] like tf.argmax"""
+        obs = self._obs(ob)
+        n = obs.shape[0]
+        self._set_batch(n)
+        u = rnd = None
+        if stochastic:
+            # the chose_random draw uses the eps of the PREVIOUS call: eps.assign is an update op of the same run whose
+            # read is not ordered after it (build_graph.py:191-196)
+            u = torch.rand(n, generator=self._gen, device=self.device, dtype=torch.float32)
+            rnd = torch.randint(0, self.num_actions, (n,), generator=self._gen, device=self.device, dtype=torch.int32)
+        a = torch.empty(n, dtype=torch.int32, device=self.device)
+        check(self.lib.mrl_qnet_act(self.handle, ptr(self.params), ptr(obs), n, float(self.eps), ptr(u), ptr(rnd), ptr(a),
+                                    None, ptr(self.workspace), self.workspace.numel(), self.max_batch, stream_ptr()),
+              'mrl_qnet_act')
+        if update_eps >= 0:
+            self.eps = float(update_eps)
+        return a.cpu().numpy().astype(np.int64)
+
+    def train(self, obs_t, action, reward, obs_tp1, done, weight):
+        """one optimizer step; returns td_errors f32 [B] (build_graph.py:430-441)"""
+        o1, o2 = self._obs(obs_t), self._obs(obs_tp1)
+        B = o1.shape[0]
+        self._set_batch(B)
+        f = lambda x, dt: (x.to(self.device, dt) if isinstance(x, torch.Tensor)
+                           else torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(self.device).to(dt)).contiguous()
+        a, r, d, w = f(action, torch.int32), f(reward, torch.float32), f(done, torch.float32), f(weight, torch.float32)
+        td = torch.empty(B, dtype=torch.float32, device=self.device)
+        check(self.lib.mrl_qnet_td_grad(self.handle, ptr(self.params), ptr(self.target), ptr(o1), ptr(a), ptr(r), ptr(o2),
+                                        ptr(d), ptr(w), self.gamma, int(self.double_q), B, ptr(self.grads), ptr(td),
+                                        ptr(self._loss), ptr(self.workspace), self.workspace.numel(), stream_ptr()),
+              'mrl_qnet_td_grad')
+        one = np.float32(1)
+        alpha = np.float32(self.lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
+        check(self.lib.mrl_qnet_adam_step(self.handle, ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
+                                          float(alpha), float(self.beta1), float(self.beta2), float(self.epsilon),
+                                          self.grad_norm_clipping, ptr(self.workspace), self.workspace.numel(),
+                                          self.max_batch, stream_ptr()), 'mrl_qnet_adam_step')
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        self.last_td = td
+        return td.cpu().numpy()
+
+    def update_target(self):
+        self.target.copy_(self.params)
+
+    # ---- checkpoints: {tf_variable_name: ndarray} like tf_util.save_variables (tf_util.py:345-372) ----------------
+    def variables(self):
+        out = {'deepq/eps:0': np.float32(self.eps)}
+        for buf, scope, suffix in ((self.params, 'deepq/q_func', ''), (self.target, 'deepq/target_q_func', ''),
+                                   (self.adam_m, 'deepq/q_func', '/Adam'), (self.adam_v, 'deepq/q_func', '/Adam_1')):
+            host = buf.detach().cpu().numpy()
+            for t in self.tensors:
+                nm = t['name'].replace('deepq/q_func', scope, 1) + suffix + ':0'
+                out[nm] = host[t['offset']:t['offset'] + t['size']].reshape(t['shape']).copy()
+        out['beta1_power:0'], out['beta2_power:0'] = np.float32(self.beta1_power), np.float32(self.beta2_power)
+        return out
+
+    def load_variables(self, d):
+        for buf, scope, suffix, required in ((self.params, 'deepq/q_func', '', True), (self.target, 'deepq/target_q_func', '', False),
+                                             (self.adam_m, 'deepq/q_func', '/Adam', False),
+                                             (self.adam_v, 'deepq/q_func', '/Adam_1', False)):
+            host = buf.detach().cpu().numpy()
+            for t in self.tensors:
+                nm = t['name'].replace('deepq/q_func', scope, 1) + suffix + ':0'
+                if nm in d:
+                    host[t['offset']:t['offset'] + t['size']] = np.asarray(d[nm], np.float32).reshape(-1)
+                elif required:
+                    raise KeyError(nm)
+            buf.copy_(torch.from_numpy(host))
+        if 'deepq/eps:0' in d:
+            self.eps = float(d['deepq/eps:0'])
+        if 'beta1_power:0' in d:
+            self.beta1_power, self.beta2_power = np.float32(d['beta1_power:0']), np.float32(d['beta2_power:0'])
+
+    def get_flat_params(self):
+        return self.params.detach().cpu().numpy().copy()

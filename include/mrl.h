@@ -57,7 +57,8 @@ int mrl_gather_rows(const void* src, const int64_t* idx, void* dst, int B, int T
 int mrl_sf01(const void* src, void* dst, int T, int N, int row_bytes, void* stream);
 
 /* ---- model description --- common/policies.py:121-179, common/models.py:15-26,74-103 ------ */
-enum { MRL_NET_MLP = 0, MRL_NET_NATURE_CNN = 1, MRL_NET_LSTM = 2, MRL_NET_CNN_LSTM = 3 };   /* models.py:74-210 */
+enum { MRL_NET_MLP = 0, MRL_NET_NATURE_CNN = 1, MRL_NET_LSTM = 2, MRL_NET_CNN_LSTM = 3,
+       MRL_NET_CONV_ONLY = 4 /* Q-networks only */ };                            /* models.py:74-249 */
 enum { MRL_PD_CATEGORICAL = 0, MRL_PD_DIAG_GAUSSIAN = 1 };
 enum { MRL_OB_F32 = 0, MRL_OB_U8 = 1 };
 enum { MRL_ACT_NONE = 0, MRL_ACT_RELU = 1, MRL_ACT_TANH = 2 };
@@ -255,6 +256,50 @@ size_t mrl_dqn_td_scratch_bytes(int B);
 int mrl_dqn_td(const float* q_t, const float* q_tp1_target, const float* q_tp1_online, const int32_t* act,
                const float* rew, const float* done, const float* weights, float gamma, int B, int nA,
                float* td_out, float* loss_out, float* dq_out, void* scratch, void* stream);
+
+/* ---- DQN Q-network --- deepq/models.py:5-45 (build_q_func), deepq/build_graph.py:146-199, 380-444 ----------
+ * q_func = network(X) -> flatten -> action_value [fc(h) relu]* fc(nact) [+ dueling: state_value [fc(h) relu]* fc(1),
+ * q = V + A - mean_a A].  network: MRL_NET_MLP / MRL_NET_NATURE_CNN (common/models.py, orthogonal init) or
+ * MRL_NET_CONV_ONLY (models.py:222-249: tf.contrib convolution2d, SAME padding, ReLU, xavier-uniform init).
+ * Parameters: ONE flat f32 buffer per network copy (online / target) in TF variable-creation order; tensor i is
+ * described by mrl_qnet_tensor_info (TF names "deepq/q_func/..."; init_kind 0 zeros, 1 orthogonal * init_scale,
+ * 2 xavier uniform).  `update_target` (build_graph.py:423-428) is a device copy of that buffer by the caller. */
+typedef struct mrl_qnet_desc {
+    int network;            /* MRL_NET_MLP | MRL_NET_NATURE_CNN | MRL_NET_CONV_ONLY */
+    int ob_ndim;  int ob_shape[3];  int ob_dtype;
+    int num_layers, num_hidden, activation;      /* mlp */
+    int nconv;  int convs[4][3];                 /* conv_only: (num_outputs, kernel_size, stride) per layer */
+    int nhidden;  int hiddens[4];                /* build_q_func(hiddens=[256]) */
+    int dueling;                                 /* build_q_func(dueling=True) */
+    int nact;
+} mrl_qnet_desc;
+typedef struct mrl_qnet mrl_qnet;
+int  mrl_qnet_create(const mrl_qnet_desc* desc, mrl_qnet** out);
+void mrl_qnet_destroy(mrl_qnet* q);
+long mrl_qnet_num_params(const mrl_qnet* q);
+int  mrl_qnet_num_tensors(const mrl_qnet* q);
+int  mrl_qnet_tensor_info(const mrl_qnet* q, int i, char* name, int name_cap, int* ndim, int shape[4], long* offset,
+                          int* init_kind, double* init_scale);
+size_t mrl_qnet_workspace_bytes(const mrl_qnet* q, int batch);
+/* q_values (build_graph.py:441): q_out f32 [n][nact] */
+int mrl_qnet_values(const mrl_qnet* q, const float* params, const void* obs, int n, float* q_out, void* workspace,
+                    size_t workspace_bytes, int batch, void* stream);
+/* act (build_graph.py:146-199): argmax_a q(obs) (first maximum), replaced by rand_actions[b] where uniforms[b] < eps
+ * (uniforms == NULL: deterministic); n <= batch; q_out may be NULL */
+int mrl_qnet_act(const mrl_qnet* q, const float* params, const void* obs, int n, float eps, const float* uniforms,
+                 const int32_t* rand_actions, int32_t* actions_out, float* q_out, void* workspace,
+                 size_t workspace_bytes, int batch, void* stream);
+/* train, gradient part (build_graph.py:380-413): td_out f32 [B] = q_t(s,a) - (r + gamma (1-done) q_tp1_best),
+ * loss_out f32 [1] = mean(w * huber(td)), grads_out f32 [P] = d loss / d online params (un-clipped) */
+int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const float* target_params, const void* obs_t,
+                     const int32_t* act, const float* rew, const void* obs_tp1, const float* done, const float* weights,
+                     float gamma, int double_q, int B, float* grads_out, float* td_out, float* loss_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* train, optimizer part (build_graph.py:416-421, deepq.py:205): every variable's gradient clipped by ITS OWN norm
+ * (tf.clip_by_norm; grad_norm_clipping <= 0: none), then TF-1 ApplyAdam with alpha = lr*sqrt(1-b2^t)/(1-b1^t) */
+int mrl_qnet_adam_step(const mrl_qnet* q, float* params, float* grads, float* adam_m, float* adam_v, float alpha,
+                       float beta1, float beta2, float eps, float grad_norm_clipping, void* workspace,
+                       size_t workspace_bytes, int batch, void* stream);
 
 /* ---- synthetic device-resident VecEnv (bench/test data source) ----------------------------
  * Stands where gym environments stand in the reference (common/vec_env/): lock-step stepping with

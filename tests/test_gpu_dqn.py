@@ -1,0 +1,198 @@
+"""GPU: the DQN learner -- Q-networks built by `build_q_func` (deepq/models.py:5-45: mlp / cnn /
+conv_only features, [dueling] heads), the TD graph and per-variable clipped Adam step (deepq/build_graph.py:380-444),
+eps-greedy acting (:146-199) and the `deepq.learn` loop (deepq/deepq.py:95-333) -- against the torch-CPU restatement in
+oracle/dqn_torch.py (fp32 and fp64) and, functionally, the reference's identity-env bar (common/tests/test_identity.py).
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.dqn_torch import OracleQNet
+
+pytestmark = pytest.mark.gpu
+
+from baselines_amd.common.spaces import Box, Discrete          # noqa: E402
+
+CASES = {
+    'mlp_plain': dict(network='mlp', ob=Box(-1.0, 1.0, (8,), np.float32), nact=3, hiddens=(64,), dueling=False),
+    'mlp_dueling': dict(network='mlp', ob=Box(-1.0, 1.0, (12,), np.float32), nact=5, hiddens=(32, 16), dueling=True),
+    'conv_only_dueling': dict(network='conv_only', ob=Box(0, 255, (84, 84, 4), np.uint8), nact=6, hiddens=(256,), dueling=True),
+    'conv_only_small': dict(network='conv_only', ob=Box(0, 255, (21, 17, 4), np.uint8), nact=4, hiddens=(32,), dueling=True,
+                            convs=((8, 5, 3), (12, 3, 2))),
+    'nature_cnn': dict(network='cnn', ob=Box(0, 255, (84, 84, 4), np.uint8), nact=4, hiddens=(64,), dueling=True),
+}
+
+
+def _pair(name, B, seed, double_q=True):
+    from baselines_amd.deepq import QModel, build_q_func
+    c = dict(CASES[name])
+    ob, nact = c.pop('ob'), c.pop('nact')
+    net_kw = {k: c.pop(k) for k in list(c) if k in ('convs',)}
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    qf = build_q_func(c['network'], hiddens=c['hiddens'], dueling=c['dueling'], **net_kw)
+    qm = QModel(qf, ob, nact, lr=1e-3, gamma=0.99, grad_norm_clipping=10, double_q=double_q, max_batch=B)
+    rng = np.random.RandomState(seed + 1)
+    # biases are zero at init: perturb everything so every gradient path is exercised
+    flat = qm.get_flat_params() + (0.02 * rng.randn(qm.P)).astype(np.float32)
+    qm.params.copy_(torch.from_numpy(flat))
+    tflat = flat + (0.05 * rng.randn(qm.P)).astype(np.float32)             # target != online
+    qm.target.copy_(torch.from_numpy(tflat))
+    kw = dict(network=c['network'], tensors=qm.tensors, nact=nact, hiddens=c['hiddens'], dueling=c['dueling'],
+              convs=qf.network.kw.get('convs', ()), lr=1e-3, gamma=0.99, clip=10.0, double_q=double_q)
+    oms = []
+    for dt in (torch.float32, torch.float64):
+        om = OracleQNet(flat_params=flat, dtype=dt, **kw)
+        om.target = {t['name']: torch.tensor(tflat[t['offset']:t['offset'] + t['size']].reshape(t['shape']), dtype=dt)
+                     for t in qm.tensors}
+        oms.append(om)
+    if ob.dtype == np.uint8:
+        mk = lambda: rng.randint(0, 256, (B,) + ob.shape).astype(np.uint8)
+    else:
+        mk = lambda: rng.randn(B, *ob.shape).astype(np.float32)
+    batch = dict(obs_t=mk(), act=rng.randint(0, nact, B), rew=rng.randn(B).astype(np.float32), obs_tp1=mk(),
+                 done=(rng.rand(B) < 0.2).astype(np.float32), w=(0.5 + rng.rand(B)).astype(np.float32))
+    return qm, oms[0], oms[1], batch
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_q_values_td_gradient_and_clipped_adam_vs_oracle(name):
+    from baselines_amd import _lib
+    B = 32
+    qm, om, om64, b = _pair(name, B, 0)
+    names = [t['name'] for t in qm.tensors]
+    assert names[-1].startswith('deepq/q_func/state_value/' if CASES[name]['dueling'] else 'deepq/q_func/action_value/')
+    # ---- q_values (online and target)
+    np.testing.assert_allclose(qm.q_values(b['obs_t']), om64.q_values(b['obs_t']), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(qm.q_values(b['obs_tp1'], target=True), om64.q_values(b['obs_tp1'], target=True), rtol=1e-4, atol=2e-5)
+    # ---- TD error, loss and un-clipped gradient
+    o1, o2 = qm._obs(b['obs_t']), qm._obs(b['obs_tp1'])
+    dev = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x)).cuda().to(dt)
+    a, r, d, w = dev(b['act'], torch.int32), dev(b['rew'], torch.float32), dev(b['done'], torch.float32), dev(b['w'], torch.float32)
+    td = torch.empty(B, dtype=torch.float32, device='cuda')
+    _lib.check(qm.lib.mrl_qnet_td_grad(qm.handle, _lib.ptr(qm.params), _lib.ptr(qm.target), _lib.ptr(o1), _lib.ptr(a), _lib.ptr(r),
+                                       _lib.ptr(o2), _lib.ptr(d), _lib.ptr(w), 0.99, 1, B, _lib.ptr(qm.grads), _lib.ptr(td),
+                                       _lib.ptr(qm._loss), _lib.ptr(qm.workspace), qm.workspace.numel(), _lib.stream_ptr()),
+               'mrl_qnet_td_grad')
+    td_o, loss_o, g_o = om.td_and_grads(b['obs_t'], b['act'], b['rew'], b['obs_tp1'], b['done'], b['w'])
+    td_64, loss_64, g_64 = om64.td_and_grads(b['obs_t'], b['act'], b['rew'], b['obs_tp1'], b['done'], b['w'])
+    np.testing.assert_allclose(td.cpu().numpy(), td_64, rtol=1e-4, atol=3e-5)
+    assert abs(float(qm._loss.cpu()) - loss_64) <= 1e-5 * max(1.0, abs(loss_64))
+    g_d = qm.grads.cpu().numpy().astype(np.float64)
+    scale = max(float(g_64[k].abs().max()) for k in names)
+    for t in qm.tensors:
+        ref = g_64[t['name']].numpy().reshape(-1)
+        got = g_d[t['offset']:t['offset'] + t['size']]
+        tol = 5e-5 * max(np.abs(ref).max(), 1e-3 * scale)
+        assert np.abs(got - ref).max() <= tol, (t['name'], np.abs(got - ref).max(),
+                                                np.abs(g_o[t['name']].numpy().reshape(-1) - ref).max(), tol)
+    # ---- three train steps (per-variable clip_by_norm(10) + Adam, epsilon 1e-8) and a target update
+    for it in range(3):
+        td_d = qm.train(b['obs_t'], b['act'], b['rew'] * (20.0 if it == 1 else 1.0), b['obs_tp1'], b['done'], b['w'])
+        td_r, _ = om.train(b['obs_t'], b['act'], b['rew'] * (20.0 if it == 1 else 1.0), b['obs_tp1'], b['done'], b['w'])
+        np.testing.assert_allclose(td_d, td_r, rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(qm.get_flat_params(), om.flat_params(), rtol=0, atol=2e-5)
+    before = qm.target.clone()
+    qm.update_target()
+    assert not torch.equal(before, qm.target) and torch.equal(qm.target, qm.params)
+
+
+def test_act_is_eps_greedy():
+    qm, om, _, b = _pair('mlp_dueling', 256, 3)
+    obs = np.random.RandomState(0).randn(256, 12).astype(np.float32)
+    greedy = om.q_values(obs).argmax(axis=1)
+    a = qm.act(obs, stochastic=False)
+    assert a.dtype == np.int64 and np.array_equal(a, greedy)
+    a0 = qm.act(obs, update_eps=1.0)                 # eps variable still 0 when this call samples (assign is an update op)
+    assert np.array_equal(a0, greedy)
+    a1 = qm.act(obs)                                 # eps == 1: every action uniformly random
+    assert (a1 != greedy).mean() > 0.6 and set(np.unique(a1)) == set(range(5))
+    qm.act(obs, update_eps=0.0)
+    assert np.array_equal(qm.act(obs), greedy)
+    from baselines_amd.deepq import ActWrapper
+    acts, _, _, _ = ActWrapper(qm, {}).step(obs[0])
+    assert acts.shape == (1,)
+
+
+class DiscreteIdentityEnv(object):
+    """common/tests/envs/identity_env.py: observation = uniform integer, reward = [action == observation]"""
+
+    def __init__(self, dim, episode_len, seed):
+        self.observation_space = self.action_space = Discrete(dim)
+        self.dim, self.episode_len = dim, episode_len
+        self._rng = np.random.RandomState(seed)
+
+    def reset(self):
+        self._t = 0
+        self._state = int(self._rng.randint(self.dim))
+        return self._state
+
+    def step(self, action):
+        rew = 1.0 if int(action) == self._state else 0.0
+        self._t += 1
+        self._state = int(self._rng.randint(self.dim))
+        return self._state, rew, self._t >= self.episode_len, {}
+
+
+@pytest.mark.parametrize('prioritized', [False, True])
+def test_deepq_learn_identity_env(prioritized, tmp_path):
+    """the reference's functional bar for deepq (common/tests/test_identity.py: gamma 0.9, network mlp, >= 90 % of the
+    reward over 100 evaluation steps), here on a 5-way identity env with a shorter schedule; then save / load round trips"""
+    from baselines_amd import deepq
+    env = DiscreteIdentityEnv(5, 50, seed=0)
+    seen = {'train': 0, 'target': 0}
+
+    def cb(lcl, _glb):
+        t = lcl['t']
+        if t > 200 and t % 1 == 0:
+            seen['train'] += 1
+        return False
+
+    act = deepq.learn(env, network='mlp', seed=0, gamma=0.9, total_timesteps=4000, lr=2e-3, buffer_size=2000,
+                      exploration_fraction=0.3, exploration_final_eps=0.02, learning_starts=200, target_network_update_freq=100,
+                      prioritized_replay=prioritized, print_freq=None, checkpoint_freq=None, callback=cb, hiddens=[32],
+                      num_hidden=32)
+    assert seen['train'] > 3000
+    test_env = DiscreteIdentityEnv(5, 1000, seed=1)
+    obs, total = test_env.reset(), 0.0
+    for _ in range(100):
+        a = act(np.array(obs)[None], stochastic=False)[0]
+        obs, rew, _, _ = test_env.step(a)
+        total += rew
+    assert total >= 90, total
+    # checkpoints: reference variable names, round trip through save / load_act
+    p = str(tmp_path / 'model.pkl')
+    act.save_act(p)
+    act2 = deepq.load_act(p)
+    probe = np.arange(5)
+    assert np.array_equal(act(probe, stochastic=False), act2(probe, stochastic=False))
+    names = set(act._model.variables())
+    assert {'deepq/eps:0', 'deepq/q_func/mlp_fc0/w:0', 'deepq/target_q_func/mlp_fc0/w:0',
+            'deepq/q_func/action_value/fully_connected/weights:0', 'deepq/q_func/state_value/fully_connected_1/biases:0',
+            'deepq/q_func/mlp_fc0/w/Adam:0'} <= names
+
+
+def test_deepq_train_step_sequence_matches_oracle_with_prioritized_replay():
+    """A short seeded learner trace: prioritized replay (device trees, reference index stream from Python's `random`),
+    double-Q TD step, priority update, periodic target copies -- replayed by the oracle on the SAME sampled batches:
+    TD errors 1e-3, parameters 2e-5 after 30 steps."""
+    from baselines_amd.deepq import PrioritizedReplayBuffer
+    qm, om, _, _ = _pair('conv_only_small', 16, 5)
+    rng = np.random.RandomState(9)
+    random.seed(9)
+    buf = PrioritizedReplayBuffer(64, alpha=0.6)
+    for _ in range(64):
+        buf.add(rng.randint(0, 256, (21, 17, 4)).astype(np.uint8), int(rng.randint(4)), float(rng.randn()),
+                rng.randint(0, 256, (21, 17, 4)).astype(np.uint8), float(rng.rand() < 0.1))
+    for step in range(30):
+        o1, a, r, o2, d, w, idx = buf.sample(16, beta=0.4 + 0.02 * step)
+        td_d = qm.train(o1, a, r, o2, d, w)
+        td_o, _ = om.train(o1, a, r, o2, d, w)
+        np.testing.assert_allclose(td_d, td_o, rtol=1e-3, atol=1e-3)
+        buf.update_priorities(idx, np.abs(td_o) + 1e-6)           # same priorities on both sides keep the index streams equal
+        if step % 10 == 9:
+            qm.update_target()
+            om.update_target()
+    np.testing.assert_allclose(qm.get_flat_params(), om.flat_params(), rtol=0, atol=2e-5)
