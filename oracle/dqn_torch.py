@@ -114,6 +114,11 @@ class OracleQNet(object):
 
     def train(self, obs_t, act, rew, obs_tp1, done, w):
         td, loss, grads = self.td_and_grads(obs_t, act, rew, obs_tp1, done, w)
+        self.apply_grads(grads)
+        return td, loss
+
+    def apply_grads(self, grads):
+        """build_graph.py:416-421 per-variable clip_by_norm, then the optimizer's apply op"""
         one = self.npdt(1)
         alpha = self.npdt(self.lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
         with torch.no_grad():
@@ -126,7 +131,6 @@ class OracleQNet(object):
                 self.p[k] -= (self.m[k] * float(alpha)) / (torch.sqrt(self.v[k]) + float(self.eps))
         self.beta1_power = self.npdt(self.beta1_power * self.beta1)
         self.beta2_power = self.npdt(self.beta2_power * self.beta2)
-        return td, loss
 
     def update_target(self):
         self.target = {k: v.detach().clone() for k, v in self.p.items()}
