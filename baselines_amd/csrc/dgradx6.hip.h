@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
 
 template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8>
 __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
-                                                       const float* __restrict__ hmask, float* __restrict__ dx, int act,
-                                                       int B, int btiles, long tiles_per_xcd, long total_tiles, int dbg) {
+                                                       const float* __restrict__ hmask, const uint32_t* __restrict__ mbits,
+                                                       float* __restrict__ dx, int act, int B, int btiles,
+                                                       long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -76,19 +77,22 @@ __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__
     constexpr int OH = G::OH, OW = G::OW, TAPS = G::TAPS;
     extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
     // logical tile order: (image group, position, column tile) with the column tile fastest; XCD x owns a contiguous run
+    // of tiles and its persistent workgroups (slots_per_xcd of them: two per CU) walk that run with stride slots_per_xcd,
+    // so at any moment the workgroups of an XCD work on ~64 consecutive positions of one image group: the TAPS^2-fold
+    // re-reads of dz pixels by neighbouring positions hit that XCD's L2
     const int xcd = blockIdx.x & 7;
-    const long slot = blockIdx.x >> 3;
-    if (slot >= tiles_per_xcd) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    if (dbg & 1) { hmask = nullptr; mbits = nullptr; }     // timing experiments (MRL_DGX6_DBG): 1 = no mask loads,
+    for (long slot = blockIdx.x >> 3; slot < tiles_per_xcd; slot += slots_per_xcd) {      // 2 = no stores, 4 = no main loop
     const long lt = (long)xcd * tiles_per_xcd + slot;
-    if (lt >= total_tiles) return;
+    if (lt >= total_tiles) break;
     const int nt_i = (int)(lt % NTN);
     const long rest = lt / NTN;
     const int pos = (int)(rest % G::NPOS);
     const int bt = (int)(rest / G::NPOS);
     const int yy = pos / G::WX, xx = pos - yy * G::WX;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
     const int b0 = bt * BM, n0 = nt_i * BN;
 
     f32x16 acc[2][2];
@@ -188,8 +192,6 @@ __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__
                 }
         }
     };
-    // dbg (timing experiments, MRL_DGX6_DBG): 1 = no mask loads, 2 = no stores (epilogue off), 4 = main loop off
-    if (dbg & 1) hmask = nullptr;
     uint16_t* L0 = x6s;
     int t = (dbg & 4) ? G::NKT : next_valid(0);
     if (t < G::NKT) fetch(ra0, rb0, t);
@@ -223,13 +225,24 @@ __global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__
                 const int bimg = b0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 o[r] = (colok && bimg < B) ? (long)bimg * (H * W * C) + pix : -1;
             }
+            if (mbits) {
+                // ReLU bit mask of the layer below (written by its forward epilogue): the 32 lanes of a half-wave hold 32
+                // consecutive channels of ONE pixel = one mask word, read as a broadcast; lane i tests bit i
+                uint32_t wv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = hmask ? hmask[o[r] < 0 ? 0 : o[r]] : 1.f;       // all loads first
+                for (int r = 0; r < 16; ++r) wv[r] = mbits[(o[r] < 0 ? 0 : o[r] - i) >> 5];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = ((wv[r] >> i) & 1u) ? 1.f : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = hmask ? act_bwd_from_out(hmask[o[r] < 0 ? 0 : o[r]], act) : 1.f;   // all loads first
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (o[r] >= 0 && (!(dbg & 2) || acc[a][b][r] == 12345.678f))
-                    dx[o[r]] = hmask ? acc[a][b][r] * act_bwd_from_out(x[r], act) : acc[a][b][r];
+                if (o[r] >= 0 && (!(dbg & 2) || acc[a][b][r] == 12345.678f)) dx[o[r]] = acc[a][b][r] * x[r];
         }
+    __syncthreads();          // the next tile's first LDS write must not overtake this tile's last fragment reads
+    }
 }
 
 template <int H, int W, int C, int RF, int S, int NF>
@@ -239,8 +252,8 @@ inline size_t dgrad_x6_plane_bytes() {
 }
 
 template <int H, int W, int C, int RF, int S, int NF, int WM, int WN>
-inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* hmask, float* dx, int act, int B,
-                                  uint16_t* planes, bool x8, hipStream_t stream, int dbg = 0) {
+inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* hmask, const uint32_t* mbits, float* dx,
+                                  int act, int B, uint16_t* planes, bool x8, int num_cus, hipStream_t stream, int dbg = 0) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     if (B <= 0) return hipSuccess;
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -261,8 +274,9 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
             if (er != hipSuccess) return er;
             raised = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, dx,
-                           act, B, btiles, per_xcd, total, dbg);
+        const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);      // two workgroups per CU
+        hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, mbits,
+                           dx, act, B, btiles, per_xcd, total, slots, dbg);
         return hipGetLastError();
     };
     if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);

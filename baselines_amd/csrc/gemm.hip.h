@@ -372,6 +372,8 @@ struct DgradB : DgradGeom {   // GEMM row = input channel c, KC over n;  W is HW
 struct EpiBiasAct {       // out[m*ld + n] = act(acc + bias[n])
     static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* bias; int act;
+    uint32_t* mask = nullptr;     // optional ReLU bit mask of the output (gemm_x6_kernel; see WresEpiBiasAct)
+    __device__ __forceinline__ bool mask_bit(float acc, float b) const { return act_fwd(acc + b, act) > 0.f; }
     __device__ __forceinline__ long addr(int m, int n, int) const { return (long)m * ld + n; }
     __device__ __forceinline__ float aux(long, int n) const { return bias[n]; }
     __device__ __forceinline__ void put(long o, float acc, float b) const { out[o] = act_fwd(acc + b, act); }
@@ -379,6 +381,8 @@ struct EpiBiasAct {       // out[m*ld + n] = act(acc + bias[n])
 struct EpiMaskAct {       // out[m*ld + n] = acc * act'(h[m*ld + n])      (fc data-gradient)
     static constexpr bool HAS_BIAS = false;
     float* out; long ld; const float* h; int act;
+    static constexpr uint32_t* mask = nullptr;
+    __device__ __forceinline__ bool mask_bit(float, float) const { return false; }
     __device__ __forceinline__ long addr(int m, int n, int) const { return (long)m * ld + n; }
     // h == nullptr: no activation below (store the plain product)
     __device__ __forceinline__ float aux(long o, int) const { return h ? h[o] : 1.f; }

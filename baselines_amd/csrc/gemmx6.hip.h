@@ -224,6 +224,13 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (o[r] >= 0) ef.put(o[r], acc[a][b][r], x[r]);
+            if (ef.mask) {         // ReLU bit mask: lanes 0-31 = 32 consecutive columns of one row, lanes 32-63 of another
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long bal = __ballot(o[r] >= 0 && ef.mask_bit(acc[a][b][r], x[r]));
+                    if (i == 0 && o[r] >= 0) ef.mask[o[r] >> 5] = (uint32_t)(h ? (bal >> 32) : bal);
+                }
+            }
         }
 }
 

@@ -225,6 +225,11 @@ struct NetWs {
     // recurrent cell (lstm.hip.h): x@wx, stored gates / masked state / tanh(c), cell output = policy latent, gradients
     float *zx = nullptr, *gates = nullptr, *cm = nullptr, *hm = nullptr, *tc = nullptr, *hout = nullptr, *dhout = nullptr,
           *dzg = nullptr;
+    // ReLU bit masks of the conv outputs (1 bit per element, written by the forward epilogues that can, consumed by the
+    // position-major data-gradient engine instead of the fp32 activations): mbits[l] may be nullptr; mvalid[l] is set
+    // by the forward pass of THIS call when the engine that ran layer l wrote them
+    std::vector<uint32_t*> mbits;
+    std::vector<char> mvalid;
     float* lat() const { return hout ? hout : h.back(); }
     float* dlat() const { return dhout ? dhout : dz.back(); }
 };
@@ -279,8 +284,8 @@ static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -342,10 +347,13 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     size_t part_floats = (size_t)HEAD_MAXBLK * m->HP;
     auto do_net = [&](const Net& net, NetWs& nw) {
-        nw.h.clear(); nw.dz.clear();
+        nw.h.clear(); nw.dz.clear(); nw.mbits.clear(); nw.mvalid.clear();
         for (const Layer& l : net.L) {
             nw.h.push_back((float*)take((size_t)chunk * l.out_elems * 4));
             nw.dz.push_back((float*)take((size_t)chunk * l.out_elems * 4));
+            const bool bits = l.kind == 0 && l.act == ACT_RELU && l.NF % 32 == 0;
+            nw.mbits.push_back(bits ? (uint32_t*)take((size_t)chunk * l.out_elems / 8) : nullptr);
+            nw.mvalid.push_back(0);
             part_floats = std::max(part_floats, (size_t)max_split_floats(l.K, l.N, layer_rows(l, chunk)));
             if (l.kind == 0) part_floats = std::max(part_floats, (size_t)IMGRES_MAX_BLOCKS * ((size_t)l.K * l.N + l.N));
         }
@@ -1121,7 +1129,10 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
 
 static bool tuned(const Layer& l, const char* pass);
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
-                         const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st) {
+                         const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st,
+                         uint32_t* mbits = nullptr, char* mwrote = nullptr) {
+    if (mwrote) *mwrote = 0;
+    if (!get_option("relu_bits", "MRL_RELU_BITS", 1)) mbits = nullptr;
     const float* W = params + l.w_off;
     const float* bias = params + l.b_off;
     RowMC bf{W, l.N, l.N, l.K, is_vec(W, l.N), nullptr};
@@ -1143,6 +1154,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                     ProfScope ps(label, fl, 0.0, st);
+                    if (mbits && l.NF == 32 && l.act == ACT_RELU) { we.mask = mbits; if (mwrote) *mwrote = 1; }
                     return (int)launch_wres_u8x3<WresEpiBiasAct, WRES_PF, 16>(wa, W, we, l.K, l.NF, tiles, num_cus(), st);
                 }
                 return wres_dispatch(l.name, "fwd", var, l.NF, wa, wb, we, 1, l.K, tiles, fl, st);
@@ -1161,6 +1173,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st);
                     if (e != hipSuccess) return (int)e;
                     EpiBiasAct efx{hout, l.NF, bias, l.act};
+                    if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efx.mask = mbits; if (mwrote) *mwrote = 1; }
                     return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st, nullptr, x6 == 2);
                 }
                 WresFwdA<false> wa;
@@ -1208,7 +1221,9 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
 static int net_forward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, int B,
                        hipStream_t st) {
     for (size_t i = 0; i < net.L.size(); ++i) {
-        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st);
+        const bool hb = i < nw.mbits.size();
+        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
+                               hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr);
         if (rc) return rc;
     }
     return 0;
@@ -1317,8 +1332,10 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     ProfScope ps(label, fl, 0.0, st);
                     const bool x8 = f32_split_mode() == 2;
                     const int dbg = get_option("dgx6_dbg", "MRL_DGX6_DBG", 0);
-                    hipError_t e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st, dbg)
-                                           : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, nw.dz[i - 1], lp.act, B, nw.planes, x8, st, dbg);
+                    // act' of the layer below: its ReLU bit mask when this call's forward pass wrote one, else its fp32 output
+                    const uint32_t* bits = ((size_t)i - 1 < nw.mvalid.size() && nw.mvalid[i - 1] && lp.act == ACT_RELU) ? nw.mbits[i - 1] : nullptr;
+                    hipError_t e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg)
+                                           : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg);
                     rc = (int)e;
                 } else
                 if (lk && (dv == V_LDSDGRAD || !overridden)) {

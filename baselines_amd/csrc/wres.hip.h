@@ -162,6 +162,9 @@ struct WresDgradB : DgradGeom {   // class z = (py, px); k = (tap, n'); column =
 // ------------------------------------------------------------------------------------------
 struct WresEpiBiasAct {      // out[m*ld + n] = act(acc + bias[n]),  m = tile*32 + row
     float* out; long ld; const float* bias; int act; long rows; int ncols;
+    // optional ReLU bit mask of the output (bit e of word e/32 <=> out[e] > 0): one word per 32 consecutive columns,
+    // written with one ballot per row pair -- 1 bit instead of 32 for the data-gradient kernel that applies act'
+    uint32_t* mask = nullptr;
     __device__ __forceinline__ long addr(long tile, int, int row, int col) const {
         long m = tile * 32 + row;
         return (m < rows && col < ncols) ? m * ld + col : -1;
@@ -405,6 +408,13 @@ __global__ __launch_bounds__(WAVES * 64) void wres_u8x3_kernel(WresFwdA<true> al
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (o[r] >= 0) ef.put(o[r], acc[r], x[r]);
+        if (ef.mask) {             // lanes 0-31 hold the 32 columns of one output row, lanes 32-63 those of another
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long bal = __ballot(o[r] >= 0 && act_fwd(acc[r] + x[r], ef.act) > 0.f);
+                if (i == 0 && o[r] >= 0) ef.mask[o[r] >> 5] = (uint32_t)(h ? (bal >> 32) : bal);
+            }
+        }
         if (next >= total_tiles) break;
         rs = rn;
         tile = next;

@@ -358,6 +358,8 @@ int mrl_tune_set(const char* label, int variant);
  *                  product, below one fp32 rounding: the default), 1 = six products (< 2^-21), 0 = fp32 MFMA
  *   "dgrad_x6"   [MRL_DGRAD_X6, 1]  conv data gradients on the tiled split engine (position-major tiles);
  *                  0 = LDS-resident fp32-MFMA engine
+ *   "relu_bits"  [MRL_RELU_BITS, 1]  conv forward epilogues also write a 1-bit-per-element ReLU mask that the tiled data
+ *                  gradient reads instead of the fp32 activations; 0 = fp32 activations
  *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
  *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg": experiment knobs

@@ -73,4 +73,27 @@ for B in (32, 4096):
         out[k] = {'us': round(us, 2), 'GB/s': round(v['bytes'] / v['count'] / (us * 1e-6) / 1e9, 1) if v['bytes'] else None,
                   'calls': v['count']}
     res['batch_%d' % B] = out
+# ---- the whole DQN learner step of the reference (deepq.py:291-303) around the replay slice: prioritized sample ->
+# Q-network TD step (conv_only + dueling, double-Q, per-variable clip, Adam; csrc/qnet.hip.h) -> priority update, batch 32
+from baselines_amd.common.spaces import Box  # noqa: E402
+from baselines_amd.deepq import QModel, build_q_func  # noqa: E402
+
+np.random.seed(0)
+qm = QModel(build_q_func('conv_only'), Box(0, 255, SHAPE, np.uint8), NA, lr=1e-4, gamma=0.99, max_batch=32)
+
+
+def dqn_step(B=32, beta=0.4):
+    o1, a, r, o2, d, w, idx = buf.sample_dev(B, beta)
+    qm.train(o1, a, r, o2, d, w.float())
+    buf.update_priorities_from_td(idx, qm.last_td)
+
+
+for _ in range(5):
+    dqn_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100):
+    dqn_step()
+torch.cuda.synchronize()
+res['dqn_learner_step_batch32_us'] = round((time.perf_counter() - t0) / 100 * 1e6, 1)
 print(json.dumps(res))

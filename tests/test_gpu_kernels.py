@@ -295,7 +295,7 @@ def test_engine_options_agree():
         dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
         return g.cpu().numpy(), st.cpu().numpy()
 
-    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6')}
+    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits')}
     assert defaults['f32_bf16x6'] == 2, 'the default arithmetic of the split engines is the 8-product mode'
     try:
         cnn = ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False)
@@ -310,12 +310,14 @@ def test_engine_options_agree():
         # ---- B = 1152 (tiled split engines everywhere they apply), screened minibatch: every entry
         B = 1152
         scr = _problem(B, 21)
-        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0)                 # all fp32 x fp32 sites on the fp32 MFMA pipe
+        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0)    # all fp32 x fp32 sites on the fp32 MFMA pipe
         g0, s0 = grads(*cnn, B, ref_opts, scr)
         scale = np.abs(g0).max()
         for name, opts, tol in [('8 products (default)', dict(defaults), 3e-6),
                                 ('6 products', dict(defaults, f32_bf16x6=1), 6e-6),
-                                ('8 products, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6)]:
+                                ('8 products, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
+                                ('8 products, act\' from the fp32 activations instead of the ReLU bit masks',
+                                 dict(defaults, relu_bits=0), 3e-6)]:
             g1, s1 = grads(*cnn, B, opts, scr)
             d = np.abs(g1 - g0)
             assert d.max() <= tol * scale + 1e-9, (name, d.max(), scale, int(d.argmax()))
