@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
 }
 
 template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8>
-__global__ __launch_bounds__(256) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
+__global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
                                                        const float* __restrict__ hmask, const uint32_t* __restrict__ mbits,
                                                        float* __restrict__ dx, int act, int B, int btiles,
                                                        long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg) {

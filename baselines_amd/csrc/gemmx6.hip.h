@@ -206,8 +206,13 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         stamp(t, 5);
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ReLU bit mask (ef.mask): one 32-bit word per (row, 32-column block) = one half of a wave ballot; the 64 words of a
+    // wave's 32 rows x 2 column blocks are collected into lane (row_in_block*2 + b) and stored with ONE instruction
+    const int mk_row = lane >> 1, mk_b = lane & 1;
+    const int mk_r = (mk_row & 3) + 4 * (mk_row >> 3), mk_h = (mk_row >> 2) & 1;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+        uint32_t mword = 0;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int col = n0 + (wn * 2 + b) * 32 + i;
@@ -224,14 +229,19 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (o[r] >= 0) ef.put(o[r], acc[a][b][r], x[r]);
-            if (ef.mask) {         // ReLU bit mask: lanes 0-31 = 32 consecutive columns of one row, lanes 32-63 of another
+            if (ef.mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned long long bal = __ballot(o[r] >= 0 && ef.mask_bit(acc[a][b][r], x[r]));
-                    if (i == 0 && o[r] >= 0) ef.mask[o[r] >> 5] = (uint32_t)(h ? (bal >> 32) : bal);
+                    if (mk_b == b && mk_r == r) mword = (uint32_t)(mk_h ? (bal >> 32) : bal);
                 }
             }
         }
+        if (ef.mask) {
+            const int row = m0 + (wm * 2 + a) * 32 + mk_row, col = n0 + (wn * 2 + mk_b) * 32;
+            if (row < M && col < N) ef.mask[ef.addr(row, col, 0) >> 5] = mword;
+        }
+    }
 }
 
 inline bool gemm_x6_ok(const void* A, long lda, int K) {

@@ -1221,7 +1221,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
 static int net_forward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, int B,
                        hipStream_t st) {
     for (size_t i = 0; i < net.L.size(); ++i) {
-        const bool hb = i < nw.mbits.size();
+        // bit masks only where a consumer exists: the layer above is a conv whose data gradient the tiled engine computes
+        const bool hb = i < nw.mbits.size() && i + 1 < net.L.size() && net.L[i + 1].kind == 0;
         int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
                                hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr);
         if (rc) return rc;

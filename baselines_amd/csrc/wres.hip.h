@@ -408,12 +408,19 @@ __global__ __launch_bounds__(WAVES * 64) void wres_u8x3_kernel(WresFwdA<true> al
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (o[r] >= 0) ef.put(o[r], acc[r], x[r]);
-        if (ef.mask) {             // lanes 0-31 hold the 32 columns of one output row, lanes 32-63 those of another
+        if (ef.mask) {             // lanes 0-31 hold the 32 columns of one output row, lanes 32-63 those of another:
+            // a wave ballot per accumulator register = the mask words of two rows; lane L < 32 collects row L's word and the
+            // 32 words of the tile leave with one coalesced store (ncols == 32: one word per output row)
+            const int lane = (h << 5) | i;
+            const int mr = (lane & 3) + 4 * (lane >> 3), mh = (lane >> 2) & 1;
+            uint32_t mword = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned long long bal = __ballot(o[r] >= 0 && act_fwd(acc[r] + x[r], ef.act) > 0.f);
-                if (i == 0 && o[r] >= 0) ef.mask[o[r] >> 5] = (uint32_t)(h ? (bal >> 32) : bal);
+                if (lane < 32 && mr == r) mword = (uint32_t)(mh ? (bal >> 32) : bal);
             }
+            const long m = tile * 32 + lane;
+            if (lane < 32 && m < ef.rows) ef.mask[m] = mword;
         }
         if (next >= total_tiles) break;
         rs = rn;

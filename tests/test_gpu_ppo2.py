@@ -310,3 +310,30 @@ def test_normalize_observations_is_the_references_clip():
     np.testing.assert_array_equal(v1, v2)
     np.testing.assert_array_equal(m.value(x), m.value(np.clip(x, -5, 5)))
     assert np.isfinite(m.get_flat_params()).all()
+
+
+def test_integration_model_fn_adapter():
+    """INTEGRATION.md level 1: the adapter of examples/model_fn_adapter.py plugged into learn()'s `model_fn`; the model it
+    returns is driven through the REFERENCE protocol only (host arrays: step / value / train), like the reference's own
+    Runner and gather loop would (here: learn() with a model that hides its fast entry points)."""
+    from baselines_amd import ppo2
+    from examples.model_fn_adapter import make_model_fn
+    inner = make_model_fn('mlp', value_network='copy')
+
+    class ProtocolOnly(object):      # exposes exactly model.py:115-126,133
+        def __init__(self, m):
+            self._m = m
+            self.initial_state, self.loss_names = m.initial_state, m.loss_names
+            self.step, self.value, self.train, self.save, self.load = m.step, m.value, m.train, m.save, m.load
+
+    made = []
+
+    def model_fn(**kw):
+        made.append(inner(**kw))
+        return ProtocolOnly(made[-1])
+
+    env = _mk('mujoco', 4, 3, False)
+    seen = []
+    model = ppo2.learn(network='mlp', env=env, total_timesteps=2 * 4 * 16, seed=0, nsteps=16, nminibatches=2, noptepochs=2,
+                       value_network='copy', model_fn=model_fn, update_fn=seen.append, log_interval=100)
+    assert seen == [1, 2] and isinstance(model, ProtocolOnly) and made[0]._train_calls == 2 * 2 * 2
