@@ -67,7 +67,7 @@ template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8>
 __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
                                                        const float* __restrict__ hmask, const uint32_t* __restrict__ mbits,
                                                        float* __restrict__ dx, int act, int B, int btiles,
-                                                       long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg) {
+                                                       long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg, int prio) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
         const int tn = next_valid(t + 1);
         fetch(ra0, rb0, tn < G::NKT ? tn : t);  // next valid tile in flight during the MFMA block (past the end: re-read, never consumed)
         __builtin_amdgcn_sched_barrier(0);
+        if (prio) __builtin_amdgcn_s_setprio(1);     // the MFMA stream outranks the co-resident workgroup's staging VALU
         mfma_block(L0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         t = tn;
     }
@@ -276,7 +278,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
         }
         const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);      // two workgroups per CU
         hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, mbits,
-                           dx, act, B, btiles, per_xcd, total, slots, dbg);
+                           dx, act, B, btiles, per_xcd, total, slots, dbg, x6_prio());
         return hipGetLastError();
     };
     if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);

@@ -76,7 +76,7 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 // pipe at every LDS wait.
 template <class AF, class EF, int WM, int WN, bool X8>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
-                                                      int mtiles, int ntiles, long long* dbg) {
+                                                      int mtiles, int ntiles, long long* dbg, int prio) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NA = BM / 32;                            // float4 of A per thread and tile
@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         // them BEFORE the MFMA block (the full memory latency exposed once per tile)
         __builtin_amdgcn_sched_barrier(0);
         stamp(t, 4);
+        if (prio) __builtin_amdgcn_s_setprio(1);     // experiment: the MFMA stream outranks the co-resident workgroup's staging VALU
         mfma_block(L0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         stamp(t, 5);
     }
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     }
 }
 
+inline int& x6_prio() { static int p = 0; return p; }      // experiment knob (mrl_set_option "x6_prio")
 inline bool gemm_x6_ok(const void* A, long lda, int K) {
     return K % X6_BK == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;
 }
@@ -271,7 +274,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio());
     return hipGetLastError();
 }
 template <class AF, class EF>

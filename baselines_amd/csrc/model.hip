@@ -23,6 +23,7 @@
 #include "ldsdgrad.hip.h"
 #include "gemmx6.hip.h"
 #include "dgradx6.hip.h"
+#include "gemmx6s.hip.h"
 #include "mlpstep.hip.h"
 #include "comm.hip.h"
 #include "lstm.hip.h"
@@ -280,12 +281,15 @@ static int get_option(const char* name, const char* env, int dflt) {
 // multiply (dropped part < 2^-21 of a product), 2 = eight products (dropped part < 2^-29: below one fp32 rounding).
 // Default 2: every product of the update is then at least as accurate as an IEEE fp32 multiply.
 static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 2); }
+// wave-specialised (producer / consumer) form of the tiled split engines (gemmx6s.hip.h): measured NOT faster than the plain
+// form (two waves of one SIMD share its VALU issue and its matrix pipe: profiles/README.md), kept as an experiment knob
+static int x6_specialised() { return get_option("x6_spec", "MRL_X6_SPEC", 0); }
 static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -295,7 +299,11 @@ extern "C" int mrl_get_option(const char* name, int* value_out) {
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
-        if (!strcmp(kOptionEnv[i][0], name)) { option_table()[name] = value; return 0; }
+        if (!strcmp(kOptionEnv[i][0], name)) {
+            option_table()[name] = value;
+            if (!strcmp(name, "x6_prio")) x6_prio() = value;
+            return 0;
+        }
     return MRL_EINVAL;
 }
 extern "C" int mrl_tune_set(const char* label, int variant) {
@@ -1174,6 +1182,11 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     if (e != hipSuccess) return (int)e;
                     EpiBiasAct efx{hout, l.NF, bias, l.act};
                     if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efx.mask = mbits; if (mwrote) *mwrote = 1; }
+                    if (x6_specialised()) {
+                        // MRL_X6_DBG = 10 + layer index: phase stamps of that conv layer's forward land behind the zero page
+                        long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
+                        return (int)launch_gemm_x6s(ca, planes, efx, npix, l.NF, l.K, num_cus(), x6 == 2, st, dbgp);
+                    }
                     return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st, nullptr, x6 == 2);
                 }
                 WresFwdA<false> wa;
@@ -1208,7 +1221,9 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st);        // B[n][k] = W[k][n]
                 if (e != hipSuccess) return (int)e;
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
-                long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) ? dbgbuf : nullptr;
+                long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) == 1 ? dbgbuf : nullptr;
+                if (x6_specialised())
+                    return (int)launch_gemm_x6s(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, num_cus(), f32_split_mode() == 2, st, dbgp);
                 return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st, dbgp,
                                            f32_split_mode() == 2);
             }
@@ -1335,8 +1350,13 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     const int dbg = get_option("dgx6_dbg", "MRL_DGX6_DBG", 0);
                     // act' of the layer below: its ReLU bit mask when this call's forward pass wrote one, else its fp32 output
                     const uint32_t* bits = ((size_t)i - 1 < nw.mvalid.size() && nw.mvalid[i - 1] && lp.act == ACT_RELU) ? nw.mbits[i - 1] : nullptr;
-                    hipError_t e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg)
-                                           : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg);
+                    hipError_t e;
+                    if (x6_specialised() && !dbg)
+                        e = lk == 1 ? launch_dgrad_x6s<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st)
+                                    : launch_dgrad_x6s<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st);
+                    else
+                        e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg)
+                                    : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg);
                     rc = (int)e;
                 } else
                 if (lk && (dv == V_LDSDGRAD || !overridden)) {
@@ -1382,8 +1402,9 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 EpiMaskAct ef{nw.dz[i - 1], l.K, hmask, lp.act};
                 hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st);
                 if (e == hipSuccess)
-                    e = launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr,
-                                       f32_split_mode() == 2);
+                    e = x6_specialised()
+                            ? launch_gemm_x6s(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, num_cus(), f32_split_mode() == 2, st)
+                            : launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr, f32_split_mode() == 2);
                 rc = (int)e;
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
