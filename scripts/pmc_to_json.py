@@ -9,8 +9,8 @@ import json
 import sys
 
 LABELS = {
-    'c2.dgrad': 'lds_dgrad_async_kernel<20, 20, 32',
-    'c3.dgrad': 'lds_dgrad_kernel<9, 9, 64',
+    'c2.dgrad': 'dgrad_x6_kernel<20, 20, 32',
+    'c3.dgrad': 'dgrad_x6_kernel<9, 9, 64',
     'c1.wgrad': 'imgres_u8x3_wgrad_kernel<84',
     'c2.wgrad': 'imgres_wgrad_kernel<false, 20, 20, 32',
     'c3.wgrad': 'imgres_wgrad_kernel<false, 9, 9, 64',

@@ -13,7 +13,7 @@ def main(db, sub=''):
     acc = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
     for k, cn, v, d in rows:
-        if sub in k and any(t in k for t in ('gemm', 'wres', 'imgres', 'lds_dgrad', 'heads', 'mlp_step', 'reduce_slabs', 'adam')):
+        if sub in k and any(t in k for t in ('gemm', 'wres', 'imgres', 'dgrad', 'heads', 'mlp_step', 'reduce_slabs', 'adam', 'lstm')):
             acc[k][cn] += v
             disp[k].add(d)
     for k in acc:
