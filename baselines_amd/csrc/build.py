@@ -11,12 +11,14 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['rollout.hip', 'model.hip', 'envs.hip', 'replay.hip', 'wrappers.hip', 'comm.hip']
-HEADERS = ['common.hip.h', 'gemm.hip.h', 'wres.hip.h', 'imgres.hip.h', 'ldsdgrad.hip.h', 'mlpstep.hip.h', 'gemmx6.hip.h', 'dgradx6.hip.h', 'gemmx6s.hip.h', 'comm.hip.h', 'lstm.hip.h', 'qnet.hip.h',
+HEADERS = ['common.hip.h', 'gemm.hip.h', 'wres.hip.h', 'imgres.hip.h', 'ldsdgrad.hip.h', 'mlpstep.hip.h', 'gemmx6.hip.h', 'dgradx6.hip.h', 'gemmx6s.hip.h', 'c1fwd.hip.h', 'wgradx8.hip.h', 'comm.hip.h', 'lstm.hip.h', 'qnet.hip.h',
            os.path.join('..', '..', 'include', 'mrl.h')]
 LIB = os.path.join(HERE, 'libmrl.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-variable']
+# MRL_BUILD_DEFINES="-DMRL_X6_EXPERIMENTS": extra kernel instantiations for the timing experiments (scripts/ab_options.py)
+FLAGS += os.environ.get('MRL_BUILD_DEFINES', '').split()
 
 
 def _mtime(p):

@@ -74,9 +74,11 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 // at 2 waves per SIMD (-18 %); ONE workgroup per CU with double-buffered LDS, two register stages and the staging
 // code scheduled between the MFMAs (sched_group_barrier) is 25-45 % slower -- a lone wave per SIMD stalls the matrix
 // pipe at every LDS wait.
-template <class AF, class EF, int WM, int WN, bool X8>
+template <class AF, class EF, int WM, int WN, bool X8, int xd = 0>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
                                                       int mtiles, int ntiles, long long* dbg, int prio) {
+    // xd (timing experiments, builds with -DMRL_X6_EXPERIMENTS, option x6_dbg = 100 + bits): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global loads in the
+    // main loop, 8 = no split arithmetic (raw halves are staged), 16 = every step re-reads k tile 0 (cache hits)
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NA = BM / 32;                            // float4 of A per thread and tile
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     float4 ra0[NA];
     u32x4v rb0[3 * NQ];                // clang vector type: HIP's uint4 struct in an array is left in scratch memory by SROA
     auto fetch = [&](float4 (&ra)[NA], u32x4v (&rb)[3 * NQ], int t) {
-        const int k0 = min(t, ntile - 1) * X6_BK;          // past the end: re-read the last tile (never consumed)
+        const int k0 = (xd & 16) ? 0 : min(t, ntile - 1) * X6_BK;          // past the end: re-read the last tile (never consumed)
         const long ko = af.koff(k0);
 #pragma unroll
         for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
@@ -135,8 +137,13 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
-            split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
-            split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
+            if (xd & 8) {
+                a0x = a1x = a2x = __float_as_uint(ra[p].x) ^ __float_as_uint(ra[p].y);
+                a0y = a1y = a2y = __float_as_uint(ra[p].z) ^ __float_as_uint(ra[p].w);
+            } else {
+                split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
+                split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
+            }
             uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
             *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
@@ -165,6 +172,15 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     fb[b][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * 2 + b) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+            if (xd & 2) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) acc[a][b][pl] += (float)fa[a][pl][0] + (float)fb[b][pl][0];
+                continue;
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         stamp(t, 2);
         __syncthreads();
         stamp(t, 3);
-        fetch(ra0, rb0, t + 1);                // next tile in flight during the MFMA block (past the end: re-reads the last)
+        if (!(xd & 4)) fetch(ra0, rb0, t + 1);                // next tile in flight during the MFMA block (past the end: re-reads the last)
         // fences: without them the compiler hoists the split arithmetic of swrite() up to the loads and waits for
         // them BEFORE the MFMA block (the full memory latency exposed once per tile)
         __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             for (int r = 0; r < 16; ++r) x[r] = ef.aux(o[r] < 0 ? 0 : o[r], colc);     // all loads first, unconditional
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (o[r] >= 0) ef.put(o[r], acc[a][b][r], x[r]);
+                if (o[r] >= 0 && (!(xd & 1) || acc[a][b][r] == 12345.678f)) ef.put(o[r], acc[a][b][r], x[r]);
             if (ef.mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -246,7 +262,8 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     }
 }
 
-inline int& x6_prio() { static int p = 0; return p; }      // experiment knob (mrl_set_option "x6_prio")
+inline int& x6_prio() { static int p = 0; return p; }
+inline int& x6_xd() { static int p = 0; return p; }        // experiment bits (mrl_set_option "x6_dbg" = 100 + bits)      // experiment knob (mrl_set_option "x6_prio")
 inline bool gemm_x6_ok(const void* A, long lda, int K) {
     return K % X6_BK == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;
 }
@@ -259,7 +276,7 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
     return hipGetLastError();
 }
 
-template <class AF, class EF, int WM, int WN, bool X8>
+template <class AF, class EF, int WM, int WN, bool X8, int XD = 0>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
                                      hipStream_t stream) {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -267,7 +284,24 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
     const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
-    auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8>;
+#ifdef MRL_X6_EXPERIMENTS
+    if (XD == 0 && x6_xd() != 0) {
+        switch (x6_xd()) {
+        case 1: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 1>(af, Bp, ef, M, N, K, dbg, stream);
+        case 2: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 2>(af, Bp, ef, M, N, K, dbg, stream);
+        case 3: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 3>(af, Bp, ef, M, N, K, dbg, stream);
+        case 4: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 4>(af, Bp, ef, M, N, K, dbg, stream);
+        case 8: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 8>(af, Bp, ef, M, N, K, dbg, stream);
+        case 7: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 7>(af, Bp, ef, M, N, K, dbg, stream);
+        case 15: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 15>(af, Bp, ef, M, N, K, dbg, stream);
+        case 16: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 16>(af, Bp, ef, M, N, K, dbg, stream);
+        case 5: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 5>(af, Bp, ef, M, N, K, dbg, stream);
+        case 17: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 17>(af, Bp, ef, M, N, K, dbg, stream);
+        default: break;
+        }
+    }
+#endif
+    auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD>;
     static bool raised = false;                // per instantiation
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -24,6 +24,8 @@
 #include "gemmx6.hip.h"
 #include "dgradx6.hip.h"
 #include "gemmx6s.hip.h"
+#include "c1fwd.hip.h"
+#include "wgradx8.hip.h"
 #include "mlpstep.hip.h"
 #include "comm.hip.h"
 #include "lstm.hip.h"
@@ -288,8 +290,8 @@ static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -302,6 +304,7 @@ extern "C" int mrl_set_option(const char* name, int value) {
         if (!strcmp(kOptionEnv[i][0], name)) {
             option_table()[name] = value;
             if (!strcmp(name, "x6_prio")) x6_prio() = value;
+            if (!strcmp(name, "x6_dbg")) x6_xd() = value >= 100 ? value - 100 : 0;
             return 0;
         }
     return MRL_EINVAL;
@@ -1162,6 +1165,14 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                     ProfScope ps(label, fl, 0.0, st);
+                    // NatureCNN's first layer: image-resident kernel (c1fwd.hip.h) -- images reach LDS once, coalesced,
+                    // instead of 16-byte per-lane gathers of overlapping patches
+                    if (l.H == C1_H && l.W == C1_W && l.C == C1_C && l.rf == C1_RF && l.stride == C1_S && l.NF == C1_NF &&
+                        l.act == ACT_RELU && get_option("c1_lds", "MRL_C1_LDS", 1)) {
+                        if (mbits) { if (mwrote) *mwrote = 1; }
+                        return (int)launch_c1fwd_lds(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st,
+                                                     get_option("c1_dbg", "MRL_C1_DBG", 0));
+                    }
                     if (mbits && l.NF == 32 && l.act == ACT_RELU) { we.mask = mbits; if (mwrote) *mwrote = 1; }
                     return (int)launch_wres_u8x3<WresEpiBiasAct, WRES_PF, 16>(wa, W, we, l.K, l.NF, tiles, num_cus(), st);
                 }
@@ -1274,7 +1285,30 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         const void* asrc = first ? in.obs : (const void*)hprev;
         const int ik = imgres_kind(l, first && m->d.ob_dtype == MRL_OB_U8, asrc);
         int rc;
-        if (ik && (var == V_IMGRES || tune_table().find(std::string(l.name) + ".wgrad") == tune_table().end())) {
+        // conv2 / conv3 / fc1 at training batch sizes: eight exact bf16 products per multiply on the bf16 pipe
+        // (wgradx8.hip.h), the arithmetic mode of the forward / data-gradient engines
+        WgradX8Plan wx;
+        if (!first && f32_split_mode() == 2 && get_option("wgrad_x8", "MRL_WGRAD_X8", 1) && !tuned(l, "wgrad") && !layer_padded(l) &&
+            (uintptr_t)hprev % 16 == 0 && (uintptr_t)dz % 16 == 0 && (l.kind != 0 || ((l.rf * l.C) % 4 == 0 && l.C % 4 == 0)))
+            wx = wgrad_x8_plan(rows, l.K, l.N, num_cus(), ws.part_floats, get_option("wgrad_x8", "MRL_WGRAD_X8", 1) >= 2);
+        if (wx.cfg) {
+            char label[40];
+            if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
+            hipError_t e;
+            {
+                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
+                if (l.kind == 0) {
+                    X6ConvA ca;
+                    fill_conv(ca, l, hprev, (int)rows, nullptr);
+                    e = launch_wgrad_x8(ca, dz, ws.part, slab, (int)rows, l.K, l.N, wx, st);
+                } else {
+                    e = launch_wgrad_x8(X6DenseA{hprev, (long)l.K}, dz, ws.part, slab, (int)rows, l.K, l.N, wx, st);
+                }
+            }
+            if (e != hipSuccess) return (int)e;
+            rc = reduce_slabs(ws.part, slab, wx.nslab, grads + l.w_off, slab, accumulate, st, &ctx);
+            if (rc) return rc;
+        } else if (ik && (var == V_IMGRES || tune_table().find(std::string(l.name) + ".wgrad") == tune_table().end())) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
             nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;

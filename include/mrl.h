@@ -360,9 +360,14 @@ int mrl_tune_set(const char* label, int variant);
  *                  0 = LDS-resident fp32-MFMA engine
  *   "relu_bits"  [MRL_RELU_BITS, 1]  conv forward epilogues also write a 1-bit-per-element ReLU mask that the tiled data
  *                  gradient reads instead of the fp32 activations; 0 = fp32 activations
+ *   "wgrad_x8"   [MRL_WGRAD_X8, 1]  weight gradients of the fp32-activation layers (conv2, conv3, fc1) on the bf16 pipe with
+ *                  eight exact products per multiply (needs f32_bf16x6 = 2): 1 = layers with >= 128 outputs (fc1), 2 = conv2 / conv3
+ *                  too (slower than their image-resident fp32 MFMA engine), 0 = fp32 MFMA engines
+ *   "c1_lds"     [MRL_C1_LDS, 1]  first conv layer forward on the image-resident engine (whole uint8 images staged once
+ *                  in LDS, double-buffered); 0 = weights-resident gather engine.  Same products, same sums.
  *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
- *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg": experiment knobs
+ *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg", "dgx6_dbg", "c1_dbg", "x6_spec", "x6_prio": experiment knobs
  * Returns MRL_EINVAL for unknown names.  mrl_get_option reports the value in effect. */
 int mrl_set_option(const char* name, int value);
 int mrl_get_option(const char* name, int* value_out);
