@@ -26,6 +26,7 @@
 #include "gemmx6s.hip.h"
 #include "c1fwd.hip.h"
 #include "wgradx8.hip.h"
+#include "c1wgrad.hip.h"
 #include "mlpstep.hip.h"
 #include "comm.hip.h"
 #include "lstm.hip.h"
@@ -290,8 +291,8 @@ static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -1122,7 +1123,9 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     hipError_t e;
     const int nacc = get_option("imgres_nacc", "MRL_IMGRES_NACC", 0);   // accumulator replicas per wave (experiment knob)
     const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);          // 0: fp32 MFMA path for the u8 layer
-    if (kind == 1 && x3 && !hcur) {
+    if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 1)) {
+        e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st);       // both operands transposed while staged (c1wgrad.hip.h)
+    } else if (kind == 1 && x3 && !hcur) {
         e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
     } else if (kind == 1) {
         if (nacc == 1) e = launch_imgres_wgrad<true, 84, 84, 4, 8, 4, 32, 8, 1, 1, 1>(x, srow, dz, hcur, B, part, nblocks, st);

@@ -363,6 +363,8 @@ int mrl_tune_set(const char* label, int variant);
  *   "wgrad_x8"   [MRL_WGRAD_X8, 1]  weight gradients of the fp32-activation layers (conv2, conv3, fc1) on the bf16 pipe with
  *                  eight exact products per multiply (needs f32_bf16x6 = 2): 1 = layers with >= 128 outputs (fc1), 2 = conv2 / conv3
  *                  too (slower than their image-resident fp32 MFMA engine), 0 = fp32 MFMA engines
+ *   "c1_wgrad2"  [MRL_C1_WGRAD2, 1]  first conv layer weight gradient with both operands transposed while staged
+ *                  (c1wgrad.hip.h); 0 = per-byte gathers (imgres.hip.h).  Same products.
  *   "c1_lds"     [MRL_C1_LDS, 1]  first conv layer forward on the image-resident engine (whole uint8 images staged once
  *                  in LDS, double-buffered); 0 = weights-resident gather engine.  Same products, same sums.
  *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions

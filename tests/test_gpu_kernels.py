@@ -295,12 +295,12 @@ def test_engine_options_agree():
         dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
         return g.cpu().numpy(), st.cpu().numpy()
 
-    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8')}
+    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2')}
     assert defaults['f32_bf16x6'] == 2, 'the default arithmetic of the split engines is the 8-product mode'
     try:
         cnn = ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False)
         # ---- small batches: plain random data
-        for cfg, B, opt in [(cnn, 160, 'u8_bf16x3'), (cnn, 161, 'c1_lds'), (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused'),
+        for cfg, B, opt in [(cnn, 160, 'u8_bf16x3'), (cnn, 161, 'c1_lds'), (cnn, 163, 'c1_wgrad2'), (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused'),
                             (('mlp', (4,), np.float32, 'categorical', 2, False), 96, 'mlp_fused')]:
             g1, s1 = grads(*cfg, B, dict(defaults, **{opt: 1}))
             g0, s0 = grads(*cfg, B, dict(defaults, **{opt: 0}))
@@ -310,7 +310,7 @@ def test_engine_options_agree():
         # ---- B = 1152 (tiled split engines everywhere they apply), screened minibatch: every entry
         B = 1152
         scr = _problem(B, 21)
-        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0)    # all fp32 x fp32 sites on the fp32 MFMA pipe
+        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0)    # all fp32 x fp32 sites on the fp32 MFMA pipe
         g0, s0 = grads(*cnn, B, ref_opts, scr)
         scale = np.abs(g0).max()
         for name, opts, tol in [('8 products (default)', dict(defaults), 3e-6),
