@@ -4,13 +4,13 @@
 // on the bf16 matrix pipe with exact products (uint8 pixels are exact in bf16, dz is split exactly into three bf16
 // planes; wres.hip.h "bf16 x 3").  The contraction index is the output PIXEL, and v_mfma_f32_32x32x16_bf16 wants 8
 // consecutive contraction elements per lane, so BOTH operands are transposed while they are staged:
-//   * image: T[y][x & 3][c][x >> 2] (bytes) -- 8 consecutive output pixels of one patch byte (kx, c) are 8 consecutive
-//     bytes (two aligned dword reads + v_alignbyte for kx >= 4) instead of 8 single-byte gathers; the 4x4 byte
-//     transposes are 8 v_perm per 16 bytes in the staging pass;
+//   * image: T[y][x & 3][c][x >> 2] (bf16, converted once per byte in the staging pass) -- 8 consecutive output pixels
+//     of one patch byte (kx, c) are 8 consecutive elements: aligned dword reads + v_alignbyte for kx >= 4 instead of 8
+//     single-byte gathers and 12 conversion instructions per fragment;
 //   * dz: threads load 16-byte pieces of 8 consecutive pixels, split, pack PIXEL pairs and write 16-byte runs of
 //     dzT[plane][n][pixel] (the transposed-write trick of wgradx8.hip.h), octets XOR-swizzled against bank conflicts;
-//   * a wave owns 4 patch rows ky (4 accumulators) and a quarter of the pixels: a dz fragment is read once per 12 MFMAs
-//     (the predecessor read it once per 3: 8 waves x the whole dzT per image made LDS the bound);
+//   * a wave owns 2 patch rows ky (2 accumulators) and half of the pixels (13 / 12 blocks of 16): a dz fragment is read
+//     once per 6 MFMAs (the predecessor read it once per 3 and gathered bytes: LDS-bound);
 //   * the next image's pixels and dz are in flight (registers) during the MFMA phase.
 // One persistent workgroup per CU, one partial slab per workgroup (summed by reduce_slabs, model.hip).
 #pragma once
@@ -22,22 +22,27 @@
 
 namespace mrl {
 
-constexpr int CW_XI = 24;                                // bytes per (y, x&3, c) run: 21 used
-constexpr int CW_TROW = 16 * CW_XI;                      // bytes per image row of T
-constexpr int CW_TBYTES = C1_H * CW_TROW;                // 32256
+constexpr int CW_XI = 24;                                // elements per (y, x&3, c) run: 21 used
+constexpr int CW_TROW = 16 * CW_XI * 2 + 40;             // bytes per image row of T (bf16): 202 dwords = 10 mod 64, so the
+                                                         // staging writes of a wave (13 rows x 5 runs of 8 bytes) spread over the banks
+constexpr int CW_TBYTES = C1_H * CW_TROW;                // 67872
 constexpr int CW_PP = 432;                               // bf16 per dzT row (400 pixels; 216 dwords = 24 mod 64)
 constexpr int CW_PLANE = C1_NF * CW_PP;
-constexpr size_t CW_LDS = (size_t)CW_TBYTES + (size_t)3 * CW_PLANE * 2;       // 115200
+constexpr size_t CW_LDS = (size_t)CW_TBYTES + (size_t)3 * CW_PLANE * 2;       // 150816
 constexpr int CW_NT = 512;
 
+template <int DBG = 0>       // timing experiments (-DMRL_X6_EXPERIMENTS, option c1_dbg = 32 + bits): 1 no MFMA phase, 2 no staging pass, 4 no loads, 8 no MFMAs, 16 no image staging, 32 no dz staging
 __global__ __launch_bounds__(CW_NT) void c1wgrad_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
                                                         const float* __restrict__ dz, int B, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) uint8_t cws[];
-    uint8_t* T = cws;
+    uint8_t* T = cws;                                     // bf16 [y][x & 3][c][x >> 2]
     uint16_t* dzt = reinterpret_cast<uint16_t*>(cws + CW_TBYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
-    const int kg = wave & 1, pg = wave >> 1;             // patch rows 4kg .. 4kg+3, pixel quarter
+    constexpr int NA = 2, NKG = C1_RF / NA, NPG = 8 / NKG;       // accumulators (patch rows) per wave; 25 blocks over NPG pixel groups
+    constexpr int NB0 = (25 + NPG - 1) / NPG, NB1 = 25 / NPG;  // blocks of group 0 / of the others: 13 + 12 (7 + 6 + 6 + 6 for NA = 4)
+    static_assert(NB0 + (NPG - 1) * NB1 == 25, "block split");
+    const int kg = wave % NKG, pg = wave / NKG;          // patch rows NA*kg .. NA*kg + NA-1, pixel group
 
     // ---- staging roles
     const bool img_full = tid < 420, img_small = tid >= 420 && tid < 504;
@@ -48,39 +53,49 @@ __global__ __launch_bounds__(CW_NT) void c1wgrad_kernel(const uint8_t* __restric
     u32x4v vi[4];
     float4 vd[8];
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int b) {
-        const long row = srow ? (long)srow[b] : (long)b;
+    auto fetch_img = [&](long row) {
         const uint8_t* gi = obs + row * C1_IMG + img_off;
         vi[0] = *reinterpret_cast<const u32x4v*>(gi);
         if (img_full) {
 #pragma unroll
             for (int j = 1; j < 4; ++j) vi[j] = *reinterpret_cast<const u32x4v*>(gi + 16 * j);
         }
+    };
+    auto fetch_dz = [&](int b) {
         const float* gd = dz + ((long)b * C1_PIX + 8 * d_o) * C1_NF + 4 * d_nc;
 #pragma unroll
         for (int r = 0; r < 8; ++r) vd[r] = *reinterpret_cast<const float4*>(gd + r * C1_NF);
     };
-    auto stage = [&]() {
-        if (img_full) {
-            uint8_t* d = T + iy * CW_TROW + 4 * iq;
+    auto image_row = [&](int b) { return b < B ? (srow ? (long)srow[b] : (long)b) : 0L; };
+    // pixels are converted to bf16 HERE, once per image byte (the MFMA phase would convert every byte ~4 times, and
+    // every VALU instruction costs the SIMD 4 cycles of matrix-pipe issue)
+    auto stage_img = [&]() {
+        if (DBG & 16) {
+        } else if (img_full) {
+            uint8_t* d = T + iy * CW_TROW + 8 * iq;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {                 // pixel x = 16 iq + 4 j + p: phase p, run index 4 iq + j
-                const uint32_t w0 = vi[0][p], w1 = vi[1][p], w2 = vi[2][p], w3 = vi[3][p];
-                const uint32_t a = __builtin_amdgcn_perm(w1, w0, 0x05010400u), bq = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
-                const uint32_t c = __builtin_amdgcn_perm(w3, w2, 0x05010400u), dq = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
-                *reinterpret_cast<uint32_t*>(d + (p * 4 + 0) * CW_XI) = __builtin_amdgcn_perm(c, a, 0x05040100u);
-                *reinterpret_cast<uint32_t*>(d + (p * 4 + 1) * CW_XI) = __builtin_amdgcn_perm(c, a, 0x07060302u);
-                *reinterpret_cast<uint32_t*>(d + (p * 4 + 2) * CW_XI) = __builtin_amdgcn_perm(dq, bq, 0x05040100u);
-                *reinterpret_cast<uint32_t*>(d + (p * 4 + 3) * CW_XI) = __builtin_amdgcn_perm(dq, bq, 0x07060302u);
-            }
+            for (int p = 0; p < 4; ++p)                   // pixel x = 16 iq + 4 j + p: phase p, run index 4 iq + j
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t f0 = __float_as_uint((float)((vi[0][p] >> (8 * c)) & 0xff));
+                    const uint32_t f1 = __float_as_uint((float)((vi[1][p] >> (8 * c)) & 0xff));
+                    const uint32_t f2 = __float_as_uint((float)((vi[2][p] >> (8 * c)) & 0xff));
+                    const uint32_t f3 = __float_as_uint((float)((vi[3][p] >> (8 * c)) & 0xff));
+                    *reinterpret_cast<uint2*>(d + (p * 4 + c) * (CW_XI * 2)) =
+                        make_uint2(__builtin_amdgcn_perm(f1, f0, 0x07060302u), __builtin_amdgcn_perm(f3, f2, 0x07060302u));
+                }
         } else if (img_small) {
-            uint8_t* d = T + iy * CW_TROW + 20;
+            uint8_t* d = T + iy * CW_TROW + 40;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) d[(p * 4 + c) * CW_XI] = (uint8_t)(vi[0][p] >> (8 * c));
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<uint16_t*>(d + (p * 4 + c) * (CW_XI * 2)) =
+                        (uint16_t)(__float_as_uint((float)((vi[0][p] >> (8 * c)) & 0xff)) >> 16);
         }
-        if (dz_on) {
+    };
+    auto stage_dz = [&]() {
+        if (dz_on && !(DBG & 32)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 uint32_t p[3][4];
@@ -101,81 +116,98 @@ __global__ __launch_bounds__(CW_NT) void c1wgrad_kernel(const uint8_t* __restric
         }
     };
 
-    f32x16 acc[4];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    // ---- MFMA roles: lane (i = kx*4 + c, g): bytes of patch column (kx, c), pixel octet 2 blk + g of the block
-    const int kx = i >> 2, cc = i & 3, sh = kx >> 2;
-    const uint8_t* tl = T + ((kx & 3) * 4 + cc) * CW_XI + (4 * kg) * CW_TROW;
-    const uint16_t* bl = dzt + i * CW_PP;
+    // ---- MFMA roles: lane (i = kx*4 + c, g): patch column (kx, c), pixel octet 2 blk + g of the block.  8 consecutive output
+    // pixels are 8 consecutive bf16 of T (+1 element for kx >= 4: dword reads from the aligned start, v_alignbyte by 2 bytes).
+    const int kx = i >> 2, cc = i & 3, shb = (kx >> 2) * 2;
+    const uint8_t* tl = T + ((kx & 3) * 4 + cc) * (CW_XI * 2) + (NA * kg) * CW_TROW;
+    const uint8_t* bl = reinterpret_cast<const uint8_t*>(dzt + i * CW_PP);
     const int bsw = i >> 3;
-    const int blk0 = pg == 0 ? 0 : 1 + 6 * pg, nblk = pg == 0 ? 7 : 6;       // 25 blocks of 16 pixels: 7 + 6 + 6 + 6
+    const int blk0 = pg == 0 ? 0 : NB0 + NB1 * (pg - 1), nblk = pg == 0 ? NB0 : NB1;
+    // per-block LDS offsets of this lane, image-independent: first / second half of the octet (bytes into T, packed 16 + 16
+    // bits) and the swizzled octet of dzT
+    uint32_t offT[NB0], offD[NB0];
+#pragma unroll
+    for (int q = 0; q < NB0; ++q) {
+        const int oo = 2 * (blk0 + min(q, nblk - 1)) + g;
+        const int p0 = 8 * oo, p1 = p0 + 4;
+        const int oyA = p0 / C1_OW, oxA = p0 - oyA * C1_OW, oyB = p1 / C1_OW, oxB = p1 - oyB * C1_OW;
+        offT[q] = (uint32_t)(oyA * (C1_S * CW_TROW) + 2 * oxA) | ((uint32_t)(oyB * (C1_S * CW_TROW) + 2 * oxB) << 16);
+        offD[q] = (uint32_t)(((oo & ~3) | ((oo & 3) ^ bsw)) * 16);
+    }
 
+    // the next image's loads are issued as soon as the registers they land in have been staged (not after the barrier): the
+    // dz staging pass and the barrier are part of the latency cover; the row index of the image after that is already here
     int b = blockIdx.x;
-    if (b < B) fetch(b);
+    long row_next = image_row(b + gridDim.x);
+    if (b < B && !(DBG & 4)) { fetch_img(image_row(b)); fetch_dz(b); }
     for (; b < B; b += gridDim.x) {
+        const bool more = b + (int)gridDim.x < B && !(DBG & 4);
         __syncthreads();                                   // previous image fully consumed
-        stage();
-        __syncthreads();
-        if (b + (int)gridDim.x < B) fetch(b + gridDim.x);  // next image in flight during the MFMA phase
+        if (!(DBG & 2)) stage_img();
+        if (more) fetch_img(row_next);
         __builtin_amdgcn_sched_barrier(0);
-        // octet o = 2 blk + g: pixels 8o .. 8o+7; first half at (oyA, oxA), second half (pixel 8o+4) at (oyB, oxB)
-        int o = 2 * blk0 + g;
-        uint32_t raw[2][4][4];
-        bf16x8 bf[2][3];
-        auto rd = [&](int oo, uint32_t (&rw)[4][4], bf16x8 (&bb)[3]) {
-            const int p0 = 8 * oo, p1 = p0 + 4;
-            const int oyA = p0 / C1_OW, oxA = p0 - oyA * C1_OW, oyB = p1 / C1_OW, oxB = p1 - oyB * C1_OW;
-            const uint8_t* pa = tl + oyA * (C1_S * CW_TROW) + oxA;
-            const uint8_t* pb = tl + oyB * (C1_S * CW_TROW) + oxB;
+        if (!(DBG & 2)) stage_dz();
+        if (more) fetch_dz(b + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        row_next = image_row(b + 2 * gridDim.x);
+        if (DBG & 1) continue;
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t raw[2][NA][6];
+        u32x4v bfr[2][3];
+        auto rd = [&](int q, uint32_t (&rw)[NA][6], u32x4v (&bb)[3]) {
+            const uint8_t* pa = tl + (offT[q] & 0xffffu);
+            const uint8_t* pb = tl + (offT[q] >> 16);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                rw[a][0] = *reinterpret_cast<const uint32_t*>(pa + a * CW_TROW);
-                rw[a][1] = *reinterpret_cast<const uint32_t*>(pa + a * CW_TROW + 4);
-                rw[a][2] = *reinterpret_cast<const uint32_t*>(pb + a * CW_TROW);
-                rw[a][3] = *reinterpret_cast<const uint32_t*>(pb + a * CW_TROW + 4);
+            for (int a = 0; a < NA; ++a) {
+                const uint2 v0 = *reinterpret_cast<const uint2*>(pa + a * CW_TROW);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(pb + a * CW_TROW);
+                rw[a][0] = v0.x; rw[a][1] = v0.y; rw[a][2] = *reinterpret_cast<const uint32_t*>(pa + a * CW_TROW + 8);
+                rw[a][3] = v1.x; rw[a][4] = v1.y; rw[a][5] = *reinterpret_cast<const uint32_t*>(pb + a * CW_TROW + 8);
             }
-            const uint16_t* bp = bl + ((oo & ~3) | ((oo & 3) ^ bsw)) * 8;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bb[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * CW_PLANE);
+            for (int pl = 0; pl < 3; ++pl) bb[pl] = *reinterpret_cast<const u32x4v*>(bl + offD[q] + pl * (CW_PLANE * 2));
         };
-        rd(o, raw[0], bf[0]);
-        for (int q = 0; q < nblk; q += 2) {
+        rd(0, raw[0], bfr[0]);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (q + u < nblk) {
-                    const int cur = u;
-                    if (q + u + 1 < nblk) rd(o + 2, raw[cur ^ 1], bf[cur ^ 1]);
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < NB0; ++q) {
+            if (q < nblk) {
+                const int cur = q & 1;
+                if (q + 1 < nblk) rd(q + 1 < NB0 ? q + 1 : NB0 - 1, raw[cur ^ 1], bfr[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const uint32_t lo = __builtin_amdgcn_alignbyte(raw[cur][a][1], raw[cur][a][0], sh);
-                        const uint32_t hi = __builtin_amdgcn_alignbyte(raw[cur][a][3], raw[cur][a][2], sh);
-                        U32x4 av;
-                        u8x4_to_bf16(lo, av.x, av.y);
-                        u8x4_to_bf16(hi, av.z, av.w);
-                        const bf16x8 af = __builtin_bit_cast(bf16x8, av);
-                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[cur][2], acc[a], 0, 0, 0);
-                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[cur][1], acc[a], 0, 0, 0);
-                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[cur][0], acc[a], 0, 0, 0);
+                for (int a = 0; a < NA; ++a) {
+                    const u32x4v av = u32x4v{__builtin_amdgcn_alignbyte(raw[cur][a][1], raw[cur][a][0], shb),
+                                             __builtin_amdgcn_alignbyte(raw[cur][a][2], raw[cur][a][1], shb),
+                                             __builtin_amdgcn_alignbyte(raw[cur][a][4], raw[cur][a][3], shb),
+                                             __builtin_amdgcn_alignbyte(raw[cur][a][5], raw[cur][a][4], shb)};
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+                    if (DBG & 8) {
+                        acc[a][0] += (float)af[0] + (float)af[7] + __uint_as_float(bfr[cur][0][0] ^ bfr[cur][1][1] ^ bfr[cur][2][2]);
+                        continue;
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    o += 2;
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfr[cur][2]), acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfr[cur][1]), acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfr[cur][0]), acc[a], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 
     // ---- combine the 4 pixel quarters (fixed order) and write the partial slab: [K][NF] weights / 255, then [NF] bias
     __syncthreads();
-    float* red = reinterpret_cast<float*>(cws);            // [6 waves][4 acc][16][64 lanes]
+    float* red = reinterpret_cast<float*>(cws);            // [(NPG - 1) * NKG waves][NA acc][16][64 lanes]
     if (pg > 0) {
-        float* r0 = red + (long)((pg - 1) * 2 + kg) * 4096;
+        float* r0 = red + (long)((pg - 1) * NKG + kg) * (NA * 1024);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) r0[(a * 16 + r) * 64 + lane] = acc[a][r];
     }
@@ -184,13 +216,13 @@ __global__ __launch_bounds__(CW_NT) void c1wgrad_kernel(const uint8_t* __restric
     float* out = part + (long)blockIdx.x * slab;
     if (pg == 0) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[a][r];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) v += red[(long)(s * 2 + kg) * 4096 + (a * 16 + r) * 64 + lane];
-                const int m = (4 * kg + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                for (int s = 0; s < NPG - 1; ++s) v += red[(long)(s * NKG + kg) * (NA * 1024) + (a * 16 + r) * 64 + lane];
+                const int m = (NA * kg + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 out[(long)m * C1_NF + i] = v / 255.f;
             }
     }
@@ -209,9 +241,28 @@ __global__ __launch_bounds__(CW_NT) void c1wgrad_kernel(const uint8_t* __restric
     }
 }
 
+template <int DBG = 0>
 inline hipError_t launch_c1wgrad(const void* obs, const int32_t* srow, const float* dz, int B, float* part, int nblocks,
-                                 hipStream_t stream) {
-    auto kern = c1wgrad_kernel;
+                                 hipStream_t stream, int dbg = 0) {
+#ifdef MRL_X6_EXPERIMENTS
+    if (DBG == 0 && dbg) {
+        switch (dbg) {
+        case 1: return launch_c1wgrad<1>(obs, srow, dz, B, part, nblocks, stream);
+        case 2: return launch_c1wgrad<2>(obs, srow, dz, B, part, nblocks, stream);
+        case 3: return launch_c1wgrad<3>(obs, srow, dz, B, part, nblocks, stream);
+        case 4: return launch_c1wgrad<4>(obs, srow, dz, B, part, nblocks, stream);
+        case 6: return launch_c1wgrad<6>(obs, srow, dz, B, part, nblocks, stream);
+        case 8: return launch_c1wgrad<8>(obs, srow, dz, B, part, nblocks, stream);
+        case 14: return launch_c1wgrad<14>(obs, srow, dz, B, part, nblocks, stream);
+        case 16: return launch_c1wgrad<16>(obs, srow, dz, B, part, nblocks, stream);
+        case 32: return launch_c1wgrad<32>(obs, srow, dz, B, part, nblocks, stream);
+        case 17: return launch_c1wgrad<17>(obs, srow, dz, B, part, nblocks, stream);
+        case 33: return launch_c1wgrad<33>(obs, srow, dz, B, part, nblocks, stream);
+        default: break;
+        }
+    }
+#endif
+    auto kern = c1wgrad_kernel<DBG>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -1124,7 +1124,7 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     const int nacc = get_option("imgres_nacc", "MRL_IMGRES_NACC", 0);   // accumulator replicas per wave (experiment knob)
     const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);          // 0: fp32 MFMA path for the u8 layer
     if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 1)) {
-        e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st);       // both operands transposed while staged (c1wgrad.hip.h)
+        e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st, std::max(0, get_option("c1_dbg", "MRL_C1_DBG", 0) - 32));       // both operands transposed while staged (c1wgrad.hip.h)
     } else if (kind == 1 && x3 && !hcur) {
         e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
     } else if (kind == 1) {
