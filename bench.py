@@ -126,6 +126,7 @@ def cpu_baseline(kind):
 def arithmetic_mode(_lib):
     """which arithmetic the GEMM sites of the NatureCNN update run in (engine options in effect, include/mrl.h)"""
     x3, x6, dg = _lib.get_option('u8_bf16x3'), _lib.get_option('f32_bf16x6'), _lib.get_option('dgrad_x6')
+    wx = _lib.get_option('wgrad_x8') if x6 == 2 else 0
     nprod = {0: 0, 1: 6, 2: 8}[x6]
     sites = {}
     for s in ('c1.fwd', 'c1.wgrad'):
@@ -134,8 +135,9 @@ def arithmetic_mode(_lib):
         sites[s] = nprod
     for s in ('c2.dgrad', 'c3.dgrad'):
         sites[s] = nprod if dg else 0
-    for s in ('c2.wgrad', 'c3.wgrad', 'fc1.wgrad'):
-        sites[s] = 0
+    for s in ('c2.wgrad', 'c3.wgrad'):
+        sites[s] = 8 if wx >= 2 else 0
+    sites['fc1.wgrad'] = 8 if wx >= 1 else 0
     text = ('fp32 storage, fp32 accumulation, every product at least as accurate as an IEEE fp32 multiply. '
             'fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise fmaf chain): %s. '
             'bf16 MFMA on EXACT operand splits -- uint8 pixels x 3 exact bf16 planes of the other operand (3 products, '

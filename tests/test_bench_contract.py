@@ -23,7 +23,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert (r['traffic'] is None or r['traffic_source'].startswith('profiles/r02')) and d['dtype'] == 'f32'
     assert d['config']['arithmetic_mode'] == 'bf16x8-split'          # the headline runs the 8-product (fp32-or-better) mode
     kr = d['kernel_rooflines']
-    assert kr['c2.wgrad']['peak'] == 157.3 and abs(kr['c2.fwd']['peak'] - 2516.6 / 8) < 1e-6 and abs(kr['c1.fwd']['peak'] - 2516.6 / 3) < 1e-6
+    assert kr['c2.wgrad']['peak'] == 157.3 and abs(kr['c2.fwd']['peak'] - 2516.6 / 8) < 1e-3 and abs(kr['c1.fwd']['peak'] - 2516.6 / 3) < 1e-3
     assert {o['workload'].split()[0] for o in d['other_configs']} == {'ppo2', 'deepq'} and len(d['other_configs']) == 3
     c = d['cpu_baseline']
     assert c['host_cpu_count'] >= c['cores'] and c['host_cpu_model']
