@@ -151,6 +151,168 @@ __global__ __launch_bounds__(WAVES * 64) void c1fwd_lds_kernel(const uint8_t* __
     }
 }
 
+// ---- second generation: the image is converted to bf16 ONCE while it is staged (every VALU instruction costs the SIMD
+// 4 cycles of matrix-pipe issue: scripts/valu_ubench.hip; the kernel above converts every byte ~4 times inside the MFMA
+// loop), a wave owns TWO 32-pixel tiles so that a filter fragment is read once per 6 MFMAs, the bias is the initial
+// accumulator value, output rows are addressed by instruction immediates and the ReLU mask words are collected with
+// v_writelane from the wave ballots.  8 waves, two LDS image buffers (2 x 56448 B bf16) + filter planes (50688 B).
+constexpr int C1_IMG16 = C1_IMG * 2;                     // bytes of a bf16 image
+typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DBG = 0>
+__global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out, uint32_t* __restrict__ mask, int B) {
+    constexpr int NT = 512, WAVES = 8;
+    constexpr int CHUNKS = C1_IMG / 16;                   // 1764 16-byte chunks of an image
+    constexpr int NLD = (CHUNKS + NT - 1) / NT;           // 4
+    constexpr int TILES = (C1_PIX + 31) / 32;             // 13 (the last one: 16 pixels)
+    extern __shared__ __attribute__((aligned(16))) uint16_t c1s[];
+    uint16_t* wp = c1s;                                   // [3][32][KP] bf16 planes of filter / 255
+    uint8_t* img = reinterpret_cast<uint8_t*>(c1s + 3 * 32 * C1_KP);      // [2 buffers][C1_IMG] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    for (int e = tid; e < 3 * 32 * C1_KP; e += NT) wp[e] = 0;
+    __syncthreads();
+    for (int e = tid; e < C1_K * C1_NF; e += NT) {
+        const int k = e / C1_NF, n = e - k * C1_NF;
+        const float v = w[e] / 255.f;
+        const uint32_t h0 = bf16_rn_bits(v);
+        const float r1 = v - __uint_as_float(h0 << 16);
+        const uint32_t h1 = bf16_rn_bits(r1);
+        const float r2 = r1 - __uint_as_float(h1 << 16);
+        const uint32_t h2 = bf16_rn_bits(r2);
+        wp[(0 * 32 + n) * C1_KP + k] = (uint16_t)h0;
+        wp[(1 * 32 + n) * C1_KP + k] = (uint16_t)h1;
+        wp[(2 * 32 + n) * C1_KP + k] = (uint16_t)h2;
+    }
+    const float bv = bias[i];
+    c1_u32x4 st[NLD];
+    auto fetch = [&](int b) {
+        const long row = srow ? (long)srow[b] : (long)b;
+        const uint8_t* g = obs + row * C1_IMG;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) st[q] = *reinterpret_cast<const c1_u32x4*>(g + (long)min(q * NT + tid, CHUNKS - 1) * 16);
+    };
+    auto stage = [&](uint8_t* dst) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int c = q * NT + tid;
+            if (c < CHUNKS) {
+                uint32_t e[8];
+                u8x4_to_bf16(st[q][0], e[0], e[1]);
+                u8x4_to_bf16(st[q][1], e[2], e[3]);
+                u8x4_to_bf16(st[q][2], e[4], e[5]);
+                u8x4_to_bf16(st[q][3], e[6], e[7]);
+                *reinterpret_cast<c1_u32x4*>(dst + (long)c * 32) = c1_u32x4{e[0], e[1], e[2], e[3]};
+                *reinterpret_cast<c1_u32x4*>(dst + (long)c * 32 + 16) = c1_u32x4{e[4], e[5], e[6], e[7]};
+            }
+        }
+    };
+    int b = blockIdx.x;
+    if (b < B) fetch(b);
+    __syncthreads();                                      // planes built
+    if (b < B) stage(img);
+    __syncthreads();
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wp + (long)i * C1_KP + 8 * h);
+    int par = 0;
+    for (; b < B; b += gridDim.x, par ^= 1) {
+        const uint8_t* cur = img + par * C1_IMG16;
+        const bool more = b + (int)gridDim.x < B;
+        if (more) fetch(b + gridDim.x);                   // next image in flight during the MFMA phase
+        __builtin_amdgcn_sched_barrier(0);
+        const int t0 = 2 * wave;
+        if (t0 < TILES) {
+            const bool two = t0 + 1 < TILES;
+            const uint8_t* arow[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int m = min((t0 + u) * 32 + i, C1_PIX - 1);
+                const int oy = m / C1_OW, ox = m - oy * C1_OW;
+                arow[u] = cur + ((oy * C1_S * C1_W + ox * C1_S) * C1_C + 8 * h) * 2;
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = bv;          // bias: column (= lane & 31) constant of the C layout
+            c1_u32x4 fa[2][2], fb[2][3];
+            auto lds_block = [&](int q, c1_u32x4 (&a)[2], c1_u32x4 (&bq)[3]) {
+                const int off = ((q >> 1) * (C1_W * C1_C) + 16 * (q & 1)) * 2;
+                a[0] = *reinterpret_cast<const c1_u32x4*>(arow[0] + off);
+                a[1] = *reinterpret_cast<const c1_u32x4*>(arow[1] + off);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bq[pl] = *reinterpret_cast<const c1_u32x4*>(wrow + (q * 16 + pl * 32 * C1_KP) * 2);
+            };
+            lds_block(0, fa[0], fb[0]);
+#pragma unroll
+            for (int q = 0; q < 2 * C1_RF; ++q) {
+                const int cq = q & 1;
+                if (q + 1 < 2 * C1_RF) lds_block(q + 1, fa[cq ^ 1], fb[cq ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl) {
+                    if (DBG & 2) continue;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cq][0]), __builtin_bit_cast(bf16x8, fb[cq][pl]), acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cq][1]), __builtin_bit_cast(bf16x8, fb[cq][pl]), acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue: ReLU, 32 channels of a pixel = 128 contiguous bytes, rows at immediate offsets; mask: one word per pixel =
+            // one half of a wave ballot, written into lane (pixel of the tile) by v_writelane.
+            // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            const long pix0 = (long)b * C1_PIX;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                const int t = t0 + u;
+                const int nr = (t == TILES - 1) ? 8 : 16;             // last tile: pixels 384 .. 399 = rows 0 .. 15
+                float* ob = out + ((pix0 + t * 32 + 4 * h) * C1_NF + i);
+                int mw = 0;
+                if (mask) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (r < nr) {
+                            const int rr = (r & 3) + 8 * (r >> 2);
+                            const float v = fmaxf(acc[u][r], 0.f);
+                            if (!(DBG & 1)) ob[rr * C1_NF] = v;
+                            const unsigned long long bal = __ballot(v > 0.f);
+                            const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
+                            // (the s_nop covers the VALU-writes-SGPR -> v_writelane wait states, which the compiler does not
+                            // insert around inline assembly)
+                            asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                                         : "+v"(mw) : "s"(blo), "s"(bhi), "n"(rr), "n"(rr + 4));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r < nr && !(DBG & 1)) ob[((r & 3) + 8 * (r >> 2)) * C1_NF] = fmaxf(acc[u][r], 0.f);
+                }
+                if (mask && lane < (nr == 16 ? 32 : 16)) mask[pix0 + t * 32 + lane] = (uint32_t)mw;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage(img + (par ^ 1) * C1_IMG16);
+        __syncthreads();                                  // next image staged; this image's patch reads are done
+    }
+}
+
+inline hipError_t launch_c1fwd2(const void* obs, const int32_t* srow, const float* w, const float* bias, float* out, uint32_t* mask,
+                                int B, int num_cus, hipStream_t stream) {
+    auto kern = c1fwd2_kernel<0>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    const size_t lds = (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * C1_IMG16;          // 163584
+    const int grid = std::max(1, std::min(B, num_cus));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B);
+    return hipGetLastError();
+}
+
 inline size_t c1fwd_lds_bytes(int G) { return (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * G * C1_IMG; }
 
 inline hipError_t launch_c1fwd_lds(const void* obs, const int32_t* srow, const float* w, const float* bias, float* out,

@@ -292,7 +292,7 @@ static const char* const kOptionEnv[][2] = {
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
     {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 1};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -1171,8 +1171,10 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     // NatureCNN's first layer: image-resident kernel (c1fwd.hip.h) -- images reach LDS once, coalesced,
                     // instead of 16-byte per-lane gathers of overlapping patches
                     if (l.H == C1_H && l.W == C1_W && l.C == C1_C && l.rf == C1_RF && l.stride == C1_S && l.NF == C1_NF &&
-                        l.act == ACT_RELU && get_option("c1_lds", "MRL_C1_LDS", 1)) {
+                        l.act == ACT_RELU && get_option("c1_lds", "MRL_C1_LDS", 2)) {
                         if (mbits) { if (mwrote) *mwrote = 1; }
+                        if (get_option("c1_lds", "MRL_C1_LDS", 2) >= 2)
+                            return (int)launch_c1fwd2(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st);
                         return (int)launch_c1fwd_lds(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st,
                                                      get_option("c1_dbg", "MRL_C1_DBG", 0));
                     }

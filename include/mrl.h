@@ -365,8 +365,9 @@ int mrl_tune_set(const char* label, int variant);
  *                  too (slower than their image-resident fp32 MFMA engine), 0 = fp32 MFMA engines
  *   "c1_wgrad2"  [MRL_C1_WGRAD2, 1]  first conv layer weight gradient with both operands transposed while staged
  *                  (c1wgrad.hip.h); 0 = per-byte gathers (imgres.hip.h).  Same products.
- *   "c1_lds"     [MRL_C1_LDS, 1]  first conv layer forward on the image-resident engine (whole uint8 images staged once
- *                  in LDS, double-buffered); 0 = weights-resident gather engine.  Same products, same sums.
+ *   "c1_lds"     [MRL_C1_LDS, 2]  first conv layer forward on the image-resident engines (whole images staged once in LDS,
+ *                  double-buffered): 2 = pixels converted to bf16 while staged, two tiles per wave; 1 = uint8 images,
+ *                  converted per fragment; 0 = weights-resident gather engine.  Same products, same sums.
  *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
  *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg", "dgx6_dbg", "c1_dbg", "x6_spec", "x6_prio": experiment knobs

@@ -320,6 +320,8 @@ def test_engine_options_agree():
                                  dict(defaults, relu_bits=0), 3e-6),
                                 ('8 products, first conv layer on the gather engine instead of the image-resident one',
                                  dict(defaults, c1_lds=0), 3e-6),
+                                ('8 products, first conv layer forward: the other image-resident kernel',
+                                 dict(defaults, c1_lds=3 - defaults['c1_lds']), 3e-6),
                                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
                                  dict(defaults, wgrad_x8=0), 3e-6),
                                 ('8 products, weight gradients of conv2 / conv3 on the split engine too',
