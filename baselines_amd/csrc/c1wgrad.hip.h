@@ -241,6 +241,215 @@ __global__ __launch_bounds__(CW_NT) void c1wgrad_kernel(const uint8_t* __restric
     }
 }
 
+// ---- half-image variant: a work unit is (image, upper / lower 10 output rows = 44 image rows), a workgroup is 4 waves and
+// 81.6 KB of LDS, TWO workgroups per CU: one workgroup's staging pass, barriers and load waits run under the other's MFMA
+// phase (the single 512-thread workgroup above spends ~30 % of its time in neither VALU nor MFMA issue)
+constexpr int CH_ROWS = 44;
+constexpr int CH_TBYTES = CH_ROWS * CW_TROW;             // 35552
+constexpr int CH_PP = 240;                               // bf16 per dzT row: 200 pixels + the empty octets 25 .. 27; 120 dwords = 56 mod 64
+constexpr int CH_PLANE = C1_NF * CH_PP;
+constexpr size_t CH_LDS = (size_t)CH_TBYTES + (size_t)3 * CH_PLANE * 2;       // 81632
+constexpr int CH_NT = 256;
+constexpr int CH_NB = 13;                                // blocks of 16 pixels: 25 octets, the 26th is empty
+
+template <int DBG = 0>
+__global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
+                                                                const float* __restrict__ dz, int B, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t cws[];
+    uint8_t* T = cws;                                     // bf16 [44 rows][x & 3][c][x >> 2]
+    uint16_t* dzt = reinterpret_cast<uint16_t*>(cws + CH_TBYTES);
+    const int tid = threadIdx.x, lane = tid & 63, kg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    constexpr int NA = 2;                                 // patch rows 2kg, 2kg + 1 per wave
+
+    // ---- staging roles
+    const bool img_on = tid < 220;
+    const int iy = img_on ? tid / 5 : 0, iq = img_on ? tid % 5 : 0;
+    const bool img_tail = img_on && iq == 4;              // also the last 4 pixels of the row (run index 20)
+    const int img_off = (iy * C1_W + 16 * iq) * C1_C;
+    const bool dz_on = tid < 200;
+    const int d_o = dz_on ? tid >> 3 : 0, d_nc = tid & 7;
+    u32x4v vi[5];
+    float4 vd[8];
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch_img = [&](long row, int half) {
+        const uint8_t* gi = obs + row * C1_IMG + half * (40 * C1_W * C1_C) + img_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vi[j] = *reinterpret_cast<const u32x4v*>(gi + 16 * j);
+        if (img_tail) vi[4] = *reinterpret_cast<const u32x4v*>(gi + 64);
+    };
+    auto fetch_dz = [&](int b, int half) {
+        const float* gd = dz + ((long)b * C1_PIX + half * 200 + 8 * d_o) * C1_NF + 4 * d_nc;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vd[r] = *reinterpret_cast<const float4*>(gd + r * C1_NF);
+    };
+    auto image_row = [&](int u) { return (u >> 1) < B ? (srow ? (long)srow[u >> 1] : (long)(u >> 1)) : 0L; };
+    auto stage_img = [&]() {
+        if (img_on && !(DBG & 16)) {
+            uint8_t* d = T + iy * CW_TROW + 8 * iq;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t f0 = __float_as_uint((float)((vi[0][p] >> (8 * c)) & 0xff));
+                    const uint32_t f1 = __float_as_uint((float)((vi[1][p] >> (8 * c)) & 0xff));
+                    const uint32_t f2 = __float_as_uint((float)((vi[2][p] >> (8 * c)) & 0xff));
+                    const uint32_t f3 = __float_as_uint((float)((vi[3][p] >> (8 * c)) & 0xff));
+                    *reinterpret_cast<uint2*>(d + (p * 4 + c) * (CW_XI * 2)) =
+                        make_uint2(__builtin_amdgcn_perm(f1, f0, 0x07060302u), __builtin_amdgcn_perm(f3, f2, 0x07060302u));
+                }
+            if (img_tail) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<uint16_t*>(d + 8 + (p * 4 + c) * (CW_XI * 2)) =
+                            (uint16_t)(__float_as_uint((float)((vi[4][p] >> (8 * c)) & 0xff)) >> 16);
+            }
+        }
+    };
+    auto stage_dz = [&]() {
+        if (dz_on && !(DBG & 32)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t p[3][4];
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const float x0 = j == 0 ? vd[r].x : j == 1 ? vd[r].y : j == 2 ? vd[r].z : vd[r].w;
+                    const float x1 = j == 0 ? vd[r + 1].x : j == 1 ? vd[r + 1].y : j == 2 ? vd[r + 1].z : vd[r + 1].w;
+                    split2_bf16x3(x0, x1, p[0][r / 2], p[1][r / 2], p[2][r / 2]);
+                }
+                const int n = 4 * d_nc + j;
+                uint16_t* d = dzt + n * CH_PP + ((d_o & ~3) | ((d_o & 3) ^ (d_nc >> 1))) * 8;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<u32x4v*>(d + pl * CH_PLANE) = u32x4v{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { bias4.x += vd[r].x; bias4.y += vd[r].y; bias4.z += vd[r].z; bias4.w += vd[r].w; }
+        }
+    };
+    // the octet slots 24 .. 27 of every dzT row: one of them is rewritten with octet 24 per image, the other three stay zero
+    // and are what the empty 26th octet of the last block reads
+    for (int e = tid; e < 3 * C1_NF * 16; e += CH_NT) {
+        const int rowi = e >> 4, w2 = e & 15;
+        reinterpret_cast<uint32_t*>(dzt + rowi * CH_PP + 24 * 8)[w2] = 0u;
+    }
+
+    f32x16 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    const int kx = i >> 2, cc = i & 3, shb = (kx >> 2) * 2;
+    const uint8_t* tl = T + ((kx & 3) * 4 + cc) * (CW_XI * 2) + (NA * kg) * CW_TROW;
+    const uint8_t* bl = reinterpret_cast<const uint8_t*>(dzt + i * CH_PP);
+    const int bsw = i >> 3;
+    uint32_t offT[CH_NB], offD[CH_NB];
+#pragma unroll
+    for (int q = 0; q < CH_NB; ++q) {
+        const int oo = 2 * q + g;                          // 0 .. 25; octet 25 does not exist: its A reads are clamped to octet 24
+        const int oa = min(oo, 24);                        // (finite values), its dz slot is zero
+        const int p0 = 8 * oa, p1 = p0 + 4;
+        const int oyA = p0 / C1_OW, oxA = p0 - oyA * C1_OW, oyB = p1 / C1_OW, oxB = p1 - oyB * C1_OW;
+        offT[q] = (uint32_t)(oyA * (C1_S * CW_TROW) + 2 * oxA) | ((uint32_t)(oyB * (C1_S * CW_TROW) + 2 * oxB) << 16);
+        offD[q] = (uint32_t)(((oo & ~3) | ((oo & 3) ^ bsw)) * 16);
+    }
+
+    const int nunits = 2 * B;
+    int u = blockIdx.x;
+    long row_next = image_row(u + gridDim.x);
+    if (u < nunits && !(DBG & 4)) { fetch_img(image_row(u), u & 1); fetch_dz(u >> 1, u & 1); }
+    for (; u < nunits; u += gridDim.x) {
+        const int un = u + gridDim.x;
+        const bool more = un < nunits && !(DBG & 4);
+        __syncthreads();                                   // previous unit fully consumed
+        if (!(DBG & 2)) stage_img();
+        if (more) fetch_img(row_next, un & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 2)) stage_dz();
+        if (more) fetch_dz(un >> 1, un & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        row_next = image_row(u + 2 * gridDim.x);
+        if (DBG & 1) continue;
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t raw[2][NA][6];
+        u32x4v bfr[2][3];
+        auto rd = [&](int q, uint32_t (&rw)[NA][6], u32x4v (&bb)[3]) {
+            const uint8_t* pa = tl + (offT[q] & 0xffffu);
+            const uint8_t* pb = tl + (offT[q] >> 16);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const uint2 v0 = *reinterpret_cast<const uint2*>(pa + a * CW_TROW);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(pb + a * CW_TROW);
+                rw[a][0] = v0.x; rw[a][1] = v0.y; rw[a][2] = *reinterpret_cast<const uint32_t*>(pa + a * CW_TROW + 8);
+                rw[a][3] = v1.x; rw[a][4] = v1.y; rw[a][5] = *reinterpret_cast<const uint32_t*>(pb + a * CW_TROW + 8);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bb[pl] = *reinterpret_cast<const u32x4v*>(bl + offD[q] + pl * (CH_PLANE * 2));
+        };
+        rd(0, raw[0], bfr[0]);
+#pragma unroll
+        for (int q = 0; q < CH_NB; ++q) {
+            const int cur = q & 1;
+            if (q + 1 < CH_NB) rd(q + 1, raw[cur ^ 1], bfr[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const u32x4v av = u32x4v{__builtin_amdgcn_alignbyte(raw[cur][a][1], raw[cur][a][0], shb),
+                                         __builtin_amdgcn_alignbyte(raw[cur][a][2], raw[cur][a][1], shb),
+                                         __builtin_amdgcn_alignbyte(raw[cur][a][4], raw[cur][a][3], shb),
+                                         __builtin_amdgcn_alignbyte(raw[cur][a][5], raw[cur][a][4], shb)};
+                const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+                if (DBG & 8) continue;
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfr[cur][2]), acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfr[cur][1]), acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bfr[cur][0]), acc[a], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- partial slab of this workgroup: [K][NF] weights / 255, then [NF] bias
+    const long slab = (long)C1_K * C1_NF + C1_NF;
+    float* out = part + (long)blockIdx.x * slab;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (NA * kg + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            out[(long)m * C1_NF + i] = acc[a][r] / 255.f;
+        }
+    __syncthreads();
+    float4* rb4 = reinterpret_cast<float4*>(cws);
+    rb4[tid] = dz_on ? bias4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tid < C1_NF) {
+        const int nc = tid >> 2, comp = tid & 3;
+        float t = 0.f;
+        for (int q = nc; q < 200; q += 8) {
+            const float4 v = rb4[q];
+            t += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+        }
+        out[(long)C1_K * C1_NF + tid] = t;
+    }
+}
+
+inline hipError_t launch_c1wgrad_half(const void* obs, const int32_t* srow, const float* dz, int B, float* part, int nblocks,
+                                      hipStream_t stream) {
+    auto kern = c1wgrad_half_kernel<0>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CH_NT), CH_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part);
+    return hipGetLastError();
+}
+
 template <int DBG = 0>
 inline hipError_t launch_c1wgrad(const void* obs, const int32_t* srow, const float* dz, int B, float* part, int nblocks,
                                  hipStream_t stream, int dbg = 0) {

@@ -292,7 +292,7 @@ static const char* const kOptionEnv[][2] = {
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
     {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 1};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 2};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -1123,7 +1123,7 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     hipError_t e;
     const int nacc = get_option("imgres_nacc", "MRL_IMGRES_NACC", 0);   // accumulator replicas per wave (experiment knob)
     const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);          // 0: fp32 MFMA path for the u8 layer
-    if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 1)) {
+    if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 2)) {
         e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st, std::max(0, get_option("c1_dbg", "MRL_C1_DBG", 0) - 32));       // both operands transposed while staged (c1wgrad.hip.h)
     } else if (kind == 1 && x3 && !hcur) {
         e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
@@ -1312,6 +1312,20 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             }
             if (e != hipSuccess) return (int)e;
             rc = reduce_slabs(ws.part, slab, wx.nslab, grads + l.w_off, slab, accumulate, st, &ctx);
+            if (rc) return rc;
+        } else if (ik == 1 && first && !tuned(l, "wgrad") && get_option("u8_bf16x3", "MRL_U8_BF16X3", 1) &&
+                   get_option("c1_wgrad2", "MRL_C1_WGRAD2", 2) >= 2) {
+            // conv1: half-image work units, two 4-wave workgroups per CU (c1wgrad.hip.h)
+            int nblocks = (int)std::min<long>(std::min<long>(2L * num_cus(), 2L * B), (long)(ws.part_floats / slab));
+            if (nblocks < 1) return MRL_ENOSPC;
+            {
+                char label[40];
+                if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
+                ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
+                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, st);
+                if (e != hipSuccess) return (int)e;
+            }
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
             if (rc) return rc;
         } else if (ik && (var == V_IMGRES || tune_table().find(std::string(l.name) + ".wgrad") == tune_table().end())) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);

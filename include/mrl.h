@@ -363,8 +363,9 @@ int mrl_tune_set(const char* label, int variant);
  *   "wgrad_x8"   [MRL_WGRAD_X8, 1]  weight gradients of the fp32-activation layers (conv2, conv3, fc1) on the bf16 pipe with
  *                  eight exact products per multiply (needs f32_bf16x6 = 2): 1 = layers with >= 128 outputs (fc1), 2 = conv2 / conv3
  *                  too (slower than their image-resident fp32 MFMA engine), 0 = fp32 MFMA engines
- *   "c1_wgrad2"  [MRL_C1_WGRAD2, 1]  first conv layer weight gradient with both operands transposed while staged
- *                  (c1wgrad.hip.h); 0 = per-byte gathers (imgres.hip.h).  Same products.
+ *   "c1_wgrad2"  [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
+ *                  (c1wgrad.hip.h): 2 = half-image work units, two workgroups per CU; 1 = whole images, one workgroup
+ *                  per CU; 0 = per-byte gathers (imgres.hip.h).  Same products.
  *   "c1_lds"     [MRL_C1_LDS, 2]  first conv layer forward on the image-resident engines (whole images staged once in LDS,
  *                  double-buffered): 2 = pixels converted to bf16 while staged, two tiles per wave; 1 = uint8 images,
  *                  converted per fragment; 0 = weights-resident gather engine.  Same products, same sums.

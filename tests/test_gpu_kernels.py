@@ -322,6 +322,8 @@ def test_engine_options_agree():
                                  dict(defaults, c1_lds=0), 3e-6),
                                 ('8 products, first conv layer forward: the other image-resident kernel',
                                  dict(defaults, c1_lds=3 - defaults['c1_lds']), 3e-6),
+                                ('8 products, conv1 weight gradient: whole-image workgroups',
+                                 dict(defaults, c1_wgrad2=1), 3e-6),
                                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
                                  dict(defaults, wgrad_x8=0), 3e-6),
                                 ('8 products, weight gradients of conv2 / conv3 on the split engine too',
