@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "wres.hip.h"
+#include "planes.hip.h"
 
 namespace mrl {
 
@@ -159,10 +160,20 @@ __global__ __launch_bounds__(WAVES * 64) void c1fwd_lds_kernel(const uint8_t* __
 constexpr int C1_IMG16 = C1_IMG * 2;                     // bytes of a bf16 image
 typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int DBG = 0>
+struct C1TrRelu {            // h = relu(acc) (bias folded into the accumulator), fp32 + bit mask + planes
+    float* out; uint32_t* mask; uint16_t* hp; long pstride;
+    __device__ __forceinline__ uint32_t block_aux(long, bool) const { return 0; }
+    __device__ __forceinline__ float4 apply(long, int, int, float4 a, uint32_t, bool) const {
+        return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+    }
+};
+// TR (planes.hip.h): MFMA operands swapped, a lane owns one pixel and 16 of its 32 channels: the epilogue also writes the
+// plane tensor of h (the pre-split A operand of conv2's forward) and stores 16 bytes per lane and instruction.
+template <int DBG = 0, bool TR = false>
 __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                     float* __restrict__ out, uint32_t* __restrict__ mask, int B) {
+                                                     float* __restrict__ out, uint32_t* __restrict__ mask, int B,
+                                                     uint16_t* __restrict__ hp, long pstride) {
     constexpr int NT = 512, WAVES = 8;
     constexpr int CHUNKS = C1_IMG / 16;                   // 1764 16-byte chunks of an image
     constexpr int NLD = (CHUNKS + NT - 1) / NT;           // 4
@@ -187,6 +198,9 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
         wp[(2 * 32 + n) * C1_KP + k] = (uint16_t)h2;
     }
     const float bv = bias[i];
+    float bvr[16];                                        // TR: the accumulator register indexes the channel
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bvr[r] = TR ? bias[(r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
     c1_u32x4 st[NLD];
     auto fetch = [&](int b) {
         const long row = srow ? (long)srow[b] : (long)b;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][r] = bv;          // bias: column (= lane & 31) constant of the C layout
+                for (int r = 0; r < 16; ++r) acc[u][r] = TR ? bvr[r] : bv;          // bias: column (= lane & 31) constant of the C layout
             c1_u32x4 fa[2][2], fb[2][3];
             auto lds_block = [&](int q, c1_u32x4 (&a)[2], c1_u32x4 (&bq)[3]) {
                 const int off = ((q >> 1) * (C1_W * C1_C) + 16 * (q & 1)) * 2;
@@ -253,8 +267,13 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
 #pragma unroll
                 for (int pl = 2; pl >= 0; --pl) {
                     if (DBG & 2) continue;
+                    if constexpr (TR) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cq][pl]), __builtin_bit_cast(bf16x8, fa[cq][0]), acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cq][pl]), __builtin_bit_cast(bf16x8, fa[cq][1]), acc[1], 0, 0, 0);
+                    } else {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cq][0]), __builtin_bit_cast(bf16x8, fb[cq][pl]), acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cq][1]), __builtin_bit_cast(bf16x8, fb[cq][pl]), acc[1], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -262,6 +281,17 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
             // one half of a wave ballot, written into lane (pixel of the tile) by v_writelane.
             // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
             const long pix0 = (long)b * C1_PIX;
+            if constexpr (TR) {
+                // lane (i, h): pixel t*32 + i, channels 8g + 4h + j; the bias is already in the accumulator
+                C1TrRelu ef{out, mask, hp, pstride};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
+                    const int pix = (t0 + u) * 32 + i;
+                    const bool valid = pix < C1_PIX;
+                    tr_block_epilogue(ef, acc[u], valid ? (pix0 + pix) * C1_NF : 0L, 0, h, valid);
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u == 1 && !two) break;
@@ -291,6 +321,7 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
                 }
                 if (mask && lane < (nr == 16 ? 32 : 16)) mask[pix0 + t * 32 + lane] = (uint32_t)mw;
             }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) stage(img + (par ^ 1) * C1_IMG16);
@@ -298,18 +329,20 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
     }
 }
 
+// hp != nullptr: transposed-accumulator kernel, also writes the plane tensor of the output (pstride elements per plane)
 inline hipError_t launch_c1fwd2(const void* obs, const int32_t* srow, const float* w, const float* bias, float* out, uint32_t* mask,
-                                int B, int num_cus, hipStream_t stream) {
-    auto kern = c1fwd2_kernel<0>;
-    static bool raised = false;
-    if (!raised) {
+                                int B, int num_cus, hipStream_t stream, uint16_t* hp = nullptr, long pstride = 0, bool tr_plain = false) {
+    const bool tr = hp || tr_plain;
+    auto kern = tr ? c1fwd2_kernel<0, true> : c1fwd2_kernel<0, false>;
+    static bool raised[2] = {false, false};
+    if (!raised[tr ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised[tr ? 1 : 0] = true;
     }
     const size_t lds = (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * C1_IMG16;          // 163584
     const int grid = std::max(1, std::min(B, num_cus));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B, hp, pstride);
     return hipGetLastError();
 }
 

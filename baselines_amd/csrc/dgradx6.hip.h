@@ -42,7 +42,7 @@ struct DgX6Geom {
 
 // B planes [plane][col = cls*C + c][k = (a*TAPS + b2)*NF + n] = split(W[py + S*a][px + S*b2][c][n]) (0 for taps beyond RF)
 template <int H, int W, int C, int RF, int S, int NF>
-__global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int kperm) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     const int total = G::N * G::K;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -57,24 +57,34 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
         const float r1 = v - __uint_as_float(u & 0xffff0000u);
         const uint32_t u1 = __float_as_uint(r1);
         const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-        out[0 * total + e] = (uint16_t)(u >> 16);
-        out[1 * total + e] = (uint16_t)(u1 >> 16);
-        out[2 * total + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+        const int eo = kperm ? col * G::K + tap * NF + (int)kperm32(n) : e;      // k in the order of a plane tensor (planes.hip.h)
+        out[0 * total + eo] = (uint16_t)(u >> 16);
+        out[1 * total + eo] = (uint16_t)(u1 >> 16);
+        out[2 * total + eo] = (uint16_t)(__float_as_uint(r2) >> 16);
     }
 }
 
-template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8>
+// PA: dz comes as a plane tensor (dzp = plane 0, dz_ps elements between planes; Bp laid out with kperm): staging without
+//     split arithmetic.  TR: MFMA operands swapped, a lane owns one image and 16 channels of a destination pixel: the
+//     epilogue reads ONE mask word per 32 channels and writes fp32 + the plane tensor of dx with 16-byte stores
+//     (planes.hip.h); C % 32 == 0, ReLU below.
+// IL: next tile's global loads issued between the MFMAs (see gemm_x6_kernel).
+template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool X8, bool PA = false, bool TR = false, bool IL = false>
 __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
                                                        const float* __restrict__ hmask, const uint32_t* __restrict__ mbits,
                                                        float* __restrict__ dx, int act, int B, int btiles,
-                                                       long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg, int prio) {
+                                                       long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg, int prio,
+                                                       const uint16_t* __restrict__ dzp, long dz_ps,
+                                                       uint16_t* __restrict__ dxp, long dx_ps) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
     static_assert(G::N % BN == 0 || G::N < BN, "column tiles");
     constexpr int NTN = (G::N + BN - 1) / BN;             // column tiles
     constexpr int NA = BM / 32, NQ = BN / 64;
+    constexpr int NAP = BM / 64;                          // PA: 16-byte pieces of A per thread, plane and tile
     constexpr int OH = G::OH, OW = G::OW, TAPS = G::TAPS;
+    static_assert(!TR || C % 32 == 0, "a 32-column block lies inside one destination pixel");
     extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
     // logical tile order: (image group, position, column tile) with the column tile fastest; XCD x owns a contiguous run
     // of tiles and its persistent workgroups (slots_per_xcd of them: two per CU) walk that run with stride slots_per_xcd,
@@ -105,10 +115,19 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 
     // A rows = images b0 + p*32 + tid/8 at dz pixel (yy, xx); a tap moves the pointer by a row-independent offset
     const float* ap[NA];
+    const uint16_t* app[NAP];          // PA: images b0 + p*64 + tid/4, 8 bf16 at k = (tid&3)*8, plane 0
+    if constexpr (PA) {
+#pragma unroll
+        for (int p = 0; p < NAP; ++p) {
+            const int b = min(b0 + p * 64 + (tid >> 2), B - 1);
+            app[p] = dzp + ((long)(b * OH + yy) * OW + xx) * NF + (tid & 3) * 8;
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
         const int b = min(b0 + p * 32 + (tid >> 3), B - 1);
         ap[p] = dz + ((long)(b * OH + yy) * OW + xx) * NF + (tid & 7) * 4;
+    }
     }
     const uint16_t* bp[NQ];
 #pragma unroll
@@ -127,21 +146,36 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
         while (t < G::NKT && !kvalid(t)) ++t;
         return t;
     };
-    float4 ra0[NA];
+    float4 ra0[PA ? 1 : NA];
+    u32x4v rp0[PA ? 3 * NAP : 1];
     u32x4v rb0[3 * NQ];
-    auto fetch = [&](float4 (&ra)[NA], u32x4v (&rb)[3 * NQ], int tt) {      // tt: a VALID k tile
+    auto fetch = [&](float4 (&ra)[PA ? 1 : NA], u32x4v (&rp)[PA ? 3 * NAP : 1], u32x4v (&rb)[3 * NQ], int tt) {      // tt: a VALID k tile
         const int tap = tt / G::KT_PER_TAP, kin = (tt - tap * G::KT_PER_TAP) * X6_BK;
         const int a = tap / TAPS, b2 = tap - a * TAPS;
         const long ko = (long)kin - (long)(a * OW + b2) * NF;
+        if constexpr (PA) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int p = 0; p < NAP; ++p) rp[pl * NAP + p] = *reinterpret_cast<const u32x4v*>(app[p] + pl * dz_ps + ko);
+        } else {
 #pragma unroll
         for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + tt * X6_BK);
     };
-    auto swrite = [&](const float4 (&ra)[NA], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
+    auto swrite = [&](const float4 (&ra)[PA ? 1 : NA], const u32x4v (&rp)[PA ? 3 * NAP : 1], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
         uint16_t* Bs = As + 3 * BM * X6_LDK;
+        if constexpr (PA) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int p = 0; p < NAP; ++p)
+                    *reinterpret_cast<u32x4v*>(As + (pl * BM + p * 64 + (tid >> 2)) * X6_LDK + (tid & 3) * 8) = rp[pl * NAP + p];
+        } else {
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
@@ -152,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
             *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
         }
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -159,6 +194,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
                 const int c = q * 256 + tid;
                 *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
             }
+    };
+    auto mma = [&](const bf16x8& a, const bf16x8& b, const f32x16& c) {
+        if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     };
     auto mfma_block = [&](const uint16_t* As) {
         const uint16_t* Bs = As + 3 * BM * X6_LDK;
@@ -180,27 +219,47 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {       // small terms first
                     if (X8) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][1], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][2], acc[a][b], 0, 0, 0);
+                        acc[a][b] = mma(fa[a][2], fb[b][1], acc[a][b]);
+                        acc[a][b] = mma(fa[a][1], fb[b][2], acc[a][b]);
                     }
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = mma(fa[a][2], fb[b][0], acc[a][b]);
+                    acc[a][b] = mma(fa[a][1], fb[b][1], acc[a][b]);
+                    acc[a][b] = mma(fa[a][0], fb[b][2], acc[a][b]);
+                    acc[a][b] = mma(fa[a][1], fb[b][0], acc[a][b]);
+                    acc[a][b] = mma(fa[a][0], fb[b][1], acc[a][b]);
+                    acc[a][b] = mma(fa[a][0], fb[b][0], acc[a][b]);
                 }
         }
     };
     uint16_t* L0 = x6s;
     int t = (dbg & 4) ? G::NKT : next_valid(0);
-    if (t < G::NKT) fetch(ra0, rb0, t);
+    if (t < G::NKT) fetch(ra0, rp0, rb0, t);
     while (t < G::NKT) {
         __syncthreads();                       // previous tile's fragment reads are done
-        swrite(ra0, rb0, L0);
+        swrite(ra0, rp0, rb0, L0);
         __syncthreads();
         const int tn = next_valid(t + 1);
-        fetch(ra0, rb0, tn < G::NKT ? tn : t);  // next valid tile in flight during the MFMA block (past the end: re-read, never consumed)
+        if constexpr (IL) {
+            constexpr int NL = (PA ? 3 * NAP : NA) + 3 * NQ;
+            static_assert(2 * NL <= 32, "two MFMAs per load inside the first half of the block");
+            const int tf = tn < G::NKT ? tn : t;
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(ra0, rp0, rb0, tf);
+            mfma_block(L0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * NL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            t = tn;
+            continue;
+        }
+        fetch(ra0, rp0, rb0, tn < G::NKT ? tn : t);  // next valid tile in flight during the MFMA block (past the end: re-read, never consumed)
         __builtin_amdgcn_sched_barrier(0);
         if (prio) __builtin_amdgcn_s_setprio(1);     // the MFMA stream outranks the co-resident workgroup's staging VALU
         mfma_block(L0);
@@ -209,6 +268,23 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
         t = tn;
     }
     // epilogue: column (class, c) of row (image, position) -> its destination pixel, masked by act'(h) of the layer below
+    if constexpr (TR) {
+        // transposed accumulators: lane (i, h) owns image b0 + .. + i and channels 8g + 4h + j of one destination pixel
+        const TrMaskRelu ef{dx, 0, hmask, mbits, dxp, dx_ps};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int cb = n0 + (wn * 2 + b) * 32;
+                const int cls = cb / C, c0 = cb - cls * C;
+                const int py = cls / S, px = cls - py * S;
+                const int iy = yy * S + py, ix = xx * S + px;
+                const int bimg = b0 + (wm * 2 + a) * 32 + i;
+                const bool valid = cb < G::N && iy < H && ix < W && bimg < B;
+                const long o = valid ? (long)bimg * (H * W * C) + ((long)iy * W + ix) * C + c0 : 0L;
+                tr_block_epilogue(ef, acc[a][b], o, c0, h, valid);
+            }
+    } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -243,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             for (int r = 0; r < 16; ++r)
                 if (o[r] >= 0 && (!(dbg & 2) || acc[a][b][r] == 12345.678f)) dx[o[r]] = acc[a][b][r] * x[r];
         }
+    }
     __syncthreads();          // the next tile's first LDS write must not overtake this tile's last fragment reads
     }
 }
@@ -255,13 +332,17 @@ inline size_t dgrad_x6_plane_bytes() {
 
 template <int H, int W, int C, int RF, int S, int NF, int WM, int WN>
 inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* hmask, const uint32_t* mbits, float* dx,
-                                  int act, int B, uint16_t* planes, bool x8, int num_cus, hipStream_t stream, int dbg = 0) {
+                                  int act, int B, uint16_t* planes, bool x8, int num_cus, hipStream_t stream, int dbg = 0,
+                                  const uint16_t* dzp = nullptr, uint16_t* dxp = nullptr, bool tr_plain = false) {
+    // dzp: plane tensor of dz (stride B*OH*OW*NF); dxp: where to leave the plane tensor of dx (stride B*H*W*C); both need
+    // the eight-product mode, dxp also ReLU (or nothing) below
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     if (B <= 0) return hipSuccess;
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NTN = (G::N + BN - 1) / BN;
+    const bool pa = dzp && x8 && !dbg, tr = (dxp || tr_plain) && x8 && !dbg && C % 32 == 0 && (act == ACT_RELU || (!hmask && !mbits));
     hipLaunchKernelGGL((dgx6_split_planes_kernel<H, W, C, RF, S, NF>), dim3((G::N * G::K + 255) / 256), dim3(256), 0, stream,
-                       w, planes);
+                       w, planes, pa ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int btiles = (B + BM - 1) / BM;
@@ -278,9 +359,16 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
         }
         const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);      // two workgroups per CU
         hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, mbits,
-                           dx, act, B, btiles, per_xcd, total, slots, dbg, x6_prio());
+                           dx, act, B, btiles, per_xcd, total, slots, dbg, x6_prio(), dzp, (long)B * G::OH * G::OW * NF, dxp,
+                           (long)B * H * W * C);
         return hipGetLastError();
     };
+    if constexpr (C % 32 == 0) {
+        if (pa && tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, true>);
+        if (tr && x6_il()) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, false, true, true>);
+        if (tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, false, true>);
+    }
+    if (pa) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, false>);
     if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);
     return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, false>);
 }

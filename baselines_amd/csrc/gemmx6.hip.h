@@ -20,9 +20,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gemm.hip.h"
 #include "wres.hip.h"      // bf16x8, U32x4, split2_bf16x3
+#include "planes.hip.h"    // pre-split activation planes: perm32, transposed-accumulator epilogue
 
 namespace mrl {
 
@@ -30,13 +32,15 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 constexpr int X6_BM = 128, X6_BN = 128, X6_BK = 32, X6_LDK = 40;
 
 // out[plane][n][k] (bf16 bits) from src[R][Cn] fp32:  transpose ? (n, k) = (col, row) : (n, k) = (row, col)
+// kperm: k runs in the order of a plane tensor (planes.hip.h: perm32 inside each aligned block of 32)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int Cn, int transpose,
-                                                           uint16_t* __restrict__ out) {
+                                                           uint16_t* __restrict__ out, int kperm = 0) {
     const long total = (long)R * Cn;
     const long Nn = transpose ? Cn : R, Kd = transpose ? R : Cn;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
         const long r = e / Cn, c = e - r * Cn;
-        const long n = transpose ? c : r, k = transpose ? r : c;
+        const long n = transpose ? c : r, k0 = transpose ? r : c;
+        const long k = kperm ? kperm32(k0) : k0;
         const float v = src[e];
         const uint32_t u = __float_as_uint(v);
         const float r1 = v - __uint_as_float(u & 0xffff0000u);
@@ -74,14 +78,22 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 // at 2 waves per SIMD (-18 %); ONE workgroup per CU with double-buffered LDS, two register stages and the staging
 // code scheduled between the MFMAs (sched_group_barrier) is 25-45 % slower -- a lone wave per SIMD stalls the matrix
 // pipe at every LDS wait.
-template <class AF, class EF, int WM, int WN, bool X8, int xd = 0>
+// PA: the A operand is a plane tensor (planes.hip.h; af.p = plane 0 as bf16, a_pstride elements between planes, the
+//     same row / k offsets): staging is 3 x BM/64 16-byte copies per thread, no split arithmetic.
+// TR: MFMA operands swapped -> a lane owns one row and 16 columns of each 32-column block; EF is a Tr* functor
+//     (planes.hip.h) and the epilogue writes fp32 + planes + bit mask with 16-byte stores.  N % 32 == 0.
+// IL: the global loads of the next k tile are issued BETWEEN the MFMAs of this one (sched_group_barrier pattern) instead of
+//     in a phase of their own in front of the MFMA block (phase stamps: issuing 10-11 16-byte loads costs a wave 700-1400
+//     cycles during which it feeds nothing to the matrix pipe).
+template <class AF, class EF, int WM, int WN, bool X8, int xd = 0, bool PA = false, bool TR = false, bool IL = false>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
-                                                      int mtiles, int ntiles, long long* dbg, int prio) {
+                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride) {
     // xd (timing experiments, builds with -DMRL_X6_EXPERIMENTS, option x6_dbg = 100 + bits): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global loads in the
     // main loop, 8 = no split arithmetic (raw halves are staged), 16 = every step re-reads k tile 0 (cache hits)
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NA = BM / 32;                            // float4 of A per thread and tile
+    constexpr int NAP = BM / 64;                           // PA: 16-byte pieces of A per thread, plane and tile
     constexpr int NQ = BN / 64;                            // 16-byte chunks of B per thread, plane and tile
     extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
     // XCD-aware tile order: the column tiles of one row panel take consecutive slots of one XCD, so the A panel (the
@@ -109,9 +121,16 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 
     // staging addresses: A rows p*32 + tid/8, 4 floats at k = (tid&7)*4;  B rows (q*256 + tid)/4, 8 bf16 at ((..)&3)*8
     const float* ap[NA];
+    const uint16_t* app[NAP];          // PA: rows p*64 + tid/4, 8 bf16 at k = (tid&3)*8, plane 0
+    if constexpr (PA) {
 #pragma unroll
-    for (int p = 0; p < NA; ++p)
-        ap[p] = static_cast<const float*>(af.p) + af.row_base(min(m0 + p * 32 + (tid >> 3), M - 1)) + (tid & 7) * 4;
+        for (int p = 0; p < NAP; ++p)
+            app[p] = reinterpret_cast<const uint16_t*>(af.p) + af.row_base(min(m0 + p * 64 + (tid >> 2), M - 1)) + (tid & 3) * 8;
+    } else {
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+            ap[p] = static_cast<const float*>(af.p) + af.row_base(min(m0 + p * 32 + (tid >> 3), M - 1)) + (tid & 7) * 4;
+    }
     const uint16_t* bp[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -120,20 +139,35 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     }
     const long bplane = (long)N * K;
     const int ntile = K / X6_BK;
-    float4 ra0[NA];
+    float4 ra0[PA ? 1 : NA];
+    u32x4v rp0[PA ? 3 * NAP : 1];
     u32x4v rb0[3 * NQ];                // clang vector type: HIP's uint4 struct in an array is left in scratch memory by SROA
-    auto fetch = [&](float4 (&ra)[NA], u32x4v (&rb)[3 * NQ], int t) {
+    auto fetch = [&](float4 (&ra)[PA ? 1 : NA], u32x4v (&rp)[PA ? 3 * NAP : 1], u32x4v (&rb)[3 * NQ], int t) {
         const int k0 = (xd & 16) ? 0 : min(t, ntile - 1) * X6_BK;          // past the end: re-read the last tile (never consumed)
         const long ko = af.koff(k0);
+        if constexpr (PA) {
 #pragma unroll
-        for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int p = 0; p < NAP; ++p) rp[pl * NAP + p] = *reinterpret_cast<const u32x4v*>(app[p] + pl * a_pstride + ko);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + k0);
     };
-    auto swrite = [&](const float4 (&ra)[NA], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
+    auto swrite = [&](const float4 (&ra)[PA ? 1 : NA], const u32x4v (&rp)[PA ? 3 * NAP : 1], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
         uint16_t* Bs = As + 3 * BM * X6_LDK;
+        if constexpr (PA) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int p = 0; p < NAP; ++p)
+                    *reinterpret_cast<u32x4v*>(As + (pl * BM + p * 64 + (tid >> 2)) * X6_LDK + (tid & 3) * 8) = rp[pl * NAP + p];
+        } else {
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
@@ -149,6 +183,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
             *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
         }
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -156,6 +191,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 const int c = q * 256 + tid;
                 *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
             }
+    };
+    // TR: D^T = B A^T -- the first MFMA operand supplies the accumulator's register-indexed dimension
+    auto mma = [&](const bf16x8& a, const bf16x8& b, const f32x16& c) {
+        if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     };
     auto mfma_block = [&](const uint16_t* As) {
         const uint16_t* Bs = As + 3 * BM * X6_LDK;
@@ -186,33 +226,58 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {       // small terms first
                     if (X8) {                       // the two 2^-22 terms: 8 products, dropped part < 2^-29 of a product
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][1], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][2], acc[a][b], 0, 0, 0);
+                        acc[a][b] = mma(fa[a][2], fb[b][1], acc[a][b]);
+                        acc[a][b] = mma(fa[a][1], fb[b][2], acc[a][b]);
                     }
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = mma(fa[a][2], fb[b][0], acc[a][b]);
+                    acc[a][b] = mma(fa[a][1], fb[b][1], acc[a][b]);
+                    acc[a][b] = mma(fa[a][0], fb[b][2], acc[a][b]);
+                    acc[a][b] = mma(fa[a][1], fb[b][0], acc[a][b]);
+                    acc[a][b] = mma(fa[a][0], fb[b][1], acc[a][b]);
+                    acc[a][b] = mma(fa[a][0], fb[b][0], acc[a][b]);
                 }
         }
     };
     uint16_t* L0 = x6s;
-    fetch(ra0, rb0, 0);
+    fetch(ra0, rp0, rb0, 0);
     // dbg != nullptr (timing experiments): wave 0 of workgroup 0 stamps the phase boundaries of its tiles 8..13
     auto stamp = [&](int t, int k) {
-        if (dbg && blockIdx.x == 0 && tid == 0 && t >= 8 && t < 14) dbg[(t - 8) * 8 + k] = (long long)__builtin_readcyclecounter();
+        if (dbg && blockIdx.x == 0 && tid == 0 && t >= 8 && t < 14) {
+            dbg[(t - 8) * 8 + k] = (long long)__builtin_readcyclecounter();
+            if (k == 0) dbg[(t - 8) * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();     // 100 MHz: the shader clock follows from the two
+        }
     };
     for (int t = 0; t < ntile; ++t) {
         stamp(t, 0);
         __syncthreads();                       // previous tile's fragment reads are done
         stamp(t, 1);
-        swrite(ra0, rb0, L0);
+        swrite(ra0, rp0, rb0, L0);
         stamp(t, 2);
         __syncthreads();
         stamp(t, 3);
-        if (!(xd & 4)) fetch(ra0, rb0, t + 1);                // next tile in flight during the MFMA block (past the end: re-reads the last)
+        if constexpr (IL) {
+            constexpr int NL = (PA ? 3 * NAP : NA) + 3 * NQ;       // global loads per thread and k tile
+            static_assert(2 * NL <= 32, "two MFMAs per load inside the first half of the block");
+            stamp(t, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(ra0, rp0, rb0, t + 1);
+            mfma_block(L0);
+            // issue order inside this region: 12 fragment reads (kb = 0), then {2 MFMAs, 1 global load} x NL, the rest of
+            // kb = 0's 32 MFMAs, 12 fragment reads (kb = 1), 32 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * NL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(t, 5);
+            continue;
+        }
+        if (!(xd & 4)) fetch(ra0, rp0, rb0, t + 1);                // next tile in flight during the MFMA block (past the end: re-reads the last)
         // fences: without them the compiler hoists the split arithmetic of swrite() up to the loads and waits for
         // them BEFORE the MFMA block (the full memory latency exposed once per tile)
         __builtin_amdgcn_sched_barrier(0);
@@ -223,6 +288,17 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         __builtin_amdgcn_sched_barrier(0);
         stamp(t, 5);
     }
+    if constexpr (TR) {
+        // transposed accumulators: lane (i, h) owns row i and columns 8g + 4h + j of each 32-column block
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int row = m0 + (wm * 2 + a) * 32 + i, cb = n0 + (wn * 2 + b) * 32;
+                const bool valid = row < M && cb < N;
+                tr_block_epilogue(ef, acc[a][b], valid ? (long)row * ef.ld + cb : 0L, cb, h, valid);
+            }
+    } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // ReLU bit mask (ef.mask): one 32-bit word per (row, 32-column block) = one half of a wave ballot; the 64 words of a
     // wave's 32 rows x 2 column blocks are collected into lane (row_in_block*2 + b) and stored with ONE instruction
@@ -260,6 +336,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             if (row < M && col < N) ef.mask[ef.addr(row, col, 0) >> 5] = mword;
         }
     }
+    }
 }
 
 inline int& x6_prio() { static int p = 0; return p; }
@@ -269,23 +346,25 @@ inline bool gemm_x6_ok(const void* A, long lda, int K) {
 }
 inline size_t gemm_x6_plane_bytes(long N, long K) { return (size_t)3 * N * K * sizeof(uint16_t); }
 
-inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool transpose, uint16_t* out, hipStream_t stream) {
+inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool transpose, uint16_t* out, hipStream_t stream,
+                                      bool kperm = false) {
     const long total = (long)R * Cn;
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out, kperm ? 1 : 0);
     return hipGetLastError();
 }
 
-template <class AF, class EF, int WM, int WN, bool X8, int XD = 0>
+inline int& x6_il() { static int p = getenv("MRL_X6_IL") ? atoi(getenv("MRL_X6_IL")) : 1; return p; }          // mrl_set_option "x6_il": loads interleaved with the MFMAs (TR launches)
+template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, bool IL = false>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, long a_pstride = 0) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
 #ifdef MRL_X6_EXPERIMENTS
-    if (XD == 0 && x6_xd() != 0) {
+    if (XD == 0 && !PA && !TR && x6_xd() != 0) {
         switch (x6_xd()) {
         case 1: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 1>(af, Bp, ef, M, N, K, dbg, stream);
         case 2: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 2>(af, Bp, ef, M, N, K, dbg, stream);
@@ -301,15 +380,28 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         }
     }
 #endif
-    auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD>;
+    if constexpr (TR && !PA && !IL && XD == 0)
+        if (x6_il()) return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, true>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+    auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
     static bool raised = false;                // per instantiation
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio());
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride);
     return hipGetLastError();
+}
+// Pre-split operands (planes.hip.h).  PA: A is a plane tensor (af.p = plane 0, a_pstride elements between planes; Bp must
+// have been laid out with kperm).  TR: EF is a Tr* functor writing fp32 + planes (+ bit mask); needs N % 32 == 0.
+// Eight-product arithmetic only (the default mode).
+template <bool PA, bool TR, class AF, class EF>
+inline hipError_t launch_gemm_x6_planes(const AF& af, long a_pstride, const uint16_t* Bp, const EF& ef, int M, int N, int K,
+                                        hipStream_t stream, long long* dbg = nullptr) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (TR && N % 32 != 0) return hipErrorInvalidValue;
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
 }
 template <class AF, class EF>
 inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream,

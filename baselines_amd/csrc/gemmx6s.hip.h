@@ -356,7 +356,7 @@ inline hipError_t launch_dgrad_x6s(const float* dz, const float* w, const float*
     constexpr int BM = WM * 64, BN = WN * 64;
     using P = X6sDgrad<H, W, C, RF, S, NF, BM, BN>;
     hipLaunchKernelGGL((dgx6_split_planes_kernel<H, W, C, RF, S, NF>), dim3((G::N * G::K + 255) / 256), dim3(256), 0, stream,
-                       w, planes);
+                       w, planes, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int btiles = (B + BM - 1) / BM;

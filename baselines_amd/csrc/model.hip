@@ -234,6 +234,11 @@ struct NetWs {
     // by the forward pass of THIS call when the engine that ran layer l wrote them
     std::vector<uint32_t*> mbits;
     std::vector<char> mvalid;
+    // pre-split plane tensors (planes.hip.h) of the layer outputs h[l] and of the pre-activation gradients dz[l]: written by
+    // the epilogue of the producing engine, staged by the consumer without split arithmetic.  hp[l] / dzp[l] may be nullptr;
+    // hpvalid[l] / dzpvalid[l] are set by THIS call's producer (plane stride = rows * width of that call's batch)
+    std::vector<uint16_t*> hp, dzp;
+    std::vector<char> hpvalid, dzpvalid;
     float* lat() const { return hout ? hout : h.back(); }
     float* dlat() const { return dhout ? dhout : dz.back(); }
 };
@@ -284,6 +289,15 @@ static int get_option(const char* name, const char* env, int dflt) {
 // multiply (dropped part < 2^-21 of a product), 2 = eight products (dropped part < 2^-29: below one fp32 rounding).
 // Default 2: every product of the update is then at least as accurate as an IEEE fp32 multiply.
 static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 2); }
+// transposed-accumulator epilogues and pre-split activation planes (planes.hip.h), eight-product mode only.  Bits:
+//   4 / 8 / 64 (default 76): transposed epilogues (16-byte stores, in-lane ReLU mask words) of the conv forward layers / the
+//                            data gradients / the hidden fc layer's forward -- c2.fwd 6.3 -> 5.5 ms, c2.dgrad 6.2 -> 5.75 ms;
+//   16: the same for the first conv layer's image-resident kernel (slower: 3.0 -> 3.4 ms, its epilogue is issue-bound);
+//   1 / 2 / 32: EXPERIMENT, measured slower -- producers also write plane tensors of h / of dz / of the last layer's dz
+//               only, consumers stage them without split arithmetic (1.5x the operand bytes in 64-byte pieces, 2.5x the
+//               producers' write traffic: c2.fwd 6.3 -> 9.0 ms).  The plane buffers exist only if the bit is set when the
+//               workspace is sized.
+static int act_planes_mode() { return f32_split_mode() == 2 ? get_option("act_planes", "MRL_ACT_PLANES", 76) : 0; }
 // wave-specialised (producer / consumer) form of the tiled split engines (gemmx6s.hip.h): measured NOT faster than the plain
 // form (two waves of one SIMD share its VALU issue and its matrix pipe: profiles/README.md), kept as an experiment knob
 static int x6_specialised() { return get_option("x6_spec", "MRL_X6_SPEC", 0); }
@@ -291,8 +305,8 @@ static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 2};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}, {"act_planes", "MRL_ACT_PLANES"}, {"x6_il", "MRL_X6_IL"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 2, 76, 1};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -305,6 +319,7 @@ extern "C" int mrl_set_option(const char* name, int value) {
         if (!strcmp(kOptionEnv[i][0], name)) {
             option_table()[name] = value;
             if (!strcmp(name, "x6_prio")) x6_prio() = value;
+            if (!strcmp(name, "x6_il")) x6_il() = value;
             if (!strcmp(name, "x6_dbg")) x6_xd() = value >= 100 ? value - 100 : 0;
             return 0;
         }
@@ -360,7 +375,19 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     size_t part_floats = (size_t)HEAD_MAXBLK * m->HP;
     auto do_net = [&](const Net& net, NetWs& nw) {
         nw.h.clear(); nw.dz.clear(); nw.mbits.clear(); nw.mvalid.clear();
+        nw.hp.clear(); nw.dzp.clear(); nw.hpvalid.clear(); nw.dzpvalid.clear();
         for (const Layer& l : net.L) {
+            const size_t li = nw.h.size();
+            // planes of h[l]: a ReLU conv output feeding another layer of the split engines; planes of dz[l]: the A operand of
+            // layer l's data gradient (l >= 1)
+            // (only when the option asks for them at workspace-query time: an experiment knob, off by default -- measured
+            // slower than splitting inside the consumers, profiles/README.md)
+            const int pm = act_planes_mode();
+            const bool hpl = (pm & 1) && l.kind == 0 && l.act == ACT_RELU && l.NF % 32 == 0 && li + 1 < net.L.size();
+            const bool dzpl = (pm & (2 | 32)) && li >= 1 && l.act == ACT_RELU && l.out_elems % 32 == 0 && (l.kind == 0 ? l.NF % 32 == 0 : true);
+            nw.hp.push_back(hpl ? (uint16_t*)take((size_t)chunk * l.out_elems * 6) : nullptr);
+            nw.dzp.push_back(dzpl ? (uint16_t*)take((size_t)chunk * l.out_elems * 6) : nullptr);
+            nw.hpvalid.push_back(0); nw.dzpvalid.push_back(0);
             nw.h.push_back((float*)take((size_t)chunk * l.out_elems * 4));
             nw.dz.push_back((float*)take((size_t)chunk * l.out_elems * 4));
             const bool bits = l.kind == 0 && l.act == ACT_RELU && l.NF % 32 == 0;
@@ -1144,8 +1171,14 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
 static bool tuned(const Layer& l, const char* pass);
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
                          const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st,
-                         uint32_t* mbits = nullptr, char* mwrote = nullptr) {
+                         uint32_t* mbits = nullptr, char* mwrote = nullptr, const uint16_t* hprev_p = nullptr,
+                         uint16_t* hp_out = nullptr, char* hpwrote = nullptr) {
+    // hprev_p: plane tensor of hprev written by the layer below in THIS call (plane stride B * K elements for an fc layer,
+    // B * H*W*C for a conv layer); hp_out: where this layer may leave the plane tensor of its own output
     if (mwrote) *mwrote = 0;
+    if (hpwrote) *hpwrote = 0;
+    if (!(act_planes_mode() & 1)) { hprev_p = nullptr; hp_out = nullptr; }
+    const bool tr_plain = (act_planes_mode() & 4) != 0;        // transposed-accumulator epilogues without plane output
     if (!get_option("relu_bits", "MRL_RELU_BITS", 1)) mbits = nullptr;
     const float* W = params + l.w_off;
     const float* bias = params + l.b_off;
@@ -1173,8 +1206,11 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     if (l.H == C1_H && l.W == C1_W && l.C == C1_C && l.rf == C1_RF && l.stride == C1_S && l.NF == C1_NF &&
                         l.act == ACT_RELU && get_option("c1_lds", "MRL_C1_LDS", 2)) {
                         if (mbits) { if (mwrote) *mwrote = 1; }
-                        if (get_option("c1_lds", "MRL_C1_LDS", 2) >= 2)
-                            return (int)launch_c1fwd2(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st);
+                        if (get_option("c1_lds", "MRL_C1_LDS", 2) >= 2) {
+                            if (hp_out && hpwrote) *hpwrote = 1;
+                            return (int)launch_c1fwd2(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st, hp_out,
+                                                      (long)B * l.out_elems, (act_planes_mode() & 16) != 0);
+                        }
                         return (int)launch_c1fwd_lds(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st,
                                                      get_option("c1_dbg", "MRL_C1_DBG", 0));
                     }
@@ -1194,8 +1230,29 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                     ProfScope ps(label, fl, 0.0, st);
-                    hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st);
+                    const bool pa = hprev_p && x6 == 2 && l.C % 32 == 0 && !x6_specialised();
+                    const bool trp = hp_out && hpwrote;          // the epilogue also leaves the plane tensor
+                    const bool tr = (trp || tr_plain) && x6 == 2 && l.NF % 32 == 0 && l.act == ACT_RELU && !x6_specialised();
+                    hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st, pa);
                     if (e != hipSuccess) return (int)e;
+                    if (pa || tr) {
+                        // pre-split operands: A staged from the plane tensor of the layer below, and / or the epilogue leaves
+                        // the plane tensor of this layer's output for the layer above
+                        const long aps = (long)B * l.H * l.W * l.C;
+                        if (pa) ca.p = hprev_p;
+                        if (tr) {
+                            TrBiasRelu tf{hout, l.NF, bias, nullptr, trp ? hp_out : nullptr, (long)npix * l.NF};
+                            if (mbits) { tf.mask = mbits; if (mwrote) *mwrote = 1; }
+                            if (trp) *hpwrote = 1;
+                            // MRL_X6_DBG = 10 + layer index: phase stamps of that conv layer's forward land behind the zero page
+                            long long* dbgq = get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
+                            return (int)(pa ? launch_gemm_x6_planes<true, true>(ca, aps, planes, tf, npix, l.NF, l.K, st, dbgq)
+                                            : launch_gemm_x6_planes<false, true>(ca, 0, planes, tf, npix, l.NF, l.K, st, dbgq));
+                        }
+                        EpiBiasAct efp{hout, l.NF, bias, l.act};
+                        if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efp.mask = mbits; if (mwrote) *mwrote = 1; }
+                        return (int)launch_gemm_x6_planes<true, false>(ca, aps, planes, efp, npix, l.NF, l.K, st);
+                    }
                     EpiBiasAct efx{hout, l.NF, bias, l.act};
                     if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efx.mask = mbits; if (mwrote) *mwrote = 1; }
                     if (x6_specialised()) {
@@ -1203,7 +1260,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                         long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
                         return (int)launch_gemm_x6s(ca, planes, efx, npix, l.NF, l.K, num_cus(), x6 == 2, st, dbgp);
                     }
-                    return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st, nullptr, x6 == 2);
+                    return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st,
+                                               get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr, x6 == 2);
                 }
                 WresFwdA<false> wa;
                 fill_conv(wa, l, hprev, npix, nullptr);
@@ -1234,8 +1292,20 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
-                hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st);        // B[n][k] = W[k][n]
+                const bool pa = hprev_p && f32_split_mode() == 2 && l.K % 32 == 0 && !x6_specialised();
+                hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st, pa);        // B[n][k] = W[k][n]
                 if (e != hipSuccess) return (int)e;
+                const bool trf = (act_planes_mode() & 64) && f32_split_mode() == 2 && l.act == ACT_RELU && l.N % 32 == 0 && !x6_specialised();
+                if (pa && !trf)
+                    return (int)launch_gemm_x6_planes<true, false>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
+                                                                   (long)B * l.K, planes, ef, B, l.N, l.K, st);
+                if (trf) {      // transposed-accumulator epilogue (16-byte stores), no mask / planes needed above an fc layer
+                    TrBiasRelu tf{hout, l.N, bias, nullptr, nullptr, 0};
+                    long long* dbgq = get_option("x6_dbg", "MRL_X6_DBG", 0) == 1 ? dbgbuf : nullptr;
+                    return (int)(pa ? launch_gemm_x6_planes<true, true>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
+                                                                        (long)B * l.K, planes, tf, B, l.N, l.K, st, dbgq)
+                                    : launch_gemm_x6_planes<false, true>(X6DenseA{hprev, (long)l.K}, 0, planes, tf, B, l.N, l.K, st, dbgq));
+                }
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
                 long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) == 1 ? dbgbuf : nullptr;
                 if (x6_specialised())
@@ -1254,8 +1324,11 @@ static int net_forward(const mrl_model* m, const Net& net, const In& in, const f
     for (size_t i = 0; i < net.L.size(); ++i) {
         // bit masks only where a consumer exists: the layer above is a conv whose data gradient the tiled engine computes
         const bool hb = i < nw.mbits.size() && i + 1 < net.L.size() && net.L[i + 1].kind == 0;
+        const bool hpi = i < nw.hp.size();
+        const uint16_t* hprev_p = (i && i - 1 < nw.hp.size() && nw.hpvalid[i - 1]) ? nw.hp[i - 1] : nullptr;
         int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
-                               hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr);
+                               hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr, hprev_p, hpi ? nw.hp[i] : nullptr,
+                               hpi ? &nw.hpvalid[i] : nullptr);
         if (rc) return rc;
     }
     return 0;
@@ -1275,9 +1348,24 @@ static bool tuned(const Layer& l, const char* pass) {
 // backward through one net; nw.dz[last] already holds dloss/d(pre-activation of the last layer)
 static int net_backward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws,
                         float* grads, int B, int accumulate, hipStream_t st, StepCtx& ctx, bool is_pi) {
+    const bool dzplanes = (act_planes_mode() & (2 | 32)) != 0;     // 32: planes of the last layer's dz only (conversion pass)
+    for (auto& v : nw.dzpvalid) v = 0;
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
         const float* dz = nw.dz[i];
+        // plane tensor of dz[i] (the A operand of this layer's data gradient): written by the data gradient of the layer
+        // above, or -- for the last layer, whose dz comes from the heads kernel -- by a conversion pass
+        const bool x6dgrad = i > 0 && nw.planes && f32_split_mode() == 2 && !x6_specialised() && !tuned(l, "dgrad");
+        if (dzplanes && x6dgrad && i == (int)net.L.size() - 1 && (size_t)i < nw.dzp.size() && nw.dzp[i] && l.kind == 1 && B >= 1024 &&
+            l.K >= 128 && l.N % 32 == 0 && gemm_x6_ok(dz, l.N, l.N)) {
+            ProfScope ps("dz.planes", 0.0, 10.0 * B * l.N, st);
+            hipError_t e = launch_planes_from_f32(dz, (long)B * l.N, nw.dzp[i], (long)B * l.N, st);
+            if (e != hipSuccess) return (int)e;
+            nw.dzpvalid[i] = 1;
+        }
+        const uint16_t* dz_p = (dzplanes && x6dgrad && (size_t)i < nw.dzp.size() && nw.dzpvalid[i]) ? nw.dzp[i] : nullptr;
+        // where the data gradient may leave the plane tensor of dz[i-1]
+        uint16_t* dx_p = ((act_planes_mode() & 2) && x6dgrad && i >= 2 && (size_t)i - 1 < nw.dzp.size() && net.L[i - 1].act == ACT_RELU) ? nw.dzp[i - 1] : nullptr;
         const float* hmask = hprev_of(nw, i);                        // act' source of the layer below
         const float* hprev = i ? nw.h[i - 1] : nullptr;
         const long rows = layer_rows(l, B);
@@ -1408,8 +1496,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                         e = lk == 1 ? launch_dgrad_x6s<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st)
                                     : launch_dgrad_x6s<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st);
                     else
-                        e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg)
-                                    : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg);
+                    {
+                        const bool trpl = (act_planes_mode() & 8) != 0;
+                        e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg, dz_p, dx_p, trpl)
+                                    : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg, dz_p, dx_p, trpl);
+                        if (dx_p && x8 && !dbg) nw.dzpvalid[i - 1] = 1;
+                    }
                     rc = (int)e;
                 } else
                 if (lk && (dv == V_LDSDGRAD || !overridden)) {
@@ -1453,8 +1545,22 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
                 EpiMaskAct ef{nw.dz[i - 1], l.K, hmask, lp.act};
-                hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st);
-                if (e == hipSuccess)
+                const bool tr = (dx_p || ((act_planes_mode() & 8) && f32_split_mode() == 2 && !x6_specialised() && lp.act == ACT_RELU)) &&
+                                l.K % 32 == 0 && (uintptr_t)hmask % 16 == 0;
+                hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st, dz_p != nullptr);
+                if (e == hipSuccess && (dz_p || tr)) {
+                    // pre-split operands (planes.hip.h): dz staged from its plane tensor, dz[i-1] leaves with its planes
+                    const X6DenseA da{dz_p ? reinterpret_cast<const float*>(dz_p) : dz, (long)l.N};
+                    const long aps = (long)B * l.N;
+                    if (tr) {
+                        TrMaskRelu tf{nw.dz[i - 1], l.K, hmask, nullptr, dx_p, (long)B * l.K};
+                        e = dz_p ? launch_gemm_x6_planes<true, true>(da, aps, nw.planes, tf, B, l.K, l.N, st)
+                                 : launch_gemm_x6_planes<false, true>(da, 0, nw.planes, tf, B, l.K, l.N, st);
+                        if (e == hipSuccess && dx_p) nw.dzpvalid[i - 1] = 1;
+                    } else {
+                        e = launch_gemm_x6_planes<true, false>(da, aps, nw.planes, ef, B, l.K, l.N, st);
+                    }
+                } else if (e == hipSuccess)
                     e = x6_specialised()
                             ? launch_gemm_x6s(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, num_cus(), f32_split_mode() == 2, st)
                             : launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr, f32_split_mode() == 2);

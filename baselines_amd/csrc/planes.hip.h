@@ -1,0 +1,129 @@
+// Pre-split activation planes (gfx950): the A operand of the split-bf16 engines leaves its PRODUCER already split.
+//
+// The tiled split engines (gemmx6.hip.h, dgradx6.hip.h) multiply fp32 x fp32 as 8 exact bf16 products; splitting the
+// activation operand while it is staged costs ~176 of the ~210 VALU instructions of a k step, and every VALU instruction
+// is paid for in matrix-pipe issue time (profiles/README.md, "issue port").  The im2col overlap makes conv2 split every
+// element of its input 4 times, conv3 9 times, the fc1 pair once per column tile.  Here the kernel that PRODUCES an
+// activation (forward: h = relu(z), common/models.py:15-26; backward: dz = dh * relu'(h), the tf.gradients chain of
+// ppo2/model.py:102-103) splits each element once in its epilogue and writes a "plane tensor" next to the fp32 tensor;
+// the consumer's staging is then a plain 16-byte copy.  The split is the same truncation split (split2_bf16x3), so the
+// products, their order and therefore the results of a consumer are those of the in-loop split.
+//
+// Plane tensor of X[rows][C] (C % 32 == 0):  three bf16 arrays P[plane][rows][C]; inside each aligned block of 32
+// elements along C, element c sits at position perm32(c).  perm32 is what makes the producer cheap: with the MFMA
+// operands swapped (D^T = B A^T) a lane of the 32x32 accumulator owns ONE row and the 16 columns
+// {8g + 4h + j : g, j < 4} (h = lane >> 5) of a 32-column block, which perm32 maps to 16 CONSECUTIVE positions: the lane
+// stores 2 x 16 bytes per plane, no cross-lane traffic, and 4 x float4 for the fp32 tensor (instead of 16 dword stores).
+// The consumers' weight planes use the same order of k (split_planes_kernel / dgx6_split_planes_kernel, kperm), so
+// the position of an element inside its block never has to be undone: a dot product does not care in which order k runs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+#include "wres.hip.h"      // split2_bf16x3
+
+namespace mrl {
+
+__host__ __device__ __forceinline__ int perm32(int c) { return ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3); }
+__host__ __device__ __forceinline__ long kperm32(long k) { return (k & ~31L) | perm32((int)(k & 31)); }
+
+typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- epilogue functors of the transposed accumulator layout ---------------------------------------------------------
+// o = element offset of output (row, c) in the fp32 tensor (and in each plane), c = column, cin = column inside the block
+struct TrBiasRelu {          // h = relu(acc + bias[c])  (+ ReLU bit mask of h, + planes of h)
+    float* out; long ld; const float* bias; uint32_t* mask; uint16_t* hp; long pstride;
+    __device__ __forceinline__ uint32_t block_aux(long, bool) const { return 0; }
+    __device__ __forceinline__ float4 apply(long, int c, int, float4 a, uint32_t, bool valid) const {
+        const float* b = bias + (valid ? c : 0);
+        float4 v;
+        v.x = act_fwd(a.x + b[0], ACT_RELU); v.y = act_fwd(a.y + b[1], ACT_RELU);
+        v.z = act_fwd(a.z + b[2], ACT_RELU); v.w = act_fwd(a.w + b[3], ACT_RELU);
+        return v;
+    }
+};
+struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of the layer below, or its bit mask, or nothing
+    float* out; long ld; const float* h; const uint32_t* hbits; uint16_t* hp; long pstride;
+    static constexpr uint32_t* mask = nullptr;
+    __device__ __forceinline__ uint32_t block_aux(long o, bool valid) const { return (hbits && valid) ? hbits[o >> 5] : 0u; }
+    __device__ __forceinline__ float4 apply(long o, int, int cin, float4 a, uint32_t aux, bool valid) const {
+        if (hbits) {
+            a.x *= ((aux >> cin) & 1u) ? 1.f : 0.f; a.y *= ((aux >> (cin + 1)) & 1u) ? 1.f : 0.f;
+            a.z *= ((aux >> (cin + 2)) & 1u) ? 1.f : 0.f; a.w *= ((aux >> (cin + 3)) & 1u) ? 1.f : 0.f;
+        } else if (h) {
+            const float4 hv = valid ? *reinterpret_cast<const float4*>(h + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a.x *= act_bwd_from_out(hv.x, ACT_RELU); a.y *= act_bwd_from_out(hv.y, ACT_RELU);
+            a.z *= act_bwd_from_out(hv.z, ACT_RELU); a.w *= act_bwd_from_out(hv.w, ACT_RELU);
+        }
+        return a;
+    }
+};
+
+// One 32 x 32 accumulator in the transposed layout: lane (i, h) owns row i and the columns 8g + 4h + j = acc[4g + j] of
+// the 32-column block whose first element has offset o (a multiple of 32) in the output tensor.  Writes the fp32 values
+// (ef.out), the plane tensor (ef.hp) and the ReLU bit mask (ef.mask: one word per block, bit = column).  All 64 lanes
+// must call it (the two halves of a block exchange their mask bits); `valid` gates the memory accesses.
+template <class EF>
+__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, long o, int cb, int h, bool valid) {
+    const uint32_t aux = ef.block_aux(o, valid);
+    uint32_t bits = 0;
+    uint32_t pk[3][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cin = 8 * g + 4 * h;
+        const float4 v = ef.apply(o + cin, cb + cin, cin, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]), aux, valid);
+        if (ef.mask)
+            bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << cin;
+        if (ef.out && valid) *reinterpret_cast<float4*>(ef.out + o + cin) = v;
+        if (ef.hp) {
+            split2_bf16x3(v.x, v.y, pk[0][2 * g], pk[1][2 * g], pk[2][2 * g]);
+            split2_bf16x3(v.z, v.w, pk[0][2 * g + 1], pk[1][2 * g + 1], pk[2][2 * g + 1]);
+        }
+    }
+    if (ef.hp && valid) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            uint16_t* d = ef.hp + pl * ef.pstride + o + 16 * h;
+            *reinterpret_cast<pl_u32x4*>(d) = pl_u32x4{pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]};
+            *reinterpret_cast<pl_u32x4*>(d + 8) = pl_u32x4{pk[pl][4], pk[pl][5], pk[pl][6], pk[pl][7]};
+        }
+    }
+    if (ef.mask) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)bits, 32);
+        if (valid && h == 0) ef.mask[o >> 5] = bits | other;
+    }
+}
+
+// fp32 tensor -> plane tensor as a separate pass (small tensors whose producer is not one of the MFMA engines: the
+// pre-activation gradient of the last hidden layer, written by the heads kernel).  n % 8 == 0, src 16-byte aligned.
+__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ src, long n, uint16_t* __restrict__ hp, long pstride) {
+    // a thread converts one half block: 16 consecutive POSITIONS p0 .. p0+15 of a block = columns 8g + 4hh + j
+    const long nhalf = n / 16;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < nhalf; e += (long)gridDim.x * 256L) {
+        const long blk = e >> 1;
+        const int hh = (int)(e & 1);
+        uint32_t pk[3][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(src + blk * 32 + 8 * g + 4 * hh);
+            split2_bf16x3(v.x, v.y, pk[0][2 * g], pk[1][2 * g], pk[2][2 * g]);
+            split2_bf16x3(v.z, v.w, pk[0][2 * g + 1], pk[1][2 * g + 1], pk[2][2 * g + 1]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            uint16_t* d = hp + pl * pstride + blk * 32 + 16 * hh;
+            *reinterpret_cast<pl_u32x4*>(d) = pl_u32x4{pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]};
+            *reinterpret_cast<pl_u32x4*>(d + 8) = pl_u32x4{pk[pl][4], pk[pl][5], pk[pl][6], pk[pl][7]};
+        }
+    }
+}
+inline hipError_t launch_planes_from_f32(const float* src, long n, uint16_t* hp, long pstride, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const long nhalf = n / 16;
+    const int blocks = (int)std::min<long>((nhalf + 255) / 256, 8192);
+    hipLaunchKernelGGL(planes_from_f32_kernel, dim3(blocks), dim3(256), 0, stream, src, n, hp, pstride);
+    return hipGetLastError();
+}
+
+}  // namespace mrl
