@@ -240,12 +240,15 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         update()                                   # the first update after the eager warm-up captures; keep that out too
     if want_prof and not graph_mode:
         _lib.prof_enable(True)
+    sampler = DeviceStateSampler().start() if (rank == 0 and os.environ.get('MRL_BENCH_SMI', '1') != '0') else None
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         lossvals = update()
     sync()
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    device_state = sampler.stop(t0, t1) if sampler else None
     prof = {}
     prof_steps = steps
     if want_prof:
@@ -266,10 +269,49 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     res = dict(value=total_envs * T * steps / dt, dt=dt, t_rollout=t_rollout, loss=[float(x) for x in lossvals], prof=prof,
                prof_steps=prof_steps, hp=hp, N=N, nbatch_train=nbatch_train, chunk=model.dm.chunk, graph_mode=graph_mode,
                model_tflops=flops_per_sample_visit * total_envs * T * hp['noptepochs'] * steps / dt / 1e12,
-               native_dp=bool(getattr(model, 'native_dp', False)))
+               native_dp=bool(getattr(model, 'native_dp', False)), device_state=device_state)
     del runner, model, env, ro
     torch.cuda.empty_cache()
     return res
+
+
+class DeviceStateSampler:
+    """rocm-smi samples (shader clock, socket power) taken on a host thread while the timed region runs.  The update is
+    power-limited on MI355X (~1.3 kW, sclk well below the 2.4 GHz the nominal matrix-pipe peaks are quoted at), so the
+    roofline fractions against nominal peaks understate what the kernels reach at the clock they are given."""
+
+    def __init__(self, period=0.4):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True, text=True, timeout=5).stdout
+                sclk = re.search(r'sclk clock level:\s*\d+:\s*\((\d+)Mhz\)', out)
+                pw = re.search(r'Power \(W\):\s*([0-9.]+)', out)
+                if sclk and pw:
+                    self.samples.append((time.perf_counter(), int(sclk.group(1)), float(pw.group(1))))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._th.start()
+        return self
+
+    def stop(self, t0, t1):
+        self._stop.set()
+        self._th.join(timeout=6)
+        inside = sorted((c, p) for (t, c, p) in self.samples if t0 <= t <= t1)
+        if not inside:
+            return None
+        clk = sorted(c for c, _ in inside)
+        pw = sorted(p for _, p in inside)
+        return {'sclk_mhz_median': clk[len(clk) // 2], 'socket_power_w_median': pw[len(pw) // 2], 'samples': len(inside),
+                'source': 'rocm-smi --showclocks --showpower on a host thread during the timed region'}
 
 
 def dominant_roofline(res, sites, workload):
@@ -387,6 +429,10 @@ def main():
     if rank == 0:
         hp = res['hp']
         roof, per = dominant_roofline(res, sites, args.workload)
+        ds = res.get('device_state')
+        if roof and ds and roof.get('bound') == 'mfma' and ds.get('sclk_mhz_median'):
+            # informational: `peak` and `frac` stay the nominal 2.4 GHz figures of MI355X_MICROARCH.md
+            roof['frac_at_sampled_sclk'] = roof['frac'] * 2400.0 / ds['sclk_mhz_median']
         out = {
             'metric': 'env-steps/sec (whole node) PPO2 update, num_envs=%d nsteps=%d' % (total_envs, T),
             'value': res['value'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -399,6 +445,8 @@ def main():
                        'parallelism': 'dp%d (envs sharded, 1 all-reduce of the flat gradient per minibatch step)' % world,
                        'world_size_observed': observed_world, 'collective': collective},
             'model_tflops': res['model_tflops'],
+            # power-limited: the sampled shader clock sits well below the 2.4 GHz the nominal peaks are quoted at
+            'device_state': res.get('device_state'),
             'full_iteration_env_steps_per_s': total_envs * T / (res['t_rollout'] + res['dt'] / args.steps),
             'rollout_s': res['t_rollout'],
             'loss': res['loss'],
@@ -422,7 +470,9 @@ def main():
                 others.append({'workload': 'ppo2 update-only %s-shaped %s num_envs=%d nsteps=128'
                                            % (wl, r['hp']['network'], n_envs),
                                'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['dt'] / 3 * 1e3, 'steps': 3,
-                               'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / 3),
+                               # power-limited: the sampled shader clock sits well below the 2.4 GHz the nominal peaks are quoted at
+            'device_state': res.get('device_state'),
+            'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / 3),
                                'roofline': rf,
                                'kernel_ms_per_step': {k: round(v['ms'] / r['prof_steps'], 3) for k, v in
                                                       sorted(r['prof'].items(), key=lambda kv: -kv[1]['ms'])}})

@@ -12,11 +12,11 @@ import sys
 LABELS = {
     'c2.dgrad': 'dgrad_x6_kernel<20, 20, 32',
     'c3.dgrad': 'dgrad_x6_kernel<9, 9, 64',
-    'c1.wgrad': 'c1wgrad_kernel',
+    'c1.wgrad': 'c1wgrad_half_kernel',
     'c2.wgrad': 'imgres_wgrad_kernel<false, 20, 20, 32',
     'c3.wgrad': 'imgres_wgrad_kernel<false, 9, 9, 64',
     'fc1.wgrad': 'wgrad_x8_kernel<mrl::X6DenseA',
-    'fc1.dgrad': 'gemm_x6_kernel<mrl::X6DenseA, mrl::EpiMaskAct',
+    'fc1.dgrad': 'gemm_x6_kernel<mrl::X6DenseA, mrl::TrMaskRelu',      # transposed-accumulator epilogue (planes.hip.h)
 }
 
 
@@ -24,9 +24,9 @@ LABELS = {
 # (".top8" lines of scripts/rocpd_pmc.py, launch order); (kernel substring, which of the alternating layers, of how many)
 TOP = {
     'c1.fwd': ('c1fwd2_kernel', 0, 1),
-    'c2.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::EpiBiasAct', 0, 2),
-    'c3.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::EpiBiasAct', 1, 2),
-    'fc1.fwd': ('gemm_x6_kernel<mrl::X6DenseA, mrl::EpiBiasAct', 0, 1),
+    'c2.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::TrBiasRelu', 0, 2),
+    'c3.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::TrBiasRelu', 1, 2),
+    'fc1.fwd': ('gemm_x6_kernel<mrl::X6DenseA, mrl::TrBiasRelu', 0, 1),
 }
 
 
