@@ -162,8 +162,7 @@ typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
 
 struct C1TrRelu {            // h = relu(acc) (bias folded into the accumulator), fp32 + bit mask + planes
     float* out; uint32_t* mask; uint16_t* hp; long pstride;
-    __device__ __forceinline__ uint32_t block_aux(long, bool) const { return 0; }
-    __device__ __forceinline__ float4 apply(long, int, int, float4 a, uint32_t, bool) const {
+    __device__ __forceinline__ float4 apply(const TrAux&, int, int, float4 a) const {
         return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
     }
 };
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
                     if (u == 1 && !two) break;
                     const int pix = (t0 + u) * 32 + i;
                     const bool valid = pix < C1_PIX;
-                    tr_block_epilogue(ef, acc[u], valid ? (pix0 + pix) * C1_NF : 0L, 0, h, valid);
+                    tr_block_epilogue(ef, acc[u], TrAux{}, valid ? (pix0 + pix) * C1_NF : 0L, h, valid);
                 }
             } else {
 #pragma unroll

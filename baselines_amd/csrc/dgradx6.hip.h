@@ -271,6 +271,9 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     if constexpr (TR) {
         // transposed accumulators: lane (i, h) owns image b0 + .. + i and channels 8g + 4h + j of one destination pixel
         const TrMaskRelu ef{dx, 0, hmask, mbits, dxp, dx_ps};
+        TrAux aux[2][2];
+        long oo[2][2];
+        bool vv[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -280,10 +283,14 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
                 const int py = cls / S, px = cls - py * S;
                 const int iy = yy * S + py, ix = xx * S + px;
                 const int bimg = b0 + (wm * 2 + a) * 32 + i;
-                const bool valid = cb < G::N && iy < H && ix < W && bimg < B;
-                const long o = valid ? (long)bimg * (H * W * C) + ((long)iy * W + ix) * C + c0 : 0L;
-                tr_block_epilogue(ef, acc[a][b], o, c0, h, valid);
+                vv[a][b] = cb < G::N && iy < H && ix < W && bimg < B;
+                oo[a][b] = vv[a][b] ? (long)bimg * (H * W * C) + ((long)iy * W + ix) * C + c0 : 0L;
+                aux[a][b] = ef.load_aux(oo[a][b], c0, h, vv[a][b]);
             }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b]);
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll

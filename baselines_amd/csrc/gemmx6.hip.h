@@ -111,6 +111,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = mt_i * BM, n0 = nt_i * BN;
 
+    // tile-level stamps (workgroup 0): dbg[48] entry, [49] in front of the k loop, [50] behind it, [51] end of the epilogue
+    auto tstamp = [&](int k) {
+        if (dbg && blockIdx.x == 0 && tid == 0) dbg[48 + k] = (long long)__builtin_readcyclecounter();
+    };
+    tstamp(0);
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             if (k == 0) dbg[(t - 8) * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();     // 100 MHz: the shader clock follows from the two
         }
     };
+    tstamp(1);
     for (int t = 0; t < ntile; ++t) {
         stamp(t, 0);
         __syncthreads();                       // previous tile's fragment reads are done
@@ -288,15 +294,25 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         __builtin_amdgcn_sched_barrier(0);
         stamp(t, 5);
     }
+    tstamp(2);
     if constexpr (TR) {
         // transposed accumulators: lane (i, h) owns row i and columns 8g + 4h + j of each 32-column block
+        TrAux aux[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int row = m0 + (wm * 2 + a) * 32 + i, cb = n0 + (wn * 2 + b) * 32;
                 const bool valid = row < M && cb < N;
-                tr_block_epilogue(ef, acc[a][b], valid ? (long)row * ef.ld + cb : 0L, cb, h, valid);
+                aux[a][b] = ef.load_aux(valid ? (long)row * ef.ld + cb : 0L, cb, h, valid);
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int row = m0 + (wm * 2 + a) * 32 + i, cb = n0 + (wn * 2 + b) * 32;
+                const bool valid = row < M && cb < N;
+                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? (long)row * ef.ld + cb : 0L, h, valid);
             }
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -337,6 +353,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         }
     }
     }
+    tstamp(3);
 }
 
 inline int& x6_prio() { static int p = 0; return p; }

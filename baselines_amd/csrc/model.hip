@@ -1232,7 +1232,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     ProfScope ps(label, fl, 0.0, st);
                     const bool pa = hprev_p && x6 == 2 && l.C % 32 == 0 && !x6_specialised();
                     const bool trp = hp_out && hpwrote;          // the epilogue also leaves the plane tensor
-                    const bool tr = (trp || tr_plain) && x6 == 2 && l.NF % 32 == 0 && l.act == ACT_RELU && !x6_specialised();
+                    const bool tr = (trp || tr_plain) && x6 == 2 && l.NF % 32 == 0 && l.act == ACT_RELU && !x6_specialised() &&
+                                    (uintptr_t)bias % 16 == 0;
                     hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st, pa);
                     if (e != hipSuccess) return (int)e;
                     if (pa || tr) {
@@ -1295,7 +1296,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 const bool pa = hprev_p && f32_split_mode() == 2 && l.K % 32 == 0 && !x6_specialised();
                 hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st, pa);        // B[n][k] = W[k][n]
                 if (e != hipSuccess) return (int)e;
-                const bool trf = (act_planes_mode() & 64) && f32_split_mode() == 2 && l.act == ACT_RELU && l.N % 32 == 0 && !x6_specialised();
+                const bool trf = (act_planes_mode() & 64) && f32_split_mode() == 2 && l.act == ACT_RELU && l.N % 32 == 0 && !x6_specialised() &&
+                                 (uintptr_t)bias % 16 == 0;
                 if (pa && !trf)
                     return (int)launch_gemm_x6_planes<true, false>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
                                                                    (long)B * l.K, planes, ef, B, l.N, l.K, st);

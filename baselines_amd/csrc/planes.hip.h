@@ -31,30 +31,49 @@ __host__ __device__ __forceinline__ long kperm32(long k) { return (k & ~31L) | p
 typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- epilogue functors of the transposed accumulator layout ---------------------------------------------------------
-// o = element offset of output (row, c) in the fp32 tensor (and in each plane), c = column, cin = column inside the block
-struct TrBiasRelu {          // h = relu(acc + bias[c])  (+ ReLU bit mask of h, + planes of h)
+// o = element offset of the block's first output in the fp32 tensor (a multiple of 32; the same offset in each plane),
+// cb = its first column, h = lane >> 5.  A kernel's epilogue runs in two passes over its accumulators: first the
+// auxiliary loads of ALL of them (load_aux: bias / activation of the layer below / its mask word -- one memory round trip
+// for the whole epilogue instead of one per accumulator), then arithmetic and stores (tr_block_epilogue).
+struct TrAux { float4 v[4]; uint32_t w; };
+
+struct TrBiasRelu {          // h = relu(acc + bias[c])  (+ ReLU bit mask of h, + planes of h); bias 16-byte aligned
     float* out; long ld; const float* bias; uint32_t* mask; uint16_t* hp; long pstride;
-    __device__ __forceinline__ uint32_t block_aux(long, bool) const { return 0; }
-    __device__ __forceinline__ float4 apply(long, int c, int, float4 a, uint32_t, bool valid) const {
-        const float* b = bias + (valid ? c : 0);
+    __device__ __forceinline__ TrAux load_aux(long, int cb, int h, bool valid) const {
+        TrAux x;
+        x.w = 0;
+        const float* b = bias + (valid ? cb + 4 * h : 4 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x.v[g] = *reinterpret_cast<const float4*>(b + 8 * g);
+        return x;
+    }
+    __device__ __forceinline__ float4 apply(const TrAux& x, int g, int, float4 a) const {
         float4 v;
-        v.x = act_fwd(a.x + b[0], ACT_RELU); v.y = act_fwd(a.y + b[1], ACT_RELU);
-        v.z = act_fwd(a.z + b[2], ACT_RELU); v.w = act_fwd(a.w + b[3], ACT_RELU);
+        v.x = act_fwd(a.x + x.v[g].x, ACT_RELU); v.y = act_fwd(a.y + x.v[g].y, ACT_RELU);
+        v.z = act_fwd(a.z + x.v[g].z, ACT_RELU); v.w = act_fwd(a.w + x.v[g].w, ACT_RELU);
         return v;
     }
 };
 struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of the layer below, or its bit mask, or nothing
     float* out; long ld; const float* h; const uint32_t* hbits; uint16_t* hp; long pstride;
     static constexpr uint32_t* mask = nullptr;
-    __device__ __forceinline__ uint32_t block_aux(long o, bool valid) const { return (hbits && valid) ? hbits[o >> 5] : 0u; }
-    __device__ __forceinline__ float4 apply(long o, int, int cin, float4 a, uint32_t aux, bool valid) const {
+    __device__ __forceinline__ TrAux load_aux(long o, int, int hh, bool valid) const {
+        TrAux x;
+        x.w = (hbits && valid) ? hbits[o >> 5] : 0u;
+        if (!hbits && h) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                x.v[g] = valid ? *reinterpret_cast<const float4*>(h + o + 8 * g + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return x;
+    }
+    __device__ __forceinline__ float4 apply(const TrAux& x, int g, int cin, float4 a) const {
         if (hbits) {
-            a.x *= ((aux >> cin) & 1u) ? 1.f : 0.f; a.y *= ((aux >> (cin + 1)) & 1u) ? 1.f : 0.f;
-            a.z *= ((aux >> (cin + 2)) & 1u) ? 1.f : 0.f; a.w *= ((aux >> (cin + 3)) & 1u) ? 1.f : 0.f;
+            a.x *= ((x.w >> cin) & 1u) ? 1.f : 0.f; a.y *= ((x.w >> (cin + 1)) & 1u) ? 1.f : 0.f;
+            a.z *= ((x.w >> (cin + 2)) & 1u) ? 1.f : 0.f; a.w *= ((x.w >> (cin + 3)) & 1u) ? 1.f : 0.f;
         } else if (h) {
-            const float4 hv = valid ? *reinterpret_cast<const float4*>(h + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            a.x *= act_bwd_from_out(hv.x, ACT_RELU); a.y *= act_bwd_from_out(hv.y, ACT_RELU);
-            a.z *= act_bwd_from_out(hv.z, ACT_RELU); a.w *= act_bwd_from_out(hv.w, ACT_RELU);
+            a.x *= act_bwd_from_out(x.v[g].x, ACT_RELU); a.y *= act_bwd_from_out(x.v[g].y, ACT_RELU);
+            a.z *= act_bwd_from_out(x.v[g].z, ACT_RELU); a.w *= act_bwd_from_out(x.v[g].w, ACT_RELU);
         }
         return a;
     }
@@ -65,14 +84,13 @@ struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of th
 // (ef.out), the plane tensor (ef.hp) and the ReLU bit mask (ef.mask: one word per block, bit = column).  All 64 lanes
 // must call it (the two halves of a block exchange their mask bits); `valid` gates the memory accesses.
 template <class EF>
-__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, long o, int cb, int h, bool valid) {
-    const uint32_t aux = ef.block_aux(o, valid);
+__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, const TrAux& aux, long o, int h, bool valid) {
     uint32_t bits = 0;
     uint32_t pk[3][8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int cin = 8 * g + 4 * h;
-        const float4 v = ef.apply(o + cin, cb + cin, cin, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]), aux, valid);
+        const float4 v = ef.apply(aux, g, cin, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
         if (ef.mask)
             bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << cin;
         if (ef.out && valid) *reinterpret_cast<float4*>(ef.out + o + cin) = v;

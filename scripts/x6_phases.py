@@ -22,7 +22,10 @@ noise = torch.rand((B, 6), device='cuda')
 for _ in range(2):
     dm.act(params, obs, noise)
 torch.cuda.synchronize()
-st = dm.workspace[-2048 + 512:-2048 + 512 + 6 * 8 * 8].view(torch.int64).cpu().numpy().reshape(6, 8)
+raw = dm.workspace[-2048 + 512:-2048 + 512 + 7 * 8 * 8].view(torch.int64).cpu().numpy()
+st = raw[:48].reshape(6, 8)
+ts = raw[48:52]
+print('tile of workgroup 0: prologue %d  k loop %d  epilogue %d cycles' % (ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]))
 names = ['barrier1', 'swrite', 'barrier2', 'fetch', 'mfma']
 rt = (st[5, 6] - st[0, 6]) * 10e-9         # s_memrealtime ticks (100 MHz) between the first stamps of k tiles 8 and 13
 print('shader clock over k tiles 8..13: %.0f MHz' % ((st[5, 0] - st[0, 0]) / rt / 1e6))
