@@ -369,6 +369,15 @@ int mrl_tune_set(const char* label, int variant);
  *   "c1_lds"     [MRL_C1_LDS, 2]  first conv layer forward on the image-resident engines (whole images staged once in LDS,
  *                  double-buffered): 2 = pixels converted to bf16 while staged, two tiles per wave; 1 = uint8 images,
  *                  converted per fragment; 0 = weights-resident gather engine.  Same products, same sums.
+ *   "act_planes" [MRL_ACT_PLANES, 76]  bit set for the eight-product split engines (planes.hip.h).  4 / 8 / 64: transposed-
+ *                  accumulator epilogues (16-byte stores, in-lane ReLU mask words) of the hidden conv layers' forward / the
+ *                  data gradients / the hidden fc layer's forward; 16: the same in the first conv layer's kernel (slower);
+ *                  1 / 2 / 32: experiment -- producers also write pre-split bf16 plane tensors of the activations / of the
+ *                  pre-activation gradients / of the last layer's gradient only, which the consumers stage without split
+ *                  arithmetic (measured slower; the plane buffers are part of the workspace only if the bit is set when
+ *                  mrl_model_workspace_bytes is called).  Same products in every mode.
+ *   "x6_il"      [MRL_X6_IL, 1]  the split engines issue the next k tile's global loads between the MFMAs of the current one
+ *                  (transposed-epilogue launches); 0 = in a phase of their own
  *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
  *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg", "dgx6_dbg", "c1_dbg", "x6_spec", "x6_prio": experiment knobs
