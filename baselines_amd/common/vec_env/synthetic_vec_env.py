@@ -7,6 +7,8 @@ spaces (BASELINE.json configs).
                       like any gym env): feeds the oracle the same rollouts and exercises the
                       host-env path of the Runner.
 """
+import time
+
 import numpy as np
 
 from .vec_env import VecEnv
@@ -37,6 +39,7 @@ def _u32(x):
 
 class _SynthBase(VecEnv):
     def __init__(self, kind, num_envs, seed=0, ob_shape=None, nact=None, lmin=None, lspan=None):
+        self.tstart = time.time()
         shape, dtype, acf, self.reward_kind, lm, ls = KINDS[kind]
         if ob_shape is not None:
             shape = tuple(ob_shape)
@@ -118,7 +121,7 @@ class SyntheticVecEnvCPU(_SynthBase):
         done = length >= L
         infos = [{} for _ in range(N)]
         for e in np.nonzero(done)[0]:
-            infos[e] = {'episode': {'r': float(ret[e]), 'l': int(length[e])}}
+            infos[e] = {'episode': {'r': float(ret[e]), 'l': int(length[e]), 't': round(time.time() - self.tstart, 6)}}
         self.ep = np.where(done, self.ep + np.uint32(1), self.ep).astype(np.uint32)
         self.st = np.where(done, 0, length).astype(np.int32)
         self.ep_ret = np.where(done, np.float32(0), ret).astype(np.float32)

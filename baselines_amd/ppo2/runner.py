@@ -15,6 +15,7 @@ when the caller wants them (`return_host=True`, default for host environments); 
 `arr[mbinds]` but gather on the device.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -78,6 +79,7 @@ class RolloutField(object):
 
 class Runner(AbstractEnvRunner):
     def __init__(self, *, env, model, nsteps, gamma, lam, return_host=None):
+        self._tstart = time.time()
         super().__init__(env=env, model=model, nsteps=nsteps)
         self.lam = lam
         self.gamma = gamma
@@ -191,14 +193,17 @@ class Runner(AbstractEnvRunner):
         last_values, fr, fl = self._rollout_steps(ro)
         return last_values, self._epinfos(fr, fl)
 
-    @staticmethod
-    def _epinfos(fr, fl):
+    def _epinfos(self, fr, fl):
+        """episode records of a device rollout in the shape of bench/monitor.py:58-77 ({'r', 'l', 't'}).  The device env
+        reports finished episodes as arrays and the host looks at them once per rollout, so 't' (seconds since the
+        runner was built) is the time the rollout ended, not the step the episode ended in."""
         mask = fl > 0
         if not bool(mask.any()):                       # one host sync per rollout, not per step
             return []
         rs = fr[mask].cpu().numpy()
         ls = fl[mask].cpu().numpy()
-        return [{'r': float(r), 'l': int(l)} for r, l in zip(rs, ls)]
+        t = round(time.time() - self._tstart, 6)
+        return [{'r': float(r), 'l': int(l), 't': t} for r, l in zip(rs, ls)]
 
     def _run_host_env(self, ro):
         T = self.nsteps

@@ -105,6 +105,8 @@ def test_runner_device_vs_host_env_vs_oracle(kind, N, T):
         np.testing.assert_array_equal(a, b)
     assert outs[0][6] is None
     assert sorted((e['l'], e['r']) for e in outs[0][7]) == sorted((e['l'], e['r']) for e in outs[1][7])
+    # the episode records have the keys of bench/monitor.py:58-77 on both paths
+    assert all(set(e) == {'r', 'l', 't'} and e['t'] >= 0 for o in outs for e in o[7])
     obs, returns, masks, actions, values, neglogpacs = outs[0][:6]
     assert returns.dtype == np.float32 and masks.dtype == np.bool_ and values.dtype == np.float32
     assert actions.dtype == (np.int64 if model.pd_kind == 'categorical' else np.float32)
