@@ -374,6 +374,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
         __syncthreads();
         row_next = image_row(u + 2 * gridDim.x);
         if (DBG & 1) continue;
+        __builtin_amdgcn_s_setprio(1);                     // the MFMA phase outranks the co-resident workgroup's staging pass
         __builtin_amdgcn_sched_barrier(0);
         uint32_t raw[2][NA][6];
         u32x4v bfr[2][3];
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- partial slab of this workgroup: [K][NF] weights / 255, then [NF] bias

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             constexpr int NL = (PA ? 3 * NAP : NA) + 3 * NQ;
             static_assert(2 * NL <= 32, "two MFMAs per load inside the first half of the block");
             const int tf = tn < G::NKT ? tn : t;
+            __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             fetch(ra0, rp0, rb0, tf);
             mfma_block(L0);
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
             t = tn;
             continue;
         }

@@ -85,7 +85,7 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 // IL: the global loads of the next k tile are issued BETWEEN the MFMAs of this one (sched_group_barrier pattern) instead of
 //     in a phase of their own in front of the MFMA block (phase stamps: issuing 10-11 16-byte loads costs a wave 700-1400
 //     cycles during which it feeds nothing to the matrix pipe).
-template <class AF, class EF, int WM, int WN, bool X8, int xd = 0, bool PA = false, bool TR = false, bool IL = false>
+template <class AF, class EF, int WM, int WN, bool X8, int xd = 0, bool PA = false, bool TR = false, int IL = 0>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
                                                       int mtiles, int ntiles, long long* dbg, int prio, long a_pstride) {
     // xd (timing experiments, builds with -DMRL_X6_EXPERIMENTS, option x6_dbg = 100 + bits): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global loads in the
@@ -265,21 +265,24 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             constexpr int NL = (PA ? 3 * NAP : NA) + 3 * NQ;       // global loads per thread and k tile
             static_assert(2 * NL <= 32, "two MFMAs per load inside the first half of the block");
             stamp(t, 4);
+            __builtin_amdgcn_s_setprio(1);                        // this wave's MFMA block outranks the co-resident workgroup's staging (-3 %)
             __builtin_amdgcn_sched_barrier(0);
             fetch(ra0, rp0, rb0, t + 1);
             mfma_block(L0);
             // issue order inside this region: 12 fragment reads (kb = 0), then {2 MFMAs, 1 global load} x NL, the rest of
             // kb = 0's 32 MFMAs, 12 fragment reads (kb = 1), 32 MFMAs
+            constexpr int MPL = 2;                                // MFMAs per load (1: c2.fwd 5.03 -> 5.14 ms)
             __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
             for (int q = 0; q < NL; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * NL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 32 - MPL * NL, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
             stamp(t, 5);
             continue;
         }
@@ -372,7 +375,7 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
 }
 
 inline int& x6_il() { static int p = getenv("MRL_X6_IL") ? atoi(getenv("MRL_X6_IL")) : 1; return p; }          // mrl_set_option "x6_il": loads interleaved with the MFMAs (TR launches)
-template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, bool IL = false>
+template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, int IL = 0>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
                                      hipStream_t stream, long a_pstride = 0) {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -397,8 +400,9 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         }
     }
 #endif
-    if constexpr (TR && !PA && !IL && XD == 0)
-        if (x6_il()) return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, true>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+    if constexpr (TR && !PA && !IL && XD == 0) {
+        if (x6_il()) return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, 1>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+    }
     auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
     static bool raised = false;                // per instantiation
     if (!raised) {

@@ -180,9 +180,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x8_kernel(AF af, const float* __r
         swrite();
         __syncthreads();
         fetch(t + 1);
+        __builtin_amdgcn_s_setprio(1);         // the MFMA block outranks the co-resident workgroup's staging pass
         __builtin_amdgcn_sched_barrier(0);     // as in gemm_x6_kernel: keep the split arithmetic behind the MFMA block
         mfma_block();
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
     }
     // ---- partial slab: dW tile (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     float* ps = part + (long)s * slab;
