@@ -278,8 +278,15 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 32 - MPL * NL, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            if constexpr (IL == 2) {       // kb = 1's fragment reads 8 MFMAs before the end of kb = 0 (+24 VGPRs)
+                static_assert(MPL * NL <= 24, "room for the early fragment reads");
+                __builtin_amdgcn_sched_group_barrier(0x008, 24 - MPL * NL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 32 - MPL * NL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(0);
@@ -401,7 +408,10 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
     }
 #endif
     if constexpr (TR && !PA && !IL && XD == 0) {
-        if (x6_il()) return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, 1>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+        // 128 x 128 tiles also read the second k half's fragments 8 MFMAs early (IL = 2: fc1.fwd 2.48 -> 2.38 ms, fc1.dgrad
+        // 2.88 -> 2.82); the 256 x 64 tiles of the conv layers lose 1 % with that (c2.fwd 4.82 -> 4.87)
+        constexpr int ILV = (WM == 2 && WN == 2) ? 2 : 1;
+        if (x6_il()) return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
     }
     auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
     static bool raised = false;                // per instantiation
