@@ -253,8 +253,15 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * NL, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            if constexpr (WM == 2 && WN == 2) {     // 128 x 128 tiles: the second k half's fragment reads 8 MFMAs early (gemmx6.hip.h)
+                static_assert(2 * NL <= 24, "room for the early fragment reads");
+                __builtin_amdgcn_sched_group_barrier(0x008, 24 - 2 * NL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * NL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(0);
