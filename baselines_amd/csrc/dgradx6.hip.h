@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
                 const int py = cls / S, px = cls - py * S;
                 const int iy = yy * S + py, ix = xx * S + px;
                 const int bimg = b0 + (wm * 2 + a) * 32 + i;
-                vv[a][b] = cb < G::N && iy < H && ix < W && bimg < B;
+                vv[a][b] = cb < G::N && iy < H && ix < W && bimg < B && (!(dbg & 2) || acc[a][b][0] == 12345.678f);   // dbg 2: no epilogue memory traffic
                 oo[a][b] = vv[a][b] ? (long)bimg * (H * W * C) + ((long)iy * W + ix) * C + c0 : 0L;
                 aux[a][b] = ef.load_aux(oo[a][b], c0, h, vv[a][b]);
             }
@@ -356,7 +356,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
     if (B <= 0) return hipSuccess;
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NTN = (G::N + BN - 1) / BN;
-    const bool pa = dzp && x8 && !dbg, tr = (dxp || tr_plain) && x8 && !dbg && C % 32 == 0 && (act == ACT_RELU || (!hmask && !mbits));
+    const bool pa = dzp && x8 && !dbg, tr = (dxp || tr_plain) && x8 && !(dbg & 1) && C % 32 == 0 && (act == ACT_RELU || (!hmask && !mbits));
     hipLaunchKernelGGL((dgx6_split_planes_kernel<H, W, C, RF, S, NF>), dim3((G::N * G::K + 255) / 256), dim3(256), 0, stream,
                        w, planes, pa ? 1 : 0);
     hipError_t e = hipGetLastError();
