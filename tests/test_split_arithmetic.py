@@ -84,3 +84,38 @@ def test_split_dot_products_are_fp32_class():
     scale = np.abs(exact).max()
     e_plain, e_split = np.abs(plain - exact).max() / scale, np.abs(split - exact).max() / scale
     assert e_split < 2e-6 and e_split < 4 * e_plain + 1e-7, (e_plain, e_split)
+
+
+def test_transposed_accumulator_layout_and_plane_order():
+    """Index algebra of baselines_amd/csrc/planes.hip.h, restated in NumPy.
+    With the MFMA operands swapped, lane (i, h) of a 32 x 32 accumulator owns row i and the columns 8g + 4h + j, held in
+    accumulator register 4g + j (C/D layout of v_mfma_f32_32x32x16: register r of lane l belongs to the register-indexed
+    dimension at (r & 3) + 8 (r >> 2) + 4 (l >> 5)).  The 64 lanes x 16 registers cover the tile exactly once, every
+    float4 store is 16-byte aligned inside its row, the mask-word bits of the two half-waves are disjoint and complete,
+    and perm32 -- the order of a plane tensor inside each block of 32 -- gives every lane 16 consecutive positions."""
+    def perm32(c):
+        return ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3)
+    assert sorted(perm32(c) for c in range(32)) == list(range(32))                       # a permutation
+    seen = np.zeros((32, 32), int)
+    for lane in range(64):
+        i, h = lane & 31, lane >> 5
+        bits = 0
+        for r in range(16):
+            col = (r & 3) + 8 * (r >> 2) + 4 * h                                         # hardware layout of register r
+            g, j = r >> 2, r & 3
+            assert col == 8 * g + 4 * h + j                                              # what tr_block_epilogue assumes
+            seen[i, col] += 1
+            bits |= 1 << col
+        assert bits == (0x0f0f0f0f << (4 * h)) & 0xffffffff                              # half-wave h: nibbles 2g + h
+        for g in range(4):
+            assert (8 * g + 4 * h) % 4 == 0                                              # float4 stores: 16-byte aligned
+            assert [perm32(8 * g + 4 * h + j) for j in range(4)] == [16 * h + 4 * g + j for j in range(4)]
+        assert sorted(perm32(8 * g + 4 * h + j) for g in range(4) for j in range(4)) == list(range(16 * h, 16 * h + 16))
+    assert (seen == 1).all()
+    # a dot product does not care in which order k runs: the consumers' weight planes use the same perm32 order
+    rng = np.random.RandomState(0)
+    a, b = rng.randn(64).astype(np.float64), rng.randn(64).astype(np.float64)
+    kp = np.array([(k & ~31) | perm32(k & 31) for k in range(64)])
+    ap, bp = np.empty(64), np.empty(64)
+    ap[kp], bp[kp] = a, b
+    assert abs(ap @ bp - a @ b) < 1e-12
