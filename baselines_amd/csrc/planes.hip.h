@@ -1,21 +1,24 @@
-// Pre-split activation planes (gfx950): the A operand of the split-bf16 engines leaves its PRODUCER already split.
+// Transposed-accumulator epilogues of the split-bf16 engines (gfx950), and the pre-split "plane tensor" experiment.
 //
-// The tiled split engines (gemmx6.hip.h, dgradx6.hip.h) multiply fp32 x fp32 as 8 exact bf16 products; splitting the
-// activation operand while it is staged costs ~176 of the ~210 VALU instructions of a k step, and every VALU instruction
-// is paid for in matrix-pipe issue time (profiles/README.md, "issue port").  The im2col overlap makes conv2 split every
-// element of its input 4 times, conv3 9 times, the fc1 pair once per column tile.  Here the kernel that PRODUCES an
-// activation (forward: h = relu(z), common/models.py:15-26; backward: dz = dh * relu'(h), the tf.gradients chain of
-// ppo2/model.py:102-103) splits each element once in its epilogue and writes a "plane tensor" next to the fp32 tensor;
-// the consumer's staging is then a plain 16-byte copy.  The split is the same truncation split (split2_bf16x3), so the
-// products, their order and therefore the results of a consumer are those of the in-loop split.
+// (1) What the product uses.  With the MFMA operands swapped (D^T = B A^T) a lane of the 32 x 32 accumulator owns ONE
+// output row and the 16 columns {8g + 4h + j : g, j < 4} (h = lane >> 5) of a 32-column block, four consecutive ones per
+// accumulator quad.  The epilogues of the hidden layers' forward kernels (h = relu(z + b), common/models.py:15-26 via
+// a2c/utils.py:37-63) and of the data gradients (dz = dh * relu'(h), the tf.gradients chain of ppo2/model.py:102-103)
+// then store float4s (16 instead of 64 store instructions per thread and tile), assemble the ReLU mask word inside the
+// lane (one shuffle per block instead of 16 ballots) and read ONE mask word per 32 channels: c2.fwd 6.3 -> 5.5 ms,
+// c2.dgrad 6.2 -> 5.75 ms (profiles/README.md).  Same products, same sums per output as the row-major epilogues.
 //
-// Plane tensor of X[rows][C] (C % 32 == 0):  three bf16 arrays P[plane][rows][C]; inside each aligned block of 32
-// elements along C, element c sits at position perm32(c).  perm32 is what makes the producer cheap: with the MFMA
-// operands swapped (D^T = B A^T) a lane of the 32x32 accumulator owns ONE row and the 16 columns
-// {8g + 4h + j : g, j < 4} (h = lane >> 5) of a 32-column block, which perm32 maps to 16 CONSECUTIVE positions: the lane
-// stores 2 x 16 bytes per plane, no cross-lane traffic, and 4 x float4 for the fp32 tensor (instead of 16 dword stores).
-// The consumers' weight planes use the same order of k (split_planes_kernel / dgx6_split_planes_kernel, kperm), so
-// the position of an element inside its block never has to be undone: a dot product does not care in which order k runs.
+// (2) The experiment (option act_planes bits 1 / 2 / 32, off by default).  The tiled split engines multiply fp32 x fp32 as
+// 8 exact bf16 products; splitting the activation operand while it is staged costs ~176 of the ~210 VALU instructions of
+// a k step, and the im2col overlap makes conv2 split every element of its input 4 times, conv3 9 times.  Here the kernel
+// that PRODUCES an activation also splits each element once in its epilogue and writes a "plane tensor" next to the fp32
+// tensor; the consumer's staging is then a plain 16-byte copy (same truncation split, split2_bf16x3: same products).
+// Plane tensor of X[rows][C] (C % 32 == 0): three bf16 arrays P[plane][rows][C]; inside each aligned block of 32
+// elements along C, element c sits at position perm32(c), which maps a lane's 16 columns to 16 CONSECUTIVE positions
+// (2 x 16 bytes per lane and plane, no cross-lane traffic); the consumers' weight planes use the same order of k
+// (split_planes_kernel / dgx6_split_planes_kernel, kperm) -- a dot product does not care in which order k runs.
+// Measured: the k loops shrink from 204 to 36 VALU instructions per 64 MFMAs and every kernel gets SLOWER (c2.fwd 6.3 ->
+// 9.0 ms): a (row, plane, k tile) piece is 64 bytes = half a cache line, the producers write 2.5x the bytes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
