@@ -172,3 +172,108 @@ def test_validate_probtype_categorical_on_oracle():
     p = np.exp(PDPARAM_CATEGORICAL) / np.exp(PDPARAM_CATEGORICAL).sum()
     assert abs(float(om._entropy(rep(PDPARAM_CATEGORICAL, 1))[0]) - float(-(p * np.log(p)).sum())) < 1e-12
     assert abs(float(om._neglogp(rep(PDPARAM_CATEGORICAL, 1), torch.tensor([2]))[0]) + math.log(p[2])) < 1e-12
+
+
+# ---- the network forward of the oracle against the DEFINING SUMS of the reference's layers -----------------------------
+def _conv_defining_sum(x, w, b, stride):
+    """a2c/utils.py:37-56 `conv`: tf.nn.conv2d(x, w, strides=[1, s, s, 1], padding='VALID', data_format='NHWC') + b with
+    w[rf, rf, nin, nf] and b broadcast over [1, 1, 1, nf]; tf.nn.conv2d is defined (TF API documentation) as
+        out[b, i, j, k] = sum_{di, dj, q} x[b, s*i + di, s*j + dj, q] * w[di, dj, q, k]
+    -- restated with NumPy windows in float64, no library convolution involved."""
+    rf = w.shape[0]
+    win = np.lib.stride_tricks.sliding_window_view(x, (rf, rf), axis=(1, 2))[:, ::stride, ::stride]   # [B, OH, OW, C, rf, rf]
+    return np.einsum('bijqde,deqk->bijk', win, w) + b.reshape(1, 1, 1, -1)
+
+
+def test_oracle_network_forward_equals_the_defining_sums():
+    """NatureCNN (common/models.py:15-26: /255, conv 8x8/4 -> 4x4/2 -> 3x3/1 with ReLU, conv_to_fc = NHWC flatten
+    (a2c/utils.py:142-145), fc 512 with ReLU) and the heads (policies.py:43-64 via distributions.py:59-74: pi = latent @ w + b,
+    vf = (latent @ w + b)[:, 0]) computed from their defining sums in float64 NumPy vs the oracle's torch restatement: pins the
+    layout conventions (HWIO filters, NHWC flatten order, bias broadcast, scaling) that a wrong permute would silently break."""
+    np.random.seed(3)
+    om = OracleModel(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6,
+                     dtype=torch.float64)
+    rng = np.random.RandomState(4)
+    with torch.no_grad():
+        for k in om.names:                                   # biases are zero at init: make every term matter
+            om.p[k] += torch.tensor(0.05 * rng.randn(*om.p[k].shape), dtype=torch.float64)
+    P = {k: v.detach().numpy() for k, v in om.p.items()}
+    obs = rng.randint(0, 256, (3, 84, 84, 4)).astype(np.uint8)
+    h = obs.astype(np.float64) / 255.
+    for name, s in (('c1', 4), ('c2', 2), ('c3', 1)):
+        h = np.maximum(_conv_defining_sum(h, P['ppo2_model/pi/%s/w' % name], P['ppo2_model/pi/%s/b' % name], s), 0.)
+    assert h.shape == (3, 7, 7, 64)
+    lat = np.maximum(h.reshape(3, -1) @ P['ppo2_model/pi/fc1/w'] + P['ppo2_model/pi/fc1/b'], 0.)
+    pi = lat @ P['ppo2_model/pi/w'] + P['ppo2_model/pi/b']
+    vf = (lat @ P['ppo2_model/vf/w'] + P['ppo2_model/vf/b'])[:, 0]
+    pi_o, vf_o = om.forward(obs)
+    np.testing.assert_allclose(pi_o.detach().numpy(), pi, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(vf_o.detach().numpy(), vf, rtol=1e-10, atol=1e-12)
+    # softmax cross-entropy / entropy of distributions.py:164-198 from their formulas
+    a = np.array([0, 5, 2])
+    a0 = pi - pi.max(axis=1, keepdims=True)
+    z0 = np.exp(a0).sum(axis=1, keepdims=True)
+    nlp = -(a0 - np.log(z0))[np.arange(3), a]
+    ent = (np.exp(a0) / z0 * (np.log(z0) - a0)).sum(axis=1)
+    np.testing.assert_allclose(om._neglogp(pi_o, torch.as_tensor(a)).detach().numpy(), nlp, rtol=1e-10)
+    np.testing.assert_allclose(om._entropy(pi_o).detach().numpy(), ent, rtol=1e-10)
+
+
+def test_oracle_loss_statistics_and_gradient_from_the_formulas_of_model_py():
+    """ppo2/model.py:57-91 restated in float64 NumPy on the oracle's own network outputs (Gaussian policy: neglogp /
+    entropy of distributions.py:238-246), and the gradient the oracle returns checked as a directional derivative of that
+    loss by central differences -- the loss the gradients are taken of is the loss the statistics report."""
+    np.random.seed(5)
+    om = OracleModel(network='mlp', ob_shape=(11,), ob_dtype=np.float32, pd_kind='gaussian', nact=3, value_network='copy',
+                     ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float64)
+    rng = np.random.RandomState(6)
+    with torch.no_grad():
+        for k in om.names:
+            om.p[k] += torch.tensor(0.1 * rng.randn(*om.p[k].shape), dtype=torch.float64)
+    B, eps = 64, 0.2
+    obs = rng.randn(B, 11).astype(np.float32)
+    act = rng.randn(B, 3).astype(np.float32)
+    ret, oldv = rng.randn(B), rng.randn(B) * 0.5
+    oldnlp = rng.rand(B) * 2 + 2.0
+    advs = om._normalised_advs(ret, oldv)
+    np.testing.assert_allclose(advs, (ret - oldv - (ret - oldv).mean()) / ((ret - oldv).std() + 1e-8), rtol=1e-12)
+
+    def loss_of():
+        loss, stats = om.loss_and_stats(obs, ret, act, oldv, oldnlp, eps, advs)
+        return loss, stats
+
+    loss, stats = loss_of()
+    pi, vf = (t.detach().numpy() for t in om.forward(obs))
+    mean = pi                                                     # pdparam = [mean, mean * 0 + logstd] (distributions.py:102-106)
+    logstd = np.zeros_like(mean) + om.p['ppo2_model/pi/logstd'].detach().numpy()
+    nlp = 0.5 * (((act - mean) / np.exp(logstd)) ** 2).sum(-1) + 0.5 * np.log(2.0 * np.pi) * 3 + logstd.sum(-1)
+    ent = (logstd + 0.5 * np.log(2.0 * np.pi * np.e)).sum(-1).mean()
+    vclip = oldv + np.clip(vf - oldv, -eps, eps)
+    vf_loss = 0.5 * np.maximum((vf - ret) ** 2, (vclip - ret) ** 2).mean()
+    ratio = np.exp(oldnlp - nlp)
+    pg_loss = np.maximum(-advs * ratio, -advs * np.clip(ratio, 1 - eps, 1 + eps)).mean()
+    want = [pg_loss, vf_loss, ent, 0.5 * ((nlp - oldnlp) ** 2).mean(), (np.abs(ratio - 1) > eps).mean()]
+    np.testing.assert_allclose([float(s) for s in stats], want, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(float(loss), pg_loss - 0.01 * ent + 0.5 * vf_loss, rtol=1e-12)
+    # directional derivative
+    _, flat = om.compute_grads(eps, obs, ret, act, oldv, oldnlp, advs=advs)
+    d = rng.randn(flat.numel())
+    d /= np.linalg.norm(d)
+    base = {k: om.p[k].detach().clone() for k in om.names}
+
+    def shifted(h):
+        off = 0
+        with torch.no_grad():
+            for k in om.names:
+                n = base[k].numel()
+                om.p[k].copy_(base[k] + h * torch.tensor(d[off:off + n].reshape(base[k].shape)))
+                off += n
+        return float(loss_of()[0])
+
+    h = 1e-5
+    fd = (shifted(h) - shifted(-h)) / (2 * h)
+    shifted(0.0)
+    assert abs(fd - float(flat.numpy() @ d)) <= 1e-7 * max(1.0, abs(fd)), (fd, float(flat.numpy() @ d))
+    # tf.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)
+    gn = float(np.linalg.norm(flat.numpy()))
+    np.testing.assert_allclose(om.average_and_clip(flat.clone()).numpy(), flat.numpy() * 0.5 / max(gn, 0.5), rtol=1e-12)
