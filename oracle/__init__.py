@@ -16,7 +16,13 @@ Pinning status (see DESIGN.md "Oracle"):
     "parity unpinned" at the TensorFlow boundary: tensorflow<2 is a third-party
     dependency absent from /root/reference and from this image.  The
     restatement follows model.py:57-114 / distributions.py / a2c/utils.py line
-    by line, is cross-checked in fp64 against autograd and finite differences,
-    and the Adam formula is cross-pinned by the reference's NumPy mirror
-    (common/mpi_adam.py:38-41).
+    by line.  What pins it short of TensorFlow itself (tests/test_oracle_pins.py):
+    the Adam formula against the reference's NumPy mirror (common/mpi_adam.py:38-41)
+    on the problem of its own test_MpiAdam; validate_probtype
+    (distributions.py:320-348) on the neglogp / entropy formulas; the NatureCNN
+    forward + heads against the defining sums of tf.nn.conv2d / conv_to_fc / fc
+    in float64 NumPy (no library convolution: layout conventions HWIO, NHWC
+    flatten, bias broadcast); the loss statistics from the formulas of
+    model.py:57-91; the gradient as a directional derivative of that loss;
+    clip_by_global_norm.
 """
