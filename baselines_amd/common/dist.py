@@ -22,22 +22,81 @@ class Comm(object):
         assert dist.is_initialized(), 'torch.distributed is not initialised'
         self.group = group
         self.native = None
+        self.native_error = None
 
     def enable_native(self):
-        """Create the mrl_comm of this rank: rank 0 draws the RCCL unique id, torch.distributed ships it."""
+        """Create the mrl_comm of this rank: rank 0 draws the RCCL unique id, torch.distributed ships it.
+
+        Collective and fail-safe: every rank takes part in the id broadcast (rank 0 sends None when it could not
+        draw one), and the outcome is agreed on with an all-reduce(MIN) of a success flag -- when ANY rank failed
+        (librccl not loadable, ncclCommInitRank error) every rank drops its handle and the collectives stay in
+        torch.distributed.  Returns True when the in-library communicator is in use on all ranks."""
         from .. import _lib
-        lib = _lib.load()
         size, rank = self.Get_size(), self.Get_rank()
-        box = [None]
-        if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            _lib.check(lib.mrl_comm_unique_id(buf), 'mrl_comm_unique_id')
-            box[0] = bytes(buf.raw)
+        box, ok, why = [None], 1, ''
+        lib = None
+        try:
+            lib = _lib.load()
+            if rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                _lib.check(lib.mrl_comm_unique_id(buf), 'mrl_comm_unique_id')
+                box[0] = bytes(buf.raw)
+        except Exception as exc:                     # the broadcast below must still run on every rank
+            ok, why = 0, repr(exc)
         dist.broadcast_object_list(box, src=0, group=self.group)
-        h = ctypes.c_void_p()
-        _lib.check(lib.mrl_comm_create(box[0], size, rank, ctypes.byref(h)), 'mrl_comm_create')
-        self.native = h
-        return self
+        h = None
+        if ok and box[0] is not None:
+            try:
+                h = ctypes.c_void_p()
+                _lib.check(lib.mrl_comm_create(box[0], size, rank, ctypes.byref(h)), 'mrl_comm_create')
+            except Exception as exc:
+                ok, why, h = 0, repr(exc), None
+        else:
+            ok = 0
+        dev = 'cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1 and dev == 'cuda':
+            # phase 2: the first collective through the new communicator, checked, and agreed on again
+            try:
+                probe = torch.ones(1024, dtype=torch.float32, device='cuda')
+                _lib.check(lib.mrl_allreduce_grads(h, _lib.ptr(probe), probe.numel(), _lib.stream_ptr()),
+                           'mrl_allreduce_grads (probe)')
+                torch.cuda.synchronize()
+                if not bool((probe == float(size)).all().item()):
+                    raise RuntimeError('probe all-reduce returned %r, expected %d' % (float(probe[0].item()), size))
+            except Exception as exc:
+                ok, why = 0, repr(exc)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            self.native = h
+            self.native_error = None
+            return True
+        if h is not None:
+            try:
+                lib.mrl_comm_destroy(h)
+            except Exception:
+                pass
+        self.native = None
+        self.native_error = why or 'another rank could not create its communicator'
+        return False
+
+    def close(self):
+        """destroy the in-library communicator (idempotent)"""
+        h, self.native = self.native, None
+        if h is not None:
+            try:
+                from .. import _lib
+                _lib.load().mrl_comm_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def Get_size(self):
         return dist.get_world_size(self.group)

@@ -104,9 +104,13 @@ extern "C" int mrl_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------
-// GAE.  One workgroup = 64 environments (one wavefront runs the recurrence, all four waves do
-// the coalesced HBM<->LDS staging).  Time is processed in chunks of TC steps from the back so
-// any nsteps fits; the f64 carry lives in a register of wave 0.
+// GAE.  One workgroup = GAE_E = 16 environments (256 workgroups at num_envs = 4096: one per CU), 256 threads stage
+// HBM <-> LDS, the first 16 lanes of wave 0 run the recurrence.  The kernel is LATENCY-bound (nsteps dependent f64
+// steps; 8.9 MB of traffic), so the work is arranged for latency: every thread issues ALL its global loads of a time
+// chunk before the first LDS write (the old form waited for each element: ~100 dependent round trips to HBM), and
+// the recurrence reads 8 steps of operands from LDS ahead of the dependent chain and keeps its outputs in separate
+// arrays, so the operand loads never wait behind a store.  Time is processed in chunks of TC steps from the back so
+// any nsteps fits; the f64 carry lives in a register.
 //
 // Reference arithmetic (ppo2/runner.py:58-64 under NumPy promotion rules):
 //   gv    = f32(gamma) * V[t+1]                      (f32 product, rounded)
@@ -116,7 +120,8 @@ extern "C" int mrl_device_count(void) {
 // Explicit *_rn intrinsics keep the compiler from contracting any of it into FMAs.
 // ------------------------------------------------------------------------------------------
 constexpr int GAE_TC = 128;
-constexpr int GAE_E = 64;
+constexpr int GAE_E = 16;
+constexpr int GAE_U = 8;                                        // recurrence steps whose operands are read ahead
 
 __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
                                                   const uint8_t* __restrict__ done,
@@ -124,44 +129,81 @@ __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew,
                                                   const uint8_t* __restrict__ last_done, float gamma_f,
                                                   double gamma_lam, float* __restrict__ adv_out,
                                                   float* __restrict__ ret_out, int T, int N) {
-    __shared__ float s_r[GAE_TC][GAE_E];        // rewards in, advantages out
+    __shared__ float s_r[GAE_TC][GAE_E];        // rewards
     __shared__ float s_v[GAE_TC + 1][GAE_E];    // values t_lo..t_hi (slot n = V[t_hi])
+    __shared__ float s_a[GAE_TC][GAE_E];        // advantages
     __shared__ float s_ret[GAE_TC][GAE_E];
-    __shared__ uint8_t s_d[GAE_TC + 1][GAE_E];  // dones t_lo+1..t_hi stored at slot (t - t_lo)
+    __shared__ float s_nnt[GAE_TC + 1][GAE_E];  // 1 - done of t_lo+1..t_hi stored at slot (t - t_lo)
 
+    constexpr int IT = ((GAE_TC + 1) * GAE_E + 255) / 256;      // staging elements per thread and chunk
     const int e0 = blockIdx.x * GAE_E;
     const int tid = threadIdx.x;
+    const int le = tid % GAE_E, e = e0 + le;
+    const bool eok = e < N;
     double carry = 0.0;
     for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {
         const int t_lo = max(0, t_hi - GAE_TC);
         const int n = t_hi - t_lo;
-        for (int q = tid; q < (n + 1) * GAE_E; q += 256) {
-            int tt = q / GAE_E, le = q % GAE_E, e = e0 + le, t = t_lo + tt;
-            if (e < N) {
-                if (tt < n) s_r[tt][le] = rew[(long)t * N + e];
-                s_v[tt][le] = (t < T) ? val[(long)t * N + e] : last_val[e];
-                if (tt > 0) s_d[tt][le] = (t < T) ? done[(long)t * N + e] : last_done[e];
+        float rr[IT], vv[IT];
+        uint8_t dd[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {          // all loads of the chunk in flight before the first LDS write
+            const int tt = tid / GAE_E + i * (256 / GAE_E), t = t_lo + tt;
+            rr[i] = 0.f; vv[i] = 0.f; dd[i] = 0;
+            if (eok && tt <= n) {
+                if (tt < n) rr[i] = rew[(long)t * N + e];
+                vv[i] = (t < T) ? val[(long)t * N + e] : last_val[e];
+                if (tt > 0) dd[i] = (t < T) ? done[(long)t * N + e] : last_done[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int tt = tid / GAE_E + i * (256 / GAE_E);
+            if (tt <= n) {
+                if (tt < n) s_r[tt][le] = rr[i];
+                s_v[tt][le] = vv[i];
+                s_nnt[tt][le] = dd[i] ? 0.f : 1.f;
             }
         }
         __syncthreads();
-        if (tid < GAE_E && e0 + tid < N) {
-            for (int tt = n - 1; tt >= 0; --tt) {
-                double nnt = s_d[tt + 1][tid] ? 0.0 : 1.0;
-                float v = s_v[tt][tid];
-                float gv = __fmul_rn(gamma_f, s_v[tt + 1][tid]);
-                double delta = __dsub_rn(__dadd_rn((double)s_r[tt][tid], __dmul_rn((double)gv, nnt)), (double)v);
+        if (tid < GAE_E && eok) {
+            int tt = n - 1;
+            for (; tt >= GAE_U - 1; tt -= GAE_U) {
+                float r_[GAE_U], v_[GAE_U], v1_[GAE_U], m_[GAE_U];
+#pragma unroll
+                for (int u = 0; u < GAE_U; ++u) {
+                    r_[u] = s_r[tt - u][tid]; v_[u] = s_v[tt - u][tid]; v1_[u] = s_v[tt - u + 1][tid];
+                    m_[u] = s_nnt[tt - u + 1][tid];
+                }
+#pragma unroll
+                for (int u = 0; u < GAE_U; ++u) {
+                    const double nnt = (double)m_[u];
+                    const float gv = __fmul_rn(gamma_f, v1_[u]);
+                    const double delta = __dsub_rn(__dadd_rn((double)r_[u], __dmul_rn((double)gv, nnt)), (double)v_[u]);
+                    carry = __dadd_rn(delta, __dmul_rn(__dmul_rn(gamma_lam, nnt), carry));
+                    const float a = (float)carry;
+                    s_a[tt - u][tid] = a;
+                    s_ret[tt - u][tid] = __fadd_rn(a, v_[u]);
+                }
+            }
+            for (; tt >= 0; --tt) {
+                const double nnt = (double)s_nnt[tt + 1][tid];
+                const float v = s_v[tt][tid];
+                const float gv = __fmul_rn(gamma_f, s_v[tt + 1][tid]);
+                const double delta = __dsub_rn(__dadd_rn((double)s_r[tt][tid], __dmul_rn((double)gv, nnt)), (double)v);
                 carry = __dadd_rn(delta, __dmul_rn(__dmul_rn(gamma_lam, nnt), carry));
-                float a = (float)carry;
-                s_r[tt][tid] = a;
+                const float a = (float)carry;
+                s_a[tt][tid] = a;
                 s_ret[tt][tid] = __fadd_rn(a, v);
             }
         }
         __syncthreads();
-        for (int q = tid; q < n * GAE_E; q += 256) {
-            int tt = q / GAE_E, le = q % GAE_E, e = e0 + le;
-            if (e < N) {
-                long o = (long)(t_lo + tt) * N + e;
-                if (adv_out) adv_out[o] = s_r[tt][le];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int tt = tid / GAE_E + i * (256 / GAE_E);
+            if (eok && tt < n) {
+                const long o = (long)(t_lo + tt) * N + e;
+                if (adv_out) adv_out[o] = s_a[tt][le];
                 ret_out[o] = s_ret[tt][le];
             }
         }

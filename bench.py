@@ -150,26 +150,88 @@ def arithmetic_mode(_lib):
     return sites, text, short
 
 
-def kernel_rooflines(prof, sites):
-    """per launch site: achieved algorithmic TFLOP/s (or GB/s) over the HIP-event time inside the timed region, against the
-    peak of the pipe THAT kernel ran on"""
+def source_sha16():
+    """identity of the kernels that are running: sha256 over the HIP sources + the public header (the built .so is not
+    tracked and .git does not travel to the GPU box).  scripts/pmc_to_json.py records the same value in the PMC file."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'baselines_amd', 'csrc')
+    names = sorted(n for n in os.listdir(src) if n.endswith(('.hip', '.h')))
+    for n in names:
+        h.update(n.encode())
+        h.update(open(os.path.join(src, n), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'mrl.h'), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def nature_cnn_alg_bytes(B):
+    """ALGORITHMIC HBM bytes per launch of each GEMM site of the NatureCNN minibatch step at B samples: every operand
+    the launch must read or write, once (fp32 activations / gradients, uint8 observations, 1-bit ReLU masks where the
+    kernel consumes or produces them; weights are negligible).  DESIGN.md section 3 lists the same figures."""
+    ob, h1, h2, h3, h4 = 84 * 84 * 4, 20 * 20 * 32 * 4, 9 * 9 * 64 * 4, 7 * 7 * 64 * 4, 512 * 4
+    m1, m2, m3 = 20 * 20 * 32 // 8, 9 * 9 * 64 // 8, 7 * 7 * 64 // 8
+    per = {'c1.fwd': ob + h1 + m1, 'c2.fwd': h1 + h2 + m2, 'c3.fwd': h2 + h3 + m3, 'fc1.fwd': h3 + h4,
+           'fc1.dgrad': h4 + h3 + m3, 'fc1.wgrad': h3 + h4, 'c3.dgrad': h3 + h2 + m2, 'c3.wgrad': h2 + h3,
+           'c2.dgrad': h2 + h1 + m1, 'c2.wgrad': h1 + h2, 'c1.wgrad': ob + h1}
+    return {k: float(v) * B for k, v in per.items()}
+
+
+def kernel_rooflines(prof, sites, alg_bytes=None, pmc=None):
+    """per launch site: the roofline that BINDS it.  A site with flops is priced on max(algorithmic bytes / HBM peak,
+    algorithmic flops / peak of the matrix pipe it runs on); `bound` says which floor is the larger one, `achieved` /
+    `peak` / `frac` are in that resource's unit (frac = floor time / measured time), and both fractions are listed.
+    `traffic` = HBM-side bytes per launch from the PMC passes of the same sources (else null)."""
     out = {}
+    alg_bytes = alg_bytes or {}
+    pmc = pmc or {}
     for k, v in prof.items():
         if not v['count'] or v['ms'] <= 0:
             continue
         avg_s = v['ms'] / v['count'] * 1e-3
+        nbytes = alg_bytes.get(k, v['bytes'] / v['count'] if v['bytes'] > 0 else 0.0)
         if v['flops'] > 0:
             nprod = sites.get(k, 0)
             peak = PEAK_BF16_MFMA_TFLOPS / nprod if nprod else PEAK_F32_MFMA_TFLOPS
-            ach = v['flops'] / v['count'] / avg_s / 1e12
-            out[k] = {'bound': 'mfma', 'pipe': ('bf16 MFMA / %d exact products per multiply' % nprod) if nprod else 'fp32 MFMA',
-                      'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'avg_ms': avg_s * 1e3,
-                      'launches': v['count']}
-        elif v['bytes'] > 0:
-            ach = v['bytes'] / v['count'] / avg_s / 1e9
+            fl = v['flops'] / v['count']
+            t_mfma, t_hbm = fl / (peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+            pipe = ('bf16 MFMA / %d exact products per multiply' % nprod) if nprod else 'fp32 MFMA'
+            r = {'pipe': pipe, 'avg_ms': avg_s * 1e3, 'launches': v['count'], 'mfma_tflops': fl / avg_s / 1e12,
+                 'mfma_peak_tflops': peak, 'mfma_frac': t_mfma / avg_s, 'alg_bytes': nbytes,
+                 'hbm_gbs': nbytes / avg_s / 1e9, 'hbm_frac': t_hbm / avg_s}
+            if t_hbm > t_mfma:
+                r.update({'bound': 'hbm', 'achieved': nbytes / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                          'frac': t_hbm / avg_s})
+            else:
+                r.update({'bound': 'mfma', 'achieved': fl / avg_s / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                          'frac': t_mfma / avg_s})
+            out[k] = r
+        elif nbytes > 0:
+            ach = nbytes / avg_s / 1e9
             out[k] = {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
-                      'avg_ms': avg_s * 1e3, 'launches': v['count']}
+                      'avg_ms': avg_s * 1e3, 'launches': v['count'], 'alg_bytes': nbytes}
+        if k in out:
+            tr = pmc.get(k, {}).get('hbm_bytes')
+            out[k]['traffic'] = tr
+            if tr and nbytes > 0:
+                out[k]['traffic_over_algorithmic'] = tr / nbytes
     return out
+
+
+def load_pmc(nbatch_train):
+    """newest committed profiles/*_pmc_hbm.json -- used only if it was collected from the sources that are running"""
+    import glob
+    if nbatch_train != 131072:
+        return {}, None
+    cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')))
+    if not cand:
+        return {}, 'no profiles/*_pmc_hbm.json'
+    with open(cand[-1]) as fh:
+        pm = json.load(fh)
+    name = 'profiles/' + os.path.basename(cand[-1])
+    have, want = pm.get('source_sha16'), source_sha16()
+    if have != want:
+        return {}, '%s was collected from other kernel sources (%s, running %s): traffic withheld' % (name, have, want)
+    return pm.get('per_launch', {}), name
 
 
 def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, want_prof):
@@ -219,6 +281,30 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     ro = runner.rollout
     last_values = model.value_dev(runner.obs)
 
+    # self-check: gradient + statistics of one minibatch of the benched shape, computed in the benched
+    # chunking (one 131072-sample chunk) and again in 8192-sample chunks -- the size the parity suite verifies against the
+    # oracle entry by entry -- must agree to 1e-5 (stats) / 1e-5 of the gradient scale (every entry)
+    self_check = None
+    if workload == 'atari' and world == 1 and nbatch_train > 8192 and os.environ.get('MRL_BENCH_SELF_CHECK', '1') != '0':
+        ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
+        idx = torch.from_numpy(np.random.RandomState(7).permutation(nbatch)[:nbatch_train]).to(model.device)
+        dm2 = ops.DeviceModel(chunk=8192, device=model.device, **policy.device_model_kwargs())
+        outs = []
+        for dmx in (model.dm, dm2):
+            g = torch.empty(dmx.P, dtype=torch.float32, device=model.device)
+            st5 = torch.empty(5, dtype=torch.float32, device=model.device)
+            dmx.grad(model.params, ro.obs, ro.actions, ro.returns, ro.values, ro.neglogpacs, idx, nbatch_train, T, N,
+                     hp['cliprange'], hp['ent_coef'], 0.5, g, st5)
+            outs.append((g, st5))
+        gscale = float(outs[1][0].abs().max())
+        self_check = {'what': 'mrl_model_grad of one %d-sample minibatch: chunk %d vs chunk 8192' % (nbatch_train, model.dm.chunk),
+                      'stats_max_abs_diff': float((outs[0][1] - outs[1][1]).abs().max()),
+                      'grad_max_abs_diff_over_scale': float((outs[0][0] - outs[1][0]).abs().max()) / gscale,
+                      'grad_scale': gscale}
+        assert self_check['stats_max_abs_diff'] <= 1e-5 and self_check['grad_max_abs_diff_over_scale'] <= 1e-5, self_check
+        del dm2, outs, g, st5
+        torch.cuda.empty_cache()
+
     def update():
         """the PPO2 update (ppo2.py:142 GAE part + :154-166)"""
         ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
@@ -266,10 +352,19 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         dt = float(tt.item())
     lossvals = lossvals.cpu().numpy()
     assert np.all(np.isfinite(lossvals)), lossvals
+    params_synced = None
+    if world > 1:              # every rank must end with bit-identical parameters (mpi_adam_optimizer.py:53-68)
+        import torch.distributed as dist
+        ck = torch.stack([model.params.double().sum(), model.params.double().abs().sum()])
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params_synced = bool(torch.equal(lo, hi))
     res = dict(value=total_envs * T * steps / dt, dt=dt, t_rollout=t_rollout, loss=[float(x) for x in lossvals], prof=prof,
                prof_steps=prof_steps, hp=hp, N=N, nbatch_train=nbatch_train, chunk=model.dm.chunk, graph_mode=graph_mode,
                model_tflops=flops_per_sample_visit * total_envs * T * hp['noptepochs'] * steps / dt / 1e12,
-               native_dp=bool(getattr(model, 'native_dp', False)), device_state=device_state)
+               native_dp=bool(getattr(model, 'native_dp', False)), device_state=device_state,
+               self_check=self_check, params_synced=params_synced)
     del runner, model, env, ro
     torch.cuda.empty_cache()
     return res
@@ -319,25 +414,25 @@ def dominant_roofline(res, sites, workload):
     prof = res['prof']
     if not prof:
         return None, {}
-    per = kernel_rooflines(prof, sites if workload == 'atari' else {})
+    atari = workload == 'atari'
+    pmc, pmc_src = load_pmc(res['nbatch_train']) if atari else ({}, None)
+    per = kernel_rooflines(prof, sites if atari else {}, nature_cnn_alg_bytes(res['nbatch_train']) if atari else None, pmc)
     tot_ms = sum(v['ms'] for v in prof.values())
     dom = max(per, key=lambda k: prof[k]['ms'])
     roof = dict(per[dom])
     roof['kernel'] = dom
-    roof['traffic'] = None
+    roof.setdefault('traffic', None)
     roof['share_of_kernel_time'] = prof[dom]['ms'] / tot_ms
-    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process; they
-    # come from the committed `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over one epoch of the same shape
+    # HBM-side bytes per launch: PMC counters cannot be collected from inside this process; they come from the committed
+    # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over one epoch of the same shape AND the same kernel sources
     # (scripts/pmc_epoch.sh -> profiles/*_pmc_hbm.json, gfx950 corrections applied by scripts/pmc_to_json.py)
-    if workload == 'atari' and res['nbatch_train'] == 131072:
-        import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')))
-        if cand:
-            with open(cand[-1]) as fh:
-                pm = json.load(fh)
-            if dom in pm.get('per_launch', {}):
-                roof['traffic'] = pm['per_launch'][dom]['hbm_bytes']
-                roof['traffic_source'] = 'profiles/' + os.path.basename(cand[-1])
+    if pmc_src:
+        roof['traffic_source'] = pmc_src
+    if atari and pmc:
+        tot_tr = sum(per[k]['traffic'] * prof[k]['count'] for k in per if per[k].get('traffic'))
+        tot_alg = sum(per[k]['alg_bytes'] * prof[k]['count'] for k in per if per[k].get('traffic'))
+        if tot_alg > 0:
+            roof['all_gemm_sites_traffic_over_algorithmic'] = tot_tr / tot_alg
     return roof, per
 
 
@@ -404,19 +499,13 @@ def main():
         comm = Comm()
         collective = 'torch.distributed all_reduce (%s), after the backward pass' % backend
         if backend == 'nccl' and os.environ.get('MRL_NATIVE_COMM', '1') != '0':
-            ok, why = 1, ''
-            try:
-                comm.enable_native()
-            except Exception as exc:           # every rank must take the same path: agree on the outcome below
-                ok, why = 0, repr(exc)
-            flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
+            # collective and fail-safe (common/dist.py): id broadcast, communicator creation and a probe all-reduce are each
+            # agreed on by all ranks; any failure leaves every rank on the torch.distributed collectives
+            if comm.enable_native():
                 collective = ('in-library RCCL (mrl_comm): fc1+heads slice all-reduced on a communication stream while the '
                               'conv layers are back-propagated, rest at the end; / total weight, clip, Adam replicated')
             else:
-                comm.native = None
-                collective += ' [in-library RCCL communicator unavailable on some rank: %s]' % why
+                collective += ' [in-library RCCL communicator unavailable on some rank: %s]' % comm.native_error
     else:
         torch.cuda.set_device(0)
 
@@ -452,6 +541,11 @@ def main():
             'loss': res['loss'],
             'roofline': roof,
         }
+        if res.get('self_check'):
+            out['self_check'] = res['self_check']
+        if world > 1:
+            out['params_synced_across_ranks'] = res.get('params_synced')
+            out['config']['native_dp'] = res.get('native_dp')
         if res['graph_mode']:
             out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps); kernel times from a separate eager update'
         if res['prof']:
@@ -470,9 +564,8 @@ def main():
                 others.append({'workload': 'ppo2 update-only %s-shaped %s num_envs=%d nsteps=128'
                                            % (wl, r['hp']['network'], n_envs),
                                'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['dt'] / 3 * 1e3, 'steps': 3,
-                               # power-limited: the sampled shader clock sits well below the 2.4 GHz the nominal peaks are quoted at
-            'device_state': res.get('device_state'),
-            'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / 3),
+                               'device_state': r.get('device_state'),          # this configuration's own rocm-smi samples
+                               'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / 3),
                                'roofline': rf,
                                'kernel_ms_per_step': {k: round(v['ms'] / r['prof_steps'], 3) for k, v in
                                                       sorted(r['prof'].items(), key=lambda kv: -kv[1]['ms'])}})

@@ -7,7 +7,11 @@ c2.dgrad writes exactly its 6.71 GB).  Only kernels whose every dispatch in the 
 largest dispatches of the run (the minibatch launches) are averaged.
 usage: pmc_to_json.py fetch.txt write.txt out.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_sha16      # noqa: E402  (identity of the kernel sources the counters were collected from)
 
 LABELS = {
     'c2.dgrad': 'dgrad_x6_kernel<20, 20, 32',
@@ -72,7 +76,7 @@ def main(fetch_txt, write_txt, out_json):
                 f1, w1 = sum(fv) / len(fv), sum(wv) / len(wv)
                 res[label] = {'fetch_bytes': f1 * 1024 * 2, 'write_bytes': w1 * 1024, 'hbm_bytes': f1 * 1024 * 2 + w1 * 1024,
                               'raw': {'FETCH_SIZE_KB': f1, 'WRITE_SIZE_KB': w1, 'dispatches': len(fv)}}
-    json.dump({'note': __doc__.split('usage')[0].strip(), 'per_launch': res}, open(out_json, 'w'), indent=1)
+    json.dump({'note': __doc__.split('usage')[0].strip(), 'source_sha16': source_sha16(), 'per_launch': res}, open(out_json, 'w'), indent=1)
     for k, v in res.items():
         print('%-10s fetch %.2f GB  write %.2f GB' % (k, v['fetch_bytes'] / 1e9, v['write_bytes'] / 1e9))
 

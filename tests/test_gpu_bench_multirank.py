@@ -1,0 +1,36 @@
+"""GPU: `bench.py --gpus 2` end to end on the one GPU of the test box.
+
+The driver measures the multi-GPU scaling curve by launching bench.py through torch.distributed.run with one rank per GPU
+over RCCL.  RCCL refuses two ranks on one device, so here the same N > 1 code path -- self-relaunch through
+torch.distributed.run, env sharding (common/dist.shard_envs), sync_from_root, one all-reduce(sum) of the flat gradient per
+minibatch step, / total weight -> clip -> Adam replicated, max-over-ranks timing, rank 0 printing ONE JSON line -- runs
+with two processes sharing the device and `MRL_BENCH_BACKEND=gloo` carrying the collectives
+(common/mpi_adam_optimizer.py:18-51, common/mpi_util.py:15-26).  Not a measurement; a does-it-run-and-agree check."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_one_json_line_and_synced_parameters():
+    env = dict(os.environ, MRL_BENCH_BACKEND='gloo', MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--num-envs', '64',
+           '--no-cpu-baseline', '--no-other-configs']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['world_size_observed'] == 2
+    assert d['config']['envs_per_gpu'] == 32 and d['scaling'] == 'strong'
+    assert d['metric'].startswith('env-steps/sec') and d['value'] > 0
+    assert all(abs(x) < 1e6 and x == x for x in d['loss'])                   # finite
+    assert d['params_synced_across_ranks'] is True
+    assert 'gloo' in d['config']['collective']
