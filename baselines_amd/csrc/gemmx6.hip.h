@@ -87,7 +87,7 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 //     cycles during which it feeds nothing to the matrix pipe).
 template <class AF, class EF, int WM, int WN, bool X8, int xd = 0, bool PA = false, bool TR = false, int IL = 0>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
-                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride) {
+                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride, int pg) {
     // xd (timing experiments, builds with -DMRL_X6_EXPERIMENTS, option x6_dbg = 100 + bits): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global loads in the
     // main loop, 8 = no split arithmetic (raw halves are staged), 16 = every step re-reads k tile 0 (cache hits)
     static_assert(WM * WN == 4, "4 waves");
@@ -101,9 +101,12 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     // (9.6 MB for fc1) do not fit the 4 MB L2 and are re-read from the Infinity Cache by every row panel (PMC:
     // 10.6 GB fetched by fc1.dgrad for 1.9 GB of algorithmic reads); giving each XCD a fixed set of column tiles instead
     // keeps the planes L2-resident but makes 8 XCDs fetch every A panel: measured 27 % SLOWER (fc1.dgrad 2.9 -> 3.7 ms).
+    // pg > 1 (option "x6_pg"): pg row panels of an XCD advance through the column tiles TOGETHER (slot order: column tile
+    // major inside a group of pg panels), so that a B tile pulled into the XCD's L2 serves pg row panels instead of one.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int nt_i = slot % ntiles;
-    const long panel = (long)(slot / ntiles) * 8 + xcd;
+    const int gsz = pg * ntiles, grp = slot / gsz, rem = slot - grp * gsz;
+    const int nt_i = rem / pg;
+    const long panel = ((long)grp * pg + (rem - nt_i * pg)) * 8 + xcd;
     if (panel >= (long)mtiles) return;
     const int mt_i = (int)panel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -381,13 +384,15 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
     return hipGetLastError();
 }
 
+inline int& x6_pg() { static int p = getenv("MRL_X6_PG") ? atoi(getenv("MRL_X6_PG")) : 1; return p; }          // mrl_set_option "x6_pg": row panels per pass over the B tiles
 inline int& x6_il() { static int p = getenv("MRL_X6_IL") ? atoi(getenv("MRL_X6_IL")) : 1; return p; }          // mrl_set_option "x6_il": loads interleaved with the MFMAs (TR launches)
 template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, int IL = 0>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
                                      hipStream_t stream, long a_pstride = 0) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
-    const long blocks = ((long)mtiles + 7) / 8 * 8 * ntiles;
+    const int pg = ntiles > 1 ? std::max(1, x6_pg()) : 1;
+    const long blocks = (((long)mtiles + 7) / 8 + pg - 1) / pg * pg * 8 * ntiles;
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
 #ifdef MRL_X6_EXPERIMENTS
@@ -420,7 +425,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride, pg);
     return hipGetLastError();
 }
 // Pre-split operands (planes.hip.h).  PA: A is a plane tensor (af.p = plane 0, a_pstride elements between planes; Bp must

@@ -26,6 +26,7 @@
 #include "gemmx6s.hip.h"
 #include "c1fwd.hip.h"
 #include "wgradx8.hip.h"
+#include "wgradtr.hip.h"
 #include "c1wgrad.hip.h"
 #include "mlpstep.hip.h"
 #include "comm.hip.h"
@@ -305,8 +306,8 @@ static const char* const kOptionEnv[][2] = {
     {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
     {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
     {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}, {"act_planes", "MRL_ACT_PLANES"}, {"x6_il", "MRL_X6_IL"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 2, 76, 1};
+    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}, {"act_planes", "MRL_ACT_PLANES"}, {"x6_il", "MRL_X6_IL"}, {"wgrad_tr", "MRL_WGRAD_TR"}, {"x6_pg", "MRL_X6_PG"}};
+static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 2, 76, 1, 1, 1};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
     for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
@@ -320,6 +321,7 @@ extern "C" int mrl_set_option(const char* name, int value) {
             option_table()[name] = value;
             if (!strcmp(name, "x6_prio")) x6_prio() = value;
             if (!strcmp(name, "x6_il")) x6_il() = value;
+            if (!strcmp(name, "x6_pg")) x6_pg() = value;
             if (!strcmp(name, "x6_dbg")) x6_xd() = value >= 100 ? value - 100 : 0;
             return 0;
         }
@@ -1386,7 +1388,29 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         if (!first && f32_split_mode() == 2 && get_option("wgrad_x8", "MRL_WGRAD_X8", 1) && !tuned(l, "wgrad") && !layer_padded(l) &&
             (uintptr_t)hprev % 16 == 0 && (uintptr_t)dz % 16 == 0 && (l.kind != 0 || ((l.rf * l.C) % 4 == 0 && l.C % 4 == 0)))
             wx = wgrad_x8_plan(rows, l.K, l.N, num_cus(), ws.part_floats, get_option("wgrad_x8", "MRL_WGRAD_X8", 1) >= 2);
-        if (wx.cfg) {
+        // conv2 / conv3 of NatureCNN: image-resident kernel, eight exact bf16 products per multiply, transpose reads
+        // (wgradtr.hip.h); option wgrad_tr = 0 keeps the fp32-MFMA image-resident engine (imgres.hip.h)
+        const bool trw = !first && !wx.cfg && (ik == 2 || ik == 3) && f32_split_mode() == 2 && !tuned(l, "wgrad") &&
+                         (uintptr_t)dz % 16 == 0 && get_option("wgrad_tr", "MRL_WGRAD_TR", 1);
+        if (trw) {
+            int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
+            nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
+            if (nblocks < 1) return MRL_ENOSPC;
+            {
+                char label[40];
+                if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
+                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
+                const int padded = get_option("wgrad_tr", "MRL_WGRAD_TR", 1) >= 2;      // A/B: padded pixel strides
+                hipError_t e;
+                if (padded) e = ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, 32, 64>(hprev, dz, B, ws.part, nblocks, st)
+                                        : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, 64, 64>(hprev, dz, B, ws.part, nblocks, st);
+                else e = ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, 0, 0>(hprev, dz, B, ws.part, nblocks, st)
+                                 : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, 0, 0>(hprev, dz, B, ws.part, nblocks, st);
+                if (e != hipSuccess) return (int)e;
+            }
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
+            if (rc) return rc;
+        } else if (wx.cfg) {
             char label[40];
             if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
             hipError_t e;

@@ -1,0 +1,258 @@
+// Image-resident conv weight gradient on the BF16 matrix pipe with fp32-class products, for gfx950 (MI355X):
+//
+//   dW[(ky,kx,c)][n] = sum over (b, oy, ox) of  X[b, oy*s+ky, ox*s+kx, c] * dz[b, oy, ox, n]
+//   db[n]            = sum over (b, oy, ox) of  dz[b, oy, ox, n]
+//
+// (tf.gradients of a2c/utils.py:37-56 `conv`, taken by ppo2/model.py:100-109) for NatureCNN's conv2 / conv3
+// (common/models.py:21-22).  Replaces the fp32-MFMA engine of imgres.hip.h for these two layers (24 % of the benched step
+// at 0.72 of the fp32 pipe, which is only 0.36 of what the 8-product arithmetic reaches on the bf16 pipe).
+//
+// Arithmetic: the 8-product mode of gemmx6.hip.h -- both operands split EXACTLY into three bf16 planes (truncation split,
+// all residuals exact), 8 of the 9 partial products accumulated in fp32, small terms first; only x2*w2 (< 2^-29 of a
+// product, below one fp32 rounding) is dropped.
+//
+// The contraction index of this GEMM is the output PIXEL, the slow index of both operands in memory, while
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive contraction elements per lane.  The tiled engine (wgradx8.hip.h) transposes
+// in its staging pass and re-splits every input element once per overlapping patch (4x / 9x).  Here instead:
+//   * a persistent workgroup per CU stages a WHOLE image and its dz map once: coalesced 16-byte loads (the next image's
+//     loads stay in flight in registers during the MFMA phase), split ONCE per element, written to LDS in their natural
+//     layout [pixel][plane][channel] with 8-byte stores -- no transpose anywhere in the staging pass;
+//   * the transpose happens in the LDS READ: `ds_read_b64_tr_b16` hands lane (column c, k group) four consecutive
+//     contraction elements of its column from a [4 k][16 c] block whose four k rows are FOUR INDEPENDENT ADDRESSES --
+//     so the four k rows of a block are simply the addresses of four patch pixels, and im2col (stride, tap offset, row
+//     wrap of the output map) costs nothing: per-lane pixel offsets are computed once, taps / planes / channel blocks
+//     are instruction immediates.  No padded "garbage" columns: the contraction runs over the NPIX real output pixels,
+//     rounded up to a multiple of 16 with zero dz rows;
+//   * every wave keeps its TM x TN accumulator tiles (tap x 32 channels  x  32 filters) in registers for the kernel's
+//     lifetime; two barriers per image; one partial slab per workgroup, combined in fixed order by reduce_slabs.
+// Pixel strides are padded so that the four k rows of a transpose read fall into different quarters of the 256-byte
+// bank row (scripts/tr_probe.hip measures the patterns).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hip.h"
+#include "wres.hip.h"      // bf16x8, split2_bf16x3
+
+namespace mrl {
+
+typedef short wt_v4i16 __attribute__((ext_vector_type(4)));
+typedef short wt_v8i16 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) wt_v4i16 wt_lds_v4i16;
+
+// 4 consecutive contraction elements of this lane's column (see the header): source role of lane l inside its 16-lane
+// group: k row (l & 15) >> 2, columns 4 * (l & 3) .. + 3 at the byte address it passes
+__device__ __forceinline__ wt_v4i16 wt_tr_read(const uint8_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_lds_v4i16*)(p));
+}
+__device__ __forceinline__ bf16x8 wt_frag(const wt_v4i16& lo, const wt_v4i16& hi) {
+    const wt_v8i16 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD>
+struct WgTrCfg {
+    static constexpr int OH = (H - RF) / STRIDE + 1, OW = (W - RF) / STRIDE + 1, NPIX = OH * OW;
+    static constexpr int NCH = (NPIX + 15) / 16;                     // contraction chunks of 16 pixels
+    static constexpr int K = RF * RF * C, MT = K / 32, NTN = NF / 32; // 32 x 32 output tiles
+    static constexpr int CB = C / 32;                                // 32-channel blocks per tap
+    static constexpr int NT = WAVES * 64;
+    static constexpr int XPS = 3 * C * 2 + XPAD;                     // bytes per input pixel: [plane][c] bf16 + pad
+    static constexpr int DPS = 3 * NF * 2 + DPAD;                    // bytes per dz pixel:    [plane][n] bf16 + pad
+    static constexpr int X_BYTES = H * W * XPS;
+    static constexpr int D_BYTES = NCH * 16 * DPS;                   // rows NPIX .. NCH*16-1 stay zero
+    static constexpr size_t LDS_BYTES = (size_t)X_BYTES + D_BYTES;
+    static constexpr int XV = H * W * C / 4, DZV = NPIX * NF / 4;     // float4 per image / per dz map
+    static constexpr int NXV = (XV + NT - 1) / NT, NDV = (DZV + NT - 1) / NT;
+    static_assert(C % 32 == 0 && NF % 32 == 0 && K % 32 == 0, "32-wide MFMA tiles");
+    static_assert(WAVES * TM * TN == MT * NTN, "waves x tiles must cover the output exactly");
+    static_assert(NT % (C / 4) == 0 && NT % (NF / 4) == 0, "staging: a thread keeps its channel / filter quad");
+    static_assert(XPS % 8 == 0 && DPS % 8 == 0 && X_BYTES % 16 == 0, "8-byte aligned transpose reads");
+    static_assert(LDS_BYTES <= 160 * 1024, "image + dz planes must fit the CU's LDS");
+    static_assert((RF - 1) * (W + 1) * XPS + 3 * C * 2 < 65536, "tap offsets must fit the DS immediate");
+};
+
+// Wave -> tiles.  The K / 32 m tiles are numbered t = (ky * CB + cb) * RF + kx (CB = C / 32 channel blocks); a wave owns TM
+// consecutive ones -- TM taps kx .. kx + TM - 1 of ONE kernel row and ONE channel block, so their LDS addresses differ by
+// immediates (one pixel stride each) -- and TN consecutive n tiles.
+template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD>
+__global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B,
+                                                              float* __restrict__ part) {
+    using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
+    static_assert(RF % TM == 0, "the m tiles of a wave are taps of one kernel row");
+    extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
+    uint8_t* xs = wt_lds;
+    uint8_t* ds = wt_lds + G::X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NGRP = G::NTN / TN;
+    const int mt0 = (wave / NGRP) * TM, nt0 = (wave % NGRP) * TN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float4 bias4 = f4zero();
+
+    // zero rows of the dz planes behind the map (contraction padding), once
+    for (int e = tid; e < (G::NCH * 16 - G::NPIX) * (G::DPS / 8); e += G::NT)
+        reinterpret_cast<uint2*>(ds + G::NPIX * G::DPS)[e] = make_uint2(0u, 0u);
+
+    // ---- per-lane operand addresses of the transpose reads
+    // lane l: 16-lane group g = l >> 4 -> 16-column half mb = g & 1 of the 32-wide tile, k half hh = g >> 1;
+    // source role p = l & 15 -> k row kr = p >> 2, column quad cq = p & 3.  Read tq (0, 1) of chunk q covers
+    // contraction elements 16 q + 8 hh + 4 tq + kr.
+    const int g = lane >> 4, mb = g & 1, hh = g >> 1, p = lane & 15, kr = p >> 2, cq = p & 3;
+    const int colb = (16 * mb + 4 * cq) * 2;                                    // byte offset of the column quad
+    // m tiles mt0 .. mt0 + TM - 1: kernel row ky, channel block cb, taps kx0 .. kx0 + TM - 1
+    const int ky = mt0 / (G::CB * RF), cb = (mt0 / RF) % G::CB, kx0 = mt0 % RF;
+    const int xbase = (ky * W + kx0) * G::XPS + cb * 64 + colb;
+    int xoff[G::NCH][2];
+#pragma unroll
+    for (int q = 0; q < G::NCH; ++q)
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+            const int r = 16 * q + 8 * hh + 4 * tq + kr;
+            const int rr = r < G::NPIX ? r : 0;                                 // padding rows: any valid pixel (dz is zero)
+            const int oy = rr / G::OW, ox = rr - oy * G::OW;
+            xoff[q][tq] = xbase + (oy * STRIDE * W + ox * STRIDE) * G::XPS;
+        }
+    const int doff = (8 * hh + kr) * G::DPS + nt0 * 64 + colb;                  // + (16 q + 4 tq) * DPS, + plane, + n tile
+    constexpr int A_STEP = G::XPS;                                              // next tap of the kernel row: one pixel
+
+    // ---- staging: global -> registers (16-byte loads) -> split -> LDS [pixel][plane][c]
+    float4 rx[G::NXV], rd[G::NDV];
+    auto issue_loads = [&](int bb) {
+        const float4* gx = reinterpret_cast<const float4*>(x + (long)bb * (H * W * C));
+        const float4* gd = reinterpret_cast<const float4*>(dz + (long)bb * (G::NPIX * NF));
+#pragma unroll
+        for (int q = 0; q < G::NXV; ++q) { const int e = tid + q * G::NT; rx[q] = gx[e < G::XV ? e : G::XV - 1]; }
+#pragma unroll
+        for (int q = 0; q < G::NDV; ++q) { const int e = tid + q * G::NT; rd[q] = gd[e < G::DZV ? e : G::DZV - 1]; }
+    };
+    constexpr int XQ = C / 4, DQ = NF / 4;                     // float4 per pixel
+    const int xw0 = (tid / XQ) * G::XPS + (tid % XQ) * 8;      // + q * (NT / XQ) * XPS
+    const int dw0 = (tid / DQ) * G::DPS + (tid % DQ) * 8;
+    auto write_stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < G::NXV; ++q) {
+            const int e = tid + q * G::NT;
+            if (e < G::XV) {
+                uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+                split2_bf16x3(rx[q].x, rx[q].y, a0x, a1x, a2x);
+                split2_bf16x3(rx[q].z, rx[q].w, a0y, a1y, a2y);
+                uint8_t* d = xs + xw0 + q * (G::NT / XQ) * G::XPS;
+                *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+                *reinterpret_cast<uint2*>(d + C * 2) = make_uint2(a1x, a1y);
+                *reinterpret_cast<uint2*>(d + C * 4) = make_uint2(a2x, a2y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G::NDV; ++q) {
+            const int e = tid + q * G::NT;
+            if (e < G::DZV) {
+                uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+                split2_bf16x3(rd[q].x, rd[q].y, a0x, a1x, a2x);
+                split2_bf16x3(rd[q].z, rd[q].w, a0y, a1y, a2y);
+                uint8_t* d = ds + dw0 + q * (G::NT / DQ) * G::DPS;
+                *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+                *reinterpret_cast<uint2*>(d + NF * 2) = make_uint2(a1x, a1y);
+                *reinterpret_cast<uint2*>(d + NF * 4) = make_uint2(a2x, a2y);
+                bias4.x += rd[q].x; bias4.y += rd[q].y; bias4.z += rd[q].z; bias4.w += rd[q].w;
+            }
+        }
+    };
+
+    int b = blockIdx.x;
+    if (b < B) issue_loads(b);
+    for (; b < B; b += gridDim.x) {
+        __syncthreads();                                   // the previous image's fragment reads are done
+        write_stage();
+        const int bn = b + gridDim.x;
+        if (bn < B) issue_loads(bn);                       // in flight during the MFMA phase
+        __syncthreads();
+        // ---- MFMA phase: NCH chunks of 16 pixels
+#pragma unroll
+        for (int q = 0; q < G::NCH; ++q) {
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const wt_v4i16 lo = wt_tr_read(xs + xoff[q][0] + a * A_STEP + pl * (C * 2));
+                    const wt_v4i16 hi = wt_tr_read(xs + xoff[q][1] + a * A_STEP + pl * (C * 2));
+                    fa[a][pl] = wt_frag(lo, hi);
+                }
+#pragma unroll
+            for (int c = 0; c < TN; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const wt_v4i16 lo = wt_tr_read(ds + doff + (16 * q) * G::DPS + c * 64 + pl * (NF * 2));
+                    const wt_v4i16 hi = wt_tr_read(ds + doff + (16 * q + 4) * G::DPS + c * 64 + pl * (NF * 2));
+                    fb[c][pl] = wt_frag(lo, hi);
+                }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int c = 0; c < TN; ++c) {      // 8 of the 9 partial products, small terms first (gemmx6.hip.h)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[c][1], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[c][2], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[c][0], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[c][1], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[c][2], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[c][0], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[c][1], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[c][0], acc[a][c], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- partial slab of this workgroup: [K][NF] weights then [NF] bias
+    // C/D layout of the 32x32 MFMA: column (filter) = lane & 31, row (m) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const long slab = (long)G::K * NF + NF;
+    float* out = part + (long)blockIdx.x * slab;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = ((ky * RF + kx0 + a) * G::CB + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // K index (ky, kx, c)
+                const int n = (nt0 + c) * 32 + i;
+                out[(long)m * NF + n] = acc[a][c][r];
+            }
+    // bias: thread t owns filter columns (4t % NF .. +3); combine the NT*4/NF threads of a column in fixed order
+    float4* red = reinterpret_cast<float4*>(wt_lds);
+    __syncthreads();
+    red[tid] = bias4;
+    __syncthreads();
+    if (tid < NF) {
+        constexpr int GROUPS = NF / 4;
+        const int gq = tid / 4, comp = tid % 4;
+        float t = 0.f;
+        for (int q = gq; q < G::NT; q += GROUPS) {
+            const float4 v = red[q];
+            t += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+        }
+        out[(long)G::K * NF + tid] = t;
+    }
+}
+
+template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD>
+inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float* part, int nblocks, hipStream_t stream) {
+    using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
+    auto kern = wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part);
+    return hipGetLastError();
+}
+
+}  // namespace mrl

@@ -135,8 +135,9 @@ def arithmetic_mode(_lib):
         sites[s] = nprod
     for s in ('c2.dgrad', 'c3.dgrad'):
         sites[s] = nprod if dg else 0
+    wtr = _lib.get_option('wgrad_tr') if x6 == 2 else 0      # image-resident transpose-read kernel (wgradtr.hip.h)
     for s in ('c2.wgrad', 'c3.wgrad'):
-        sites[s] = 8 if wx >= 2 else 0
+        sites[s] = 8 if (wx >= 2 or wtr) else 0
     sites['fc1.wgrad'] = 8 if wx >= 1 else 0
     text = ('fp32 storage, fp32 accumulation, every product at least as accurate as an IEEE fp32 multiply. '
             'fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise fmaf chain): %s. '

@@ -363,6 +363,9 @@ int mrl_tune_set(const char* label, int variant);
  *   "wgrad_x8"   [MRL_WGRAD_X8, 1]  weight gradients of the fp32-activation layers (conv2, conv3, fc1) on the bf16 pipe with
  *                  eight exact products per multiply (needs f32_bf16x6 = 2): 1 = layers with >= 128 outputs (fc1), 2 = conv2 / conv3
  *                  too (slower than their image-resident fp32 MFMA engine), 0 = fp32 MFMA engines
+ *   "wgrad_tr"   [MRL_WGRAD_TR, 1]  conv2 / conv3 weight gradients of NatureCNN on the image-resident eight-product kernel
+ *                  (wgradtr.hip.h: image and dz map split once, natural LDS layout, operands fetched with LDS transpose
+ *                  reads; needs f32_bf16x6 = 2); 0 = image-resident fp32-MFMA engine (imgres.hip.h)
  *   "c1_wgrad2"  [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
  *                  (c1wgrad.hip.h): 2 = half-image work units, two workgroups per CU; 1 = whole images, one workgroup
  *                  per CU; 0 = per-byte gathers (imgres.hip.h).  Same products.

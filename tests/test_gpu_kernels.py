@@ -295,9 +295,10 @@ def test_engine_options_agree():
         dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
         return g.cpu().numpy(), st.cpu().numpy()
 
-    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'act_planes', 'x6_il')}
+    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'act_planes', 'x6_il', 'wgrad_tr')}
     assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1, 'transposed epilogues + interleaved loads are the default'
     assert defaults['f32_bf16x6'] == 2, 'the default arithmetic of the split engines is the 8-product mode'
+    assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 weight gradients: image-resident transpose-read kernel by default'
     try:
         cnn = ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False)
         # ---- small batches: plain random data
@@ -313,7 +314,7 @@ def test_engine_options_agree():
         # ---- B = 1152 (tiled split engines everywhere they apply), screened minibatch: every entry
         B = 1152
         scr = _problem(B, 21)
-        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0, act_planes=0, x6_il=0)    # all fp32 x fp32 sites on the fp32 MFMA pipe
+        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0, act_planes=0, x6_il=0, wgrad_tr=0)    # all fp32 x fp32 sites on the fp32 MFMA pipe
         g0, s0 = grads(*cnn, B, ref_opts, scr)
         scale = np.abs(g0).max()
         for name, opts, tol in [('8 products (default)', dict(defaults), 3e-6),
@@ -336,9 +337,11 @@ def test_engine_options_agree():
                                 ('8 products, conv1 weight gradient: whole-image workgroups',
                                  dict(defaults, c1_wgrad2=1), 3e-6),
                                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
-                                 dict(defaults, wgrad_x8=0), 3e-6),
+                                 dict(defaults, wgrad_x8=0, wgrad_tr=0), 3e-6),
+                                ('8 products, weight gradients of conv2 / conv3 on the fp32-MFMA image-resident engine',
+                                 dict(defaults, wgrad_tr=0), 3e-6),
                                 ('8 products, weight gradients of conv2 / conv3 on the split engine too',
-                                 dict(defaults, wgrad_x8=2), 3e-6)]:
+                                 dict(defaults, wgrad_x8=2, wgrad_tr=0), 3e-6)]:
             g1, s1 = grads(*cnn, B, opts, scr)
             d = np.abs(g1 - g0)
             assert d.max() <= tol * scale + 1e-9, (name, d.max(), scale, int(d.argmax()))
