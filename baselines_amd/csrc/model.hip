@@ -1392,7 +1392,21 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         // (wgradtr.hip.h); option wgrad_tr = 0 keeps the fp32-MFMA image-resident engine (imgres.hip.h)
         const bool trw = !first && !wx.cfg && (ik == 2 || ik == 3) && f32_split_mode() == 2 && !tuned(l, "wgrad") &&
                          (uintptr_t)dz % 16 == 0 && get_option("wgrad_tr", "MRL_WGRAD_TR", 1);
-        if (trw) {
+        // fully connected layers at training batch sizes: natural-layout staging + transpose reads (wgradtr.hip.h, dense form)
+        WgTrDensePlan wd;
+        if (!first && l.kind == 1 && wx.cfg && get_option("wgrad_tr", "MRL_WGRAD_TR", 1) == 1)
+            wd = wgrad_tr_dense_plan(rows, l.K, l.N, l.K, num_cus(), ws.part_floats);
+        if (wd.mt) {
+            {
+                char label[40];
+                if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
+                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
+                hipError_t e = launch_wgrad_tr_dense(hprev, l.K, dz, ws.part, slab, (int)rows, l.K, l.N, wd, st);
+                if (e != hipSuccess) return (int)e;
+            }
+            rc = reduce_slabs(ws.part, slab, wd.nslab, grads + l.w_off, slab, accumulate, st, &ctx);
+            if (rc) return rc;
+        } else if (trw) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
             nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;
@@ -1400,12 +1414,18 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
                 ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
-                const int padded = get_option("wgrad_tr", "MRL_WGRAD_TR", 1) >= 2;      // A/B: padded pixel strides
+                const int wtv = get_option("wgrad_tr", "MRL_WGRAD_TR", 1);
                 hipError_t e;
-                if (padded) e = ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, 32, 64>(hprev, dz, B, ws.part, nblocks, st)
-                                        : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, 64, 64>(hprev, dz, B, ws.part, nblocks, st);
-                else e = ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, 0, 0>(hprev, dz, B, ws.part, nblocks, st)
-                                 : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, 0, 0>(hprev, dz, B, ws.part, nblocks, st);
+#define MRL_WT(XP2, DP2, XP3, DP3, DBG)                                                                                   \
+    (ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, XP2, DP2, DBG>(hprev, dz, B, ws.part, nblocks, st)       \
+             : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, XP3, DP3, DBG>(hprev, dz, B, ws.part, nblocks, st))
+                switch (wtv) {          // 1: product.  2-4: timing experiments (unpadded pixel strides; phases left out)
+                case 2: e = MRL_WT(0, 0, 0, 0, 0); break;
+                case 3: e = MRL_WT(32, 64, 64, 64, 1); break;
+                case 4: e = MRL_WT(32, 64, 64, 64, 2); break;
+                default: e = MRL_WT(32, 64, 64, 64, 0); break;
+                }
+#undef MRL_WT
                 if (e != hipSuccess) return (int)e;
             }
             rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);

@@ -25,6 +25,9 @@
 //     rounded up to a multiple of 16 with zero dz rows;
 //   * every wave keeps its TM x TN accumulator tiles (tap x 32 channels  x  32 filters) in registers for the kernel's
 //     lifetime; two barriers per image; one partial slab per workgroup, combined in fixed order by reduce_slabs.
+// Measured and dropped (profiles/README.md, r03d): splitting image b+1 in registers in the MIDDLE of the MFMA phase of image b
+// (only the LDS writes left between the barriers) -- 4.78 vs 4.64 ms: VALU issued beside the partner wave's MFMAs is paid in
+// matrix time on this chip (the "SIMD time = MFMA + 4 x VALU" rule of DESIGN.md 3.3), and 250 instead of 170 VGPRs.
 // Pixel strides are padded so that the four k rows of a transpose read fall into different quarters of the 256-byte
 // bank row (scripts/tr_probe.hip measures the patterns).
 #pragma once
@@ -75,7 +78,7 @@ struct WgTrCfg {
 // Wave -> tiles.  The K / 32 m tiles are numbered t = (ky * CB + cb) * RF + kx (CB = C / 32 channel blocks); a wave owns TM
 // consecutive ones -- TM taps kx .. kx + TM - 1 of ONE kernel row and ONE channel block, so their LDS addresses differ by
 // immediates (one pixel stride each) -- and TN consecutive n tiles.
-template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD>
+template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B,
                                                               float* __restrict__ part) {
     using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
@@ -169,11 +172,12 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     if (b < B) issue_loads(b);
     for (; b < B; b += gridDim.x) {
         __syncthreads();                                   // the previous image's fragment reads are done
-        write_stage();
+        if (!(DBG & 1) || b == (int)blockIdx.x) write_stage();      // DBG 1 (timing experiment): stage the first image only
         const int bn = b + gridDim.x;
         if (bn < B) issue_loads(bn);                       // in flight during the MFMA phase
         __syncthreads();
         // ---- MFMA phase: NCH chunks of 16 pixels
+        if (DBG & 2) continue;                             // DBG 2 (timing experiment): no MFMA phase
 #pragma unroll
         for (int q = 0; q < G::NCH; ++q) {
             bf16x8 fa[TM][3], fb[TN][3];
@@ -241,10 +245,10 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     }
 }
 
-template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD>
+template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD, int DBG = 0>
 inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float* part, int nblocks, hipStream_t stream) {
     using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
-    auto kern = wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
+    auto kern = wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD, DBG>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -253,6 +257,225 @@ inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float*
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part);
     return hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// Dense weight gradient (fully connected layers) with the same ingredients:
+//   dW[k][n] = sum_m A[m][k] * dZ[m][n],  db[n] = sum_m dZ[m][n]        (NatureCNN fc1: K = 3136, N = 512, m = sample)
+// replaces the transposed-staging tiles of wgradx8.hip.h (fc1.wgrad 3.7 ms at 0.36 of its pipe; 43 % MFMA-busy, more LDS
+// bank-conflict cycles than half its LDS-active cycles).  Both operands are staged in their NATURAL layout
+// [row m][plane][column] (coalesced 16-byte loads, split while staged, 8-byte LDS stores, no transposing writes) and the
+// contraction-major fragments come out of `ds_read_b64_tr_b16`, whose four k rows are four consecutive samples.
+//   * tile = (MT * 32) x 256 outputs per workgroup of 8 waves, wave w = 32-filter column block w x all MT row blocks:
+//     a 224 x 256 tile (MT = 7) divides fc1 exactly (14 x 2 tiles), splits each A element twice and each dZ element 14
+//     times (128 x 128 tiles: 4 and 25 times) -- 1.4 instead of 2.75 split instructions per MFMA;
+//   * split-K over samples: `nslab` row ranges, one partial slab each (tiles of a slab fill it completely), combined in
+//     fixed order by reduce_slabs; 32 samples per step, the next step's loads in flight in registers during the MFMAs;
+//   * the bias column sums ride on the dZ staging registers of the workgroups of row-tile 0.
+template <int MT>
+struct WgTrDenseCfg {
+    static constexpr int BK = MT * 32, BN = 256, R = 32, NT = 512;
+    static constexpr int ARS = 3 * BK * 2 + 64, BRS = 3 * BN * 2 + 64;      // LDS bytes per sample row: [plane][column] + pad
+    static constexpr int A_BYTES = R * ARS, B_BYTES = R * BRS;
+    static constexpr size_t LDS_BYTES = (size_t)A_BYTES + B_BYTES;
+    static constexpr int AQ = BK / 4, BQ = BN / 4;                           // float4 per row
+    static constexpr int AV = R * AQ, BV = R * BQ;
+    static constexpr int NAV = (AV + NT - 1) / NT, NBV = BV / NT;
+    static_assert(BV % NT == 0 && NT % BQ == 0, "dZ staging: a thread keeps its filter quad");
+    static_assert(LDS_BYTES <= 160 * 1024, "one stage must fit the CU's LDS");
+};
+
+template <int MT>
+__global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __restrict__ A, long lda, const float* __restrict__ dz,
+                                                             float* __restrict__ part, long slab, int M, int K, int N,
+                                                             int ktiles, int ntiles, int rows_per_slab) {
+    using G = WgTrDenseCfg<MT>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
+    uint8_t* as = wt_lds;
+    uint8_t* bs = wt_lds + G::A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = ktiles * ntiles;
+    const int s = blockIdx.x / T, tile = blockIdx.x - s * T;
+    const int kt = tile / ntiles, nt = tile - kt * ntiles;
+    const int k0 = kt * G::BK, n0 = nt * G::BN;
+    const long m_begin = (long)s * rows_per_slab;
+    const long m_end = min((long)M, m_begin + rows_per_slab);
+    const int nsteps = (int)((m_end - m_begin + G::R - 1) / G::R);
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float4 bias4 = f4zero();
+
+    // transpose-read roles (see wgrad_tr_kernel): the four k rows of a read are four consecutive samples
+    const int g = lane >> 4, mb = g & 1, hh = g >> 1, p = lane & 15, kr = p >> 2, cq = p & 3;
+    const uint8_t* abase = as + (8 * hh + kr) * G::ARS + (16 * mb + 4 * cq) * 2;
+    const uint8_t* bbase = bs + (8 * hh + kr) * G::BRS + (16 * mb + 4 * cq) * 2 + wave * 64;
+
+    // staging roles: A float4 e = tid + q * NT -> (row e / AQ, quad e % AQ); dZ: row (tid / BQ) + q * (NT / BQ), quad tid % BQ
+    int arow[G::NAV], aoff[G::NAV];            // sample row inside the step, element offset inside the A row
+#pragma unroll
+    for (int q = 0; q < G::NAV; ++q) {
+        const int e = tid + q * G::NT, ec = e < G::AV ? e : G::AV - 1;
+        arow[q] = ec / G::AQ;
+        aoff[q] = (ec - arow[q] * G::AQ) * 4;
+    }
+    const int brow = tid / G::BQ, boff = (tid % G::BQ) * 4;
+    float4 ra[G::NAV], rb[G::NBV];
+    auto issue_loads = [&](int step) {
+        const long m0 = m_begin + (long)step * G::R;
+#pragma unroll
+        for (int q = 0; q < G::NAV; ++q) {
+            const long m = min(m0 + arow[q], m_end - 1);
+            ra[q] = *reinterpret_cast<const float4*>(A + m * lda + k0 + aoff[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < G::NBV; ++q) {
+            const long m = min(m0 + brow + q * (G::NT / G::BQ), m_end - 1);
+            rb[q] = *reinterpret_cast<const float4*>(dz + m * N + n0 + boff);
+        }
+    };
+    auto write_stage = [&](int step) {
+        const long m0 = m_begin + (long)step * G::R;
+#pragma unroll
+        for (int q = 0; q < G::NAV; ++q) {
+            if (tid + q * G::NT < G::AV) {
+                float4 v = ra[q];
+                if (m0 + arow[q] >= m_end) v = f4zero();                    // rows behind the range contribute nothing
+                uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+                split2_bf16x3(v.x, v.y, a0x, a1x, a2x);
+                split2_bf16x3(v.z, v.w, a0y, a1y, a2y);
+                uint8_t* d = as + arow[q] * G::ARS + aoff[q] * 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+                *reinterpret_cast<uint2*>(d + G::BK * 2) = make_uint2(a1x, a1y);
+                *reinterpret_cast<uint2*>(d + G::BK * 4) = make_uint2(a2x, a2y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G::NBV; ++q) {
+            float4 v = rb[q];
+            const int row = brow + q * (G::NT / G::BQ);
+            if (m0 + row >= m_end) v = f4zero();
+            uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+            split2_bf16x3(v.x, v.y, a0x, a1x, a2x);
+            split2_bf16x3(v.z, v.w, a0y, a1y, a2y);
+            uint8_t* d = bs + row * G::BRS + boff * 2;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+            *reinterpret_cast<uint2*>(d + G::BN * 2) = make_uint2(a1x, a1y);
+            *reinterpret_cast<uint2*>(d + G::BN * 4) = make_uint2(a2x, a2y);
+            bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
+        }
+    };
+
+    if (nsteps > 0) issue_loads(0);
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                                   // the previous step's fragment reads are done
+        write_stage(step);
+        if (step + 1 < nsteps) issue_loads(step + 1);      // in flight during the MFMA phase
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < G::R / 16; ++ch) {
+            bf16x8 fb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const wt_v4i16 lo = wt_tr_read(bbase + (16 * ch) * G::BRS + pl * (G::BN * 2));
+                const wt_v4i16 hi = wt_tr_read(bbase + (16 * ch + 4) * G::BRS + pl * (G::BN * 2));
+                fb[pl] = wt_frag(lo, hi);
+            }
+            // explicit fragment pipeline (row block j + 1 is read while the 8 MFMAs of row block j run); the fences keep the
+            // scheduler from hoisting all 7 row blocks' reads (84 VGPRs) in front of the first MFMA
+            bf16x8 fa[2][3];
+            auto read_a = [&](int j, bf16x8 (&f)[3]) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const wt_v4i16 lo = wt_tr_read(abase + (16 * ch) * G::ARS + pl * (G::BK * 2) + j * 64);
+                    const wt_v4i16 hi = wt_tr_read(abase + (16 * ch + 4) * G::ARS + pl * (G::BK * 2) + j * 64);
+                    f[pl] = wt_frag(lo, hi);
+                }
+            };
+            read_a(0, fa[0]);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                if (j + 1 < MT) read_a(j + 1, fa[(j + 1) & 1]);
+                const bf16x8(&f)[3] = fa[j & 1];
+                // 8 of the 9 partial products, small terms first (gemmx6.hip.h)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], fb[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], fb[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], fb[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], fb[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], fb[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], fb[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], fb[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], fb[0], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- this tile's part of slab s: [K][N] weights then [N] bias
+    float* out = part + (long)s * slab;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(long)m * N + n0 + wave * 32 + i] = acc[j][r];
+        }
+    if (kt == 0) {      // bias: thread t owns filter columns n0 + 4 (t % BQ) .. + 3; the NT / BQ threads of a quad in fixed order
+        float4* red = reinterpret_cast<float4*>(wt_lds);
+        __syncthreads();
+        red[tid] = bias4;
+        __syncthreads();
+        if (tid < G::BN) {
+            const int quad = tid / 4, comp = tid % 4;
+            float t = 0.f;
+            for (int q = quad; q < G::NT; q += G::BQ) {
+                const float4 v = red[q];
+                t += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+            }
+            out[(long)K * N + n0 + tid] = t;
+        }
+    }
+}
+
+struct WgTrDensePlan { int mt = 0, ktiles = 0, ntiles = 0, nslab = 0, rows_per_slab = 0; };
+// usable when the tiles divide the output exactly and the operands allow 16-byte loads
+inline WgTrDensePlan wgrad_tr_dense_plan(long M, int K, int N, long lda, int num_cus, size_t part_floats) {
+    WgTrDensePlan p;
+    if (M < 1024 || M > 0x7fffffffL || N % 256 != 0 || lda % 4 != 0) return p;
+    if (K % 224 == 0) p.mt = 7; else if (K % 256 == 0) p.mt = 8; else return p;
+    p.ktiles = K / (p.mt * 32);
+    p.ntiles = N / 256;
+    const int T = p.ktiles * p.ntiles;
+    const long slab = (long)K * N + N;
+    long S = std::max<long>(1, num_cus / T);
+    S = std::min<long>(S, (long)(part_floats / slab));
+    if (S < 1) { p.mt = 0; return p; }
+    p.rows_per_slab = (int)(((M + S - 1) / S + 31) / 32 * 32);
+    p.nslab = (int)((M + p.rows_per_slab - 1) / p.rows_per_slab);
+    return p;
+}
+
+inline hipError_t launch_wgrad_tr_dense(const float* A, long lda, const float* dz, float* part, long slab, int M, int K, int N,
+                                        const WgTrDensePlan& p, hipStream_t stream) {
+    const unsigned blocks = (unsigned)(p.nslab * p.ktiles * p.ntiles);
+    auto go = [&](auto kern, size_t lds) {
+        static bool raised = false;            // per instantiation (one lambda instantiation per kernel type)
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, stream, A, lda, dz, part, slab, M, K, N, p.ktiles, p.ntiles,
+                           p.rows_per_slab);
+        return hipGetLastError();
+    };
+    if (p.mt == 7) return go(wgrad_tr_dense_kernel<7>, WgTrDenseCfg<7>::LDS_BYTES);
+    return go(wgrad_tr_dense_kernel<8>, WgTrDenseCfg<8>::LDS_BYTES);
 }
 
 }  // namespace mrl
