@@ -346,7 +346,8 @@ inline size_t dgrad_x6_plane_bytes() {
     return (size_t)3 * G::N * G::K * sizeof(uint16_t);
 }
 
-template <int H, int W, int C, int RF, int S, int NF, int WM, int WN>
+// EXP: also instantiate the plane-tensor (PA) forms and the non-interleaved transposed form (experiment builds)
+template <int H, int W, int C, int RF, int S, int NF, int WM, int WN, bool EXP = false>
 inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* hmask, const uint32_t* mbits, float* dx,
                                   int act, int B, uint16_t* planes, bool x8, int num_cus, hipStream_t stream, int dbg = 0,
                                   const uint16_t* dzp = nullptr, uint16_t* dxp = nullptr, bool tr_plain = false) {
@@ -380,11 +381,15 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
         return hipGetLastError();
     };
     if constexpr (C % 32 == 0) {
-        if (pa && tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, true>);
-        if (tr && x6_il()) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, false, true, true>);
-        if (tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, false, true>);
+        if constexpr (EXP) {
+            if (pa && tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, true>);
+            if (tr && !x6_il()) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, false, true>);
+        }
+        if (tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, false, true, true>);
     }
-    if (pa) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, false>);
+    if constexpr (EXP) {
+        if (pa) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, false>);
+    }
     if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);
     return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, false>);
 }

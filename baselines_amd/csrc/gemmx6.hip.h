@@ -384,7 +384,7 @@ inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool tran
     return hipGetLastError();
 }
 
-inline int& x6_pg() { static int p = getenv("MRL_X6_PG") ? atoi(getenv("MRL_X6_PG")) : 1; return p; }          // mrl_set_option "x6_pg": row panels per pass over the B tiles
+inline int& x6_pg() { static int p = getenv("MRL_X6_PG") ? atoi(getenv("MRL_X6_PG")) : 8; return p; }          // mrl_set_option "x6_pg": row panels per pass over the B tiles
 inline int& x6_il() { static int p = getenv("MRL_X6_IL") ? atoi(getenv("MRL_X6_IL")) : 1; return p; }          // mrl_set_option "x6_il": loads interleaved with the MFMAs (TR launches)
 template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, int IL = 0>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
@@ -396,8 +396,8 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
 #ifdef MRL_X6_EXPERIMENTS
-    if (XD == 0 && !PA && !TR && x6_xd() != 0) {
-        switch (x6_xd()) {
+    if constexpr (XD == 0 && !PA && !TR) {
+        if (x6_xd() != 0) switch (x6_xd()) {
         case 1: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 1>(af, Bp, ef, M, N, K, dbg, stream);
         case 2: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 2>(af, Bp, ef, M, N, K, dbg, stream);
         case 3: return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, 3>(af, Bp, ef, M, N, K, dbg, stream);
@@ -416,7 +416,10 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         // 128 x 128 tiles also read the second k half's fragments 8 MFMAs early (IL = 2: fc1.fwd 2.48 -> 2.38 ms, fc1.dgrad
         // 2.88 -> 2.82); the 256 x 64 tiles of the conv layers lose 1 % with that (c2.fwd 4.82 -> 4.87)
         constexpr int ILV = (WM == 2 && WN == 2) ? 2 : 1;
-        if (x6_il()) return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+#ifdef MRL_X6_EXPERIMENTS
+        if (x6_il())
+#endif
+        return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
     }
     auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
     static bool raised = false;                // per instantiation

@@ -23,7 +23,9 @@
 #include "ldsdgrad.hip.h"
 #include "gemmx6.hip.h"
 #include "dgradx6.hip.h"
+#ifdef MRL_X6_EXPERIMENTS
 #include "gemmx6s.hip.h"
+#endif
 #include "c1fwd.hip.h"
 #include "wgradx8.hip.h"
 #include "wgradtr.hip.h"
@@ -37,6 +39,15 @@ using namespace mrl;
 // ============================================================================================
 // host-side layout
 // ============================================================================================
+// Product builds carry the engines the options of include/mrl.h select.  -DMRL_X6_EXPERIMENTS (MRL_BUILD_DEFINES, csrc/build.py)
+// adds the measured-and-dropped variants the A/B scripts and profiles/README.md refer to: the wave-specialised split engine
+// (gemmx6s.hip.h), pre-split plane tensors (act_planes bits 1 / 2 / 32), phase-stamp and phase-omission knobs (*_dbg).
+#ifdef MRL_X6_EXPERIMENTS
+constexpr bool kExp = true;
+#else
+constexpr bool kExp = false;
+#endif
+
 struct Layer {
     int kind;   // 0 conv, 1 fc
     int H, W, C, rf, stride, OH, OW, NF;   // conv
@@ -298,26 +309,41 @@ static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 
 //               only, consumers stage them without split arithmetic (1.5x the operand bytes in 64-byte pieces, 2.5x the
 //               producers' write traffic: c2.fwd 6.3 -> 9.0 ms).  The plane buffers exist only if the bit is set when the
 //               workspace is sized.
-static int act_planes_mode() { return f32_split_mode() == 2 ? get_option("act_planes", "MRL_ACT_PLANES", 76) : 0; }
+static int act_planes_mode() {
+    if (f32_split_mode() != 2) return 0;
+    if (kExp) return get_option("act_planes", "MRL_ACT_PLANES", 76);
+    return get_option("tr_epilogue", "MRL_TR_EPILOGUE", 1) ? 76 : 0;       // product: transposed-accumulator epilogues on / off
+}
 // wave-specialised (producer / consumer) form of the tiled split engines (gemmx6s.hip.h): measured NOT faster than the plain
 // form (two waves of one SIMD share its VALU issue and its matrix pipe: profiles/README.md), kept as an experiment knob
-static int x6_specialised() { return get_option("x6_spec", "MRL_X6_SPEC", 0); }
-static const char* const kOptionEnv[][2] = {
-    {"u8_bf16x3", "MRL_U8_BF16X3"}, {"f32_bf16x6", "MRL_F32_BF16X6"}, {"mlp_fused", "MRL_MLP_FUSED"},
-    {"heads_wave", "MRL_HEADS_WAVE"}, {"dgrad_async", "MRL_DGRAD_ASYNC"}, {"imgres_nacc", "MRL_IMGRES_NACC"},
-    {"mlp_dbg", "MRL_MLP_DBG"}, {"dgrad_dbg", "MRL_DGRAD_DBG"}, {"x6_dbg", "MRL_X6_DBG"}, {"dgrad_x6", "MRL_DGRAD_X6"},
-    {"fused_norm", "MRL_FUSED_NORM"}, {"dgx6_dbg", "MRL_DGX6_DBG"}, {"relu_bits", "MRL_RELU_BITS"}, {"x6_spec", "MRL_X6_SPEC"}, {"x6_prio", "MRL_X6_PRIO"}, {"c1_lds", "MRL_C1_LDS"}, {"c1_dbg", "MRL_C1_DBG"}, {"wgrad_x8", "MRL_WGRAD_X8"}, {"c1_wgrad2", "MRL_C1_WGRAD2"}, {"act_planes", "MRL_ACT_PLANES"}, {"x6_il", "MRL_X6_IL"}, {"wgrad_tr", "MRL_WGRAD_TR"}, {"x6_pg", "MRL_X6_PG"}};
-static const int kOptionDefault[] = {1, 2, 1, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 2, 0, 1, 2, 76, 1, 1, 1};
+static int x6_specialised() { return kExp ? get_option("x6_spec", "MRL_X6_SPEC", 0) : 0; }
+// phase-stamp / phase-omission knobs exist in experiment builds only
+static int dbg_option(const char* name, const char* env) { return kExp ? get_option(name, env, 0) : 0; }
+struct OptionDef { const char* name; const char* env; int dflt; };
+static const OptionDef kOptions[] = {
+    // ---- product options (include/mrl.h)
+    {"u8_bf16x3", "MRL_U8_BF16X3", 1}, {"f32_bf16x6", "MRL_F32_BF16X6", 2}, {"mlp_fused", "MRL_MLP_FUSED", 1},
+    {"heads_wave", "MRL_HEADS_WAVE", 1}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 1},
+    {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 2},
+    {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 2}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
+    {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1},
+#ifdef MRL_X6_EXPERIMENTS
+    // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
+    {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
+    {"x6_dbg", "MRL_X6_DBG", 0}, {"dgx6_dbg", "MRL_DGX6_DBG", 0}, {"x6_spec", "MRL_X6_SPEC", 0}, {"x6_prio", "MRL_X6_PRIO", 0},
+    {"c1_dbg", "MRL_C1_DBG", 0}, {"act_planes", "MRL_ACT_PLANES", 76}, {"x6_il", "MRL_X6_IL", 1},
+#endif
+};
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
-    for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
-        if (!strcmp(kOptionEnv[i][0], name)) { *value_out = get_option(name, kOptionEnv[i][1], kOptionDefault[i]); return 0; }
+    for (const OptionDef& o : kOptions)
+        if (!strcmp(o.name, name)) { *value_out = get_option(name, o.env, o.dflt); return 0; }
     return MRL_EINVAL;
 }
 extern "C" int mrl_set_option(const char* name, int value) {
     if (!name) return MRL_EINVAL;
-    for (size_t i = 0; i < sizeof kOptionEnv / sizeof kOptionEnv[0]; ++i)
-        if (!strcmp(kOptionEnv[i][0], name)) {
+    for (const OptionDef& o : kOptions)
+        if (!strcmp(o.name, name)) {
             option_table()[name] = value;
             if (!strcmp(name, "x6_prio")) x6_prio() = value;
             if (!strcmp(name, "x6_il")) x6_il() = value;
@@ -1063,11 +1089,18 @@ static int gemm_dispatch(const char* lname, const char* pass, int variant, const
     ProfScope ps(label, alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K * ((ksplit >= K) ? zdim : 1), 0.0, st);
     const bool db = variant >= V_COUNT;     // variants V_COUNT.. are the double-buffered forms
     switch (db ? variant - V_COUNT : variant) {
+#ifdef MRL_X6_EXPERIMENTS
 #define MRL_CASE(V, WM, WN, TM, TN)                                                                          \
         case V:                                                                                              \
             e = db ? launch_gemm<AF, BF, EF, WM, WN, TM, TN, true>(af, bf, ef, M, N, K, zdim, ksplit, st)     \
                    : launch_gemm<AF, BF, EF, WM, WN, TM, TN, false>(af, bf, ef, M, N, K, zdim, ksplit, st);   \
             break;
+#else       // product builds: the single-buffered form of every tile shape (the double-buffered forms measured slower)
+#define MRL_CASE(V, WM, WN, TM, TN)                                                                          \
+        case V:                                                                                              \
+            e = launch_gemm<AF, BF, EF, WM, WN, TM, TN, false>(af, bf, ef, M, N, K, zdim, ksplit, st);        \
+            break;
+#endif
         MRL_CASE(V_128x32, 4, 1, 1, 1)
         MRL_CASE(V_256x32, 4, 1, 2, 1)
         MRL_CASE(V_128x64_W41, 4, 1, 1, 2)
@@ -1150,10 +1183,10 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
     ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
     hipError_t e;
-    const int nacc = get_option("imgres_nacc", "MRL_IMGRES_NACC", 0);   // accumulator replicas per wave (experiment knob)
+    const int nacc = kExp ? get_option("imgres_nacc", "MRL_IMGRES_NACC", 0) : 0;   // accumulator replicas per wave (experiment knob)
     const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);          // 0: fp32 MFMA path for the u8 layer
     if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 2)) {
-        e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st, std::max(0, get_option("c1_dbg", "MRL_C1_DBG", 0) - 32));       // both operands transposed while staged (c1wgrad.hip.h)
+        e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st, std::max(0, dbg_option("c1_dbg", "MRL_C1_DBG") - 32));       // both operands transposed while staged (c1wgrad.hip.h)
     } else if (kind == 1 && x3 && !hcur) {
         e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
     } else if (kind == 1) {
@@ -1171,6 +1204,7 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
 }
 
 static bool tuned(const Layer& l, const char* pass);
+template <bool EXP>
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
                          const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st,
                          uint32_t* mbits = nullptr, char* mwrote = nullptr, const uint16_t* hprev_p = nullptr,
@@ -1179,7 +1213,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
     // B * H*W*C for a conv layer); hp_out: where this layer may leave the plane tensor of its own output
     if (mwrote) *mwrote = 0;
     if (hpwrote) *hpwrote = 0;
-    if (!(act_planes_mode() & 1)) { hprev_p = nullptr; hp_out = nullptr; }
+    if (!EXP || !(act_planes_mode() & 1)) { hprev_p = nullptr; hp_out = nullptr; }
     const bool tr_plain = (act_planes_mode() & 4) != 0;        // transposed-accumulator epilogues without plane output
     if (!get_option("relu_bits", "MRL_RELU_BITS", 1)) mbits = nullptr;
     const float* W = params + l.w_off;
@@ -1214,7 +1248,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                                                       (long)B * l.out_elems, (act_planes_mode() & 16) != 0);
                         }
                         return (int)launch_c1fwd_lds(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st,
-                                                     get_option("c1_dbg", "MRL_C1_DBG", 0));
+                                                     dbg_option("c1_dbg", "MRL_C1_DBG"));
                     }
                     if (mbits && l.NF == 32 && l.act == ACT_RELU) { we.mask = mbits; if (mwrote) *mwrote = 1; }
                     return (int)launch_wres_u8x3<WresEpiBiasAct, WRES_PF, 16>(wa, W, we, l.K, l.NF, tiles, num_cus(), st);
@@ -1232,8 +1266,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                     ProfScope ps(label, fl, 0.0, st);
-                    const bool pa = hprev_p && x6 == 2 && l.C % 32 == 0 && !x6_specialised();
-                    const bool trp = hp_out && hpwrote;          // the epilogue also leaves the plane tensor
+                    const bool pa = EXP && hprev_p && x6 == 2 && l.C % 32 == 0 && !x6_specialised();
+                    const bool trp = EXP && hp_out && hpwrote;   // the epilogue also leaves the plane tensor
                     const bool tr = (trp || tr_plain) && x6 == 2 && l.NF % 32 == 0 && l.act == ACT_RELU && !x6_specialised() &&
                                     (uintptr_t)bias % 16 == 0;
                     hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st, pa);
@@ -1248,23 +1282,29 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                             if (mbits) { tf.mask = mbits; if (mwrote) *mwrote = 1; }
                             if (trp) *hpwrote = 1;
                             // MRL_X6_DBG = 10 + layer index: phase stamps of that conv layer's forward land behind the zero page
-                            long long* dbgq = get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
-                            return (int)(pa ? launch_gemm_x6_planes<true, true>(ca, aps, planes, tf, npix, l.NF, l.K, st, dbgq)
-                                            : launch_gemm_x6_planes<false, true>(ca, 0, planes, tf, npix, l.NF, l.K, st, dbgq));
+                            long long* dbgq = dbg_option("x6_dbg", "MRL_X6_DBG") == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
+                            if constexpr (EXP) {
+                                if (pa) return (int)launch_gemm_x6_planes<true, true>(ca, aps, planes, tf, npix, l.NF, l.K, st, dbgq);
+                            }
+                            return (int)launch_gemm_x6_planes<false, true>(ca, 0, planes, tf, npix, l.NF, l.K, st, dbgq);
                         }
-                        EpiBiasAct efp{hout, l.NF, bias, l.act};
-                        if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efp.mask = mbits; if (mwrote) *mwrote = 1; }
-                        return (int)launch_gemm_x6_planes<true, false>(ca, aps, planes, efp, npix, l.NF, l.K, st);
+                        if constexpr (EXP) {
+                            EpiBiasAct efp{hout, l.NF, bias, l.act};
+                            if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efp.mask = mbits; if (mwrote) *mwrote = 1; }
+                            return (int)launch_gemm_x6_planes<true, false>(ca, aps, planes, efp, npix, l.NF, l.K, st);
+                        }
                     }
                     EpiBiasAct efx{hout, l.NF, bias, l.act};
                     if (mbits && l.NF % 32 == 0 && l.act == ACT_RELU) { efx.mask = mbits; if (mwrote) *mwrote = 1; }
+#ifdef MRL_X6_EXPERIMENTS
                     if (x6_specialised()) {
                         // MRL_X6_DBG = 10 + layer index: phase stamps of that conv layer's forward land behind the zero page
-                        long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
+                        long long* dbgp = dbg_option("x6_dbg", "MRL_X6_DBG") == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
                         return (int)launch_gemm_x6s(ca, planes, efx, npix, l.NF, l.K, num_cus(), x6 == 2, st, dbgp);
                     }
+#endif
                     return (int)launch_gemm_x6(ca, planes, efx, npix, l.NF, l.K, st,
-                                               get_option("x6_dbg", "MRL_X6_DBG", 0) == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr, x6 == 2);
+                                               dbg_option("x6_dbg", "MRL_X6_DBG") == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr, x6 == 2);
                 }
                 WresFwdA<false> wa;
                 fill_conv(wa, l, hprev, npix, nullptr);
@@ -1295,25 +1335,31 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
-                const bool pa = hprev_p && f32_split_mode() == 2 && l.K % 32 == 0 && !x6_specialised();
+                const bool pa = EXP && hprev_p && f32_split_mode() == 2 && l.K % 32 == 0 && !x6_specialised();
                 hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st, pa);        // B[n][k] = W[k][n]
                 if (e != hipSuccess) return (int)e;
                 const bool trf = (act_planes_mode() & 64) && f32_split_mode() == 2 && l.act == ACT_RELU && l.N % 32 == 0 && !x6_specialised() &&
                                  (uintptr_t)bias % 16 == 0;
-                if (pa && !trf)
-                    return (int)launch_gemm_x6_planes<true, false>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
-                                                                   (long)B * l.K, planes, ef, B, l.N, l.K, st);
+                if constexpr (EXP) {
+                    if (pa && !trf)
+                        return (int)launch_gemm_x6_planes<true, false>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
+                                                                       (long)B * l.K, planes, ef, B, l.N, l.K, st);
+                }
                 if (trf) {      // transposed-accumulator epilogue (16-byte stores), no mask / planes needed above an fc layer
                     TrBiasRelu tf{hout, l.N, bias, nullptr, nullptr, 0};
-                    long long* dbgq = get_option("x6_dbg", "MRL_X6_DBG", 0) == 1 ? dbgbuf : nullptr;
-                    return (int)(pa ? launch_gemm_x6_planes<true, true>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
-                                                                        (long)B * l.K, planes, tf, B, l.N, l.K, st, dbgq)
-                                    : launch_gemm_x6_planes<false, true>(X6DenseA{hprev, (long)l.K}, 0, planes, tf, B, l.N, l.K, st, dbgq));
+                    long long* dbgq = dbg_option("x6_dbg", "MRL_X6_DBG") == 1 ? dbgbuf : nullptr;
+                    if constexpr (EXP) {
+                        if (pa) return (int)launch_gemm_x6_planes<true, true>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
+                                                                              (long)B * l.K, planes, tf, B, l.N, l.K, st, dbgq);
+                    }
+                    return (int)launch_gemm_x6_planes<false, true>(X6DenseA{hprev, (long)l.K}, 0, planes, tf, B, l.N, l.K, st, dbgq);
                 }
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
-                long long* dbgp = get_option("x6_dbg", "MRL_X6_DBG", 0) == 1 ? dbgbuf : nullptr;
+                long long* dbgp = dbg_option("x6_dbg", "MRL_X6_DBG") == 1 ? dbgbuf : nullptr;
+#ifdef MRL_X6_EXPERIMENTS
                 if (x6_specialised())
                     return (int)launch_gemm_x6s(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, num_cus(), f32_split_mode() == 2, st, dbgp);
+#endif
                 return (int)launch_gemm_x6(X6DenseA{hprev, (long)l.K}, planes, ef, B, l.N, l.K, st, dbgp,
                                            f32_split_mode() == 2);
             }
@@ -1330,7 +1376,7 @@ static int net_forward(const mrl_model* m, const Net& net, const In& in, const f
         const bool hb = i < nw.mbits.size() && i + 1 < net.L.size() && net.L[i + 1].kind == 0;
         const bool hpi = i < nw.hp.size();
         const uint16_t* hprev_p = (i && i - 1 < nw.hp.size() && nw.hpvalid[i - 1]) ? nw.hp[i - 1] : nullptr;
-        int rc = layer_forward(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
+        int rc = layer_forward<kExp>(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
                                hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr, hprev_p, hpi ? nw.hp[i] : nullptr,
                                hpi ? &nw.hpvalid[i] : nullptr);
         if (rc) return rc;
@@ -1350,9 +1396,10 @@ static bool tuned(const Layer& l, const char* pass) {
 }
 
 // backward through one net; nw.dz[last] already holds dloss/d(pre-activation of the last layer)
+template <bool EXP>
 static int net_backward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, Ws& ws,
                         float* grads, int B, int accumulate, hipStream_t st, StepCtx& ctx, bool is_pi) {
-    const bool dzplanes = (act_planes_mode() & (2 | 32)) != 0;     // 32: planes of the last layer's dz only (conversion pass)
+    const bool dzplanes = EXP && (act_planes_mode() & (2 | 32)) != 0;     // 32: planes of the last layer's dz only (conversion pass)
     for (auto& v : nw.dzpvalid) v = 0;
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
@@ -1360,6 +1407,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         // plane tensor of dz[i] (the A operand of this layer's data gradient): written by the data gradient of the layer
         // above, or -- for the last layer, whose dz comes from the heads kernel -- by a conversion pass
         const bool x6dgrad = i > 0 && nw.planes && f32_split_mode() == 2 && !x6_specialised() && !tuned(l, "dgrad");
+        if constexpr (EXP) {
         if (dzplanes && x6dgrad && i == (int)net.L.size() - 1 && (size_t)i < nw.dzp.size() && nw.dzp[i] && l.kind == 1 && B >= 1024 &&
             l.K >= 128 && l.N % 32 == 0 && gemm_x6_ok(dz, l.N, l.N)) {
             ProfScope ps("dz.planes", 0.0, 10.0 * B * l.N, st);
@@ -1367,9 +1415,10 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             if (e != hipSuccess) return (int)e;
             nw.dzpvalid[i] = 1;
         }
+        }
         const uint16_t* dz_p = (dzplanes && x6dgrad && (size_t)i < nw.dzp.size() && nw.dzpvalid[i]) ? nw.dzp[i] : nullptr;
         // where the data gradient may leave the plane tensor of dz[i-1]
-        uint16_t* dx_p = ((act_planes_mode() & 2) && x6dgrad && i >= 2 && (size_t)i - 1 < nw.dzp.size() && net.L[i - 1].act == ACT_RELU) ? nw.dzp[i - 1] : nullptr;
+        uint16_t* dx_p = (EXP && (act_planes_mode() & 2) && x6dgrad && i >= 2 && (size_t)i - 1 < nw.dzp.size() && net.L[i - 1].act == ACT_RELU) ? nw.dzp[i - 1] : nullptr;
         const float* hmask = hprev_of(nw, i);                        // act' source of the layer below
         const float* hprev = i ? nw.h[i - 1] : nullptr;
         const long rows = layer_rows(l, B);
@@ -1419,10 +1468,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
 #define MRL_WT(XP2, DP2, XP3, DP3, DBG)                                                                                   \
     (ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, XP2, DP2, DBG>(hprev, dz, B, ws.part, nblocks, st)       \
              : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, XP3, DP3, DBG>(hprev, dz, B, ws.part, nblocks, st))
-                switch (wtv) {          // 1: product.  2-4: timing experiments (unpadded pixel strides; phases left out)
+                switch (wtv) {
+#ifdef MRL_X6_EXPERIMENTS       // 2-4: timing experiments (unpadded pixel strides; staging / MFMA phase left out)
                 case 2: e = MRL_WT(0, 0, 0, 0, 0); break;
                 case 3: e = MRL_WT(32, 64, 64, 64, 1); break;
                 case 4: e = MRL_WT(32, 64, 64, 64, 2); break;
+#endif
                 default: e = MRL_WT(32, 64, 64, 64, 0); break;
                 }
 #undef MRL_WT
@@ -1534,18 +1585,20 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
                     ProfScope ps(label, fl, 0.0, st);
                     const bool x8 = f32_split_mode() == 2;
-                    const int dbg = get_option("dgx6_dbg", "MRL_DGX6_DBG", 0);
+                    const int dbg = dbg_option("dgx6_dbg", "MRL_DGX6_DBG");
                     // act' of the layer below: its ReLU bit mask when this call's forward pass wrote one, else its fp32 output
                     const uint32_t* bits = ((size_t)i - 1 < nw.mvalid.size() && nw.mvalid[i - 1] && lp.act == ACT_RELU) ? nw.mbits[i - 1] : nullptr;
                     hipError_t e;
+#ifdef MRL_X6_EXPERIMENTS
                     if (x6_specialised() && !dbg)
                         e = lk == 1 ? launch_dgrad_x6s<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st)
                                     : launch_dgrad_x6s<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st);
                     else
+#endif
                     {
                         const bool trpl = (act_planes_mode() & 8) != 0;
-                        e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg, dz_p, dx_p, trpl)
-                                    : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg, dz_p, dx_p, trpl);
+                        e = lk == 1 ? launch_dgrad_x6<20, 20, 32, 4, 2, 64, 2, 2, EXP>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg, dz_p, dx_p, trpl)
+                                    : launch_dgrad_x6<9, 9, 64, 3, 1, 64, 4, 1, EXP>(dz, params + l.w_off, hmask, bits, nw.dz[i - 1], lp.act, B, nw.planes, x8, num_cus(), st, dbg, dz_p, dx_p, trpl);
                         if (dx_p && x8 && !dbg) nw.dzpvalid[i - 1] = 1;
                     }
                     rc = (int)e;
@@ -1557,7 +1610,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     hipError_t e;
                     const float* wsrc = params + l.w_off;
                     // MRL_DGRAD_DBG=<layer index>: phase timestamps of workgroup 0 land behind the zero page
-                    long long* dbgp = get_option("dgrad_dbg", "MRL_DGRAD_DBG", 0) == i ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
+                    long long* dbgp = dbg_option("dgrad_dbg", "MRL_DGRAD_DBG") == i ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
                     // conv2 (4 taps per class: the memory phases are a third of a group): asynchronous variant (LDS-DMA
                     // staging, mask prefetch) 9.05 -> 8.7 ms; conv3 (9 taps): 6.6 -> 6.9 ms, stays on the synchronous kernel
                     // (16 waves x 1 row tile, groups of 6 images; 8 x 2 and two half-size workgroups per CU are slower)
@@ -1595,21 +1648,29 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                                 l.K % 32 == 0 && (uintptr_t)hmask % 16 == 0;
                 hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st, dz_p != nullptr);
                 if (e == hipSuccess && (dz_p || tr)) {
-                    // pre-split operands (planes.hip.h): dz staged from its plane tensor, dz[i-1] leaves with its planes
+                    // transposed-accumulator epilogue; experiment builds: dz staged from its plane tensor, dz[i-1] leaves with
+                    // its planes (planes.hip.h)
                     const X6DenseA da{dz_p ? reinterpret_cast<const float*>(dz_p) : dz, (long)l.N};
                     const long aps = (long)B * l.N;
                     if (tr) {
                         TrMaskRelu tf{nw.dz[i - 1], l.K, hmask, nullptr, dx_p, (long)B * l.K};
-                        e = dz_p ? launch_gemm_x6_planes<true, true>(da, aps, nw.planes, tf, B, l.K, l.N, st)
-                                 : launch_gemm_x6_planes<false, true>(da, 0, nw.planes, tf, B, l.K, l.N, st);
+                        bool done = false;
+                        if constexpr (EXP) {
+                            if (dz_p) { e = launch_gemm_x6_planes<true, true>(da, aps, nw.planes, tf, B, l.K, l.N, st); done = true; }
+                        }
+                        if (!done) e = launch_gemm_x6_planes<false, true>(da, 0, nw.planes, tf, B, l.K, l.N, st);
                         if (e == hipSuccess && dx_p) nw.dzpvalid[i - 1] = 1;
                     } else {
-                        e = launch_gemm_x6_planes<true, false>(da, aps, nw.planes, ef, B, l.K, l.N, st);
+                        if constexpr (EXP) e = launch_gemm_x6_planes<true, false>(da, aps, nw.planes, ef, B, l.K, l.N, st);
                     }
-                } else if (e == hipSuccess)
-                    e = x6_specialised()
-                            ? launch_gemm_x6s(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, num_cus(), f32_split_mode() == 2, st)
-                            : launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr, f32_split_mode() == 2);
+                } else if (e == hipSuccess) {
+#ifdef MRL_X6_EXPERIMENTS
+                    if (x6_specialised())
+                        e = launch_gemm_x6s(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, num_cus(), f32_split_mode() == 2, st);
+                    else
+#endif
+                    e = launch_gemm_x6(X6DenseA{dz, (long)l.N}, nw.planes, ef, B, l.K, l.N, st, nullptr, f32_split_mode() == 2);
+                }
                 rc = (int)e;
             } else {
                 RowKC af{dz, l.N, B, l.N, is_vec(dz, l.N), nullptr};
@@ -1910,7 +1971,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         a.tile_idx = idx;                               // already advanced to the slice (nullptr: direct rows)
         a.srow = nullptr;
         {   // MRL_MLP_DBG=1: phase timestamps of workgroup 0 land in the last 64 bytes of the zero page
-            const int dbgon = get_option("mlp_dbg", "MRL_MLP_DBG", 0);
+            const int dbgon = dbg_option("mlp_dbg", "MRL_MLP_DBG");
             a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
         }
         const size_t lds = mlp_step_lds_bytes(K0, nets);
@@ -2004,8 +2065,8 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         if (m->pi.lstm && (rc = lstm_backward(m->pi, in, params, ws.pi, ws, grads_out, rnn->nseq, Bc / rnn->nseq, rnn->masks,
                                               in.srow, st, ctx)))
             return rc;
-        if ((rc = net_backward(m, m->pi, in, params, ws.pi, ws, grads_out, Bc, accumulate, st, ctx, true))) return rc;
-        if (m->vf_copy && (rc = net_backward(m, m->vf, in, params, ws.vf, ws, grads_out, Bc, accumulate, st, ctx, false)))
+        if ((rc = net_backward<kExp>(m, m->pi, in, params, ws.pi, ws, grads_out, Bc, accumulate, st, ctx, true))) return rc;
+        if (m->vf_copy && (rc = net_backward<kExp>(m, m->vf, in, params, ws.vf, ws, grads_out, Bc, accumulate, st, ctx, false)))
             return rc;
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, st, stats_acc, invB, stats_out);

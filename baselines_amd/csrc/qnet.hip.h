@@ -255,7 +255,7 @@ static int q_heads_forward(const mrl_qnet* q, const Net& net, const float* lat, 
                            hipStream_t st) {
     In in{lat, nullptr};
     for (size_t i = 0; i < net.L.size(); ++i) {
-        int rc = layer_forward(&q->base, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st);
+        int rc = layer_forward<kExp>(&q->base, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st);
         if (rc) return rc;
     }
     return 0;
@@ -313,7 +313,7 @@ static int q_heads_backward(const mrl_qnet* q, const Net& net, const float* lat,
     ws.part = qws.part; ws.part_floats = qws.part_floats; ws.zeros = qws.zeros;
     In in{lat, nullptr};
     StepCtx ctx;
-    int rc = net_backward(&q->base, net, in, params, nw, ws, grads, B, 0, st, ctx, false);
+    int rc = net_backward<kExp>(&q->base, net, in, params, nw, ws, grads, B, 0, st, ctx, false);
     if (rc) return rc;
     // into the latent: dlat (+)= dz0 @ W0^T, masked by act'(latent) when it is the last contribution
     const Layer& l0 = net.L[0];
@@ -363,7 +363,7 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
     mws.part = ws.part; mws.part_floats = ws.part_floats; mws.zeros = ws.zeros;
     In in{obs_t, nullptr};
     StepCtx ctx;
-    return net_backward(&q->base, q->base.pi, in, params, ws.feat, mws, grads_out, B, 0, st, ctx, false);
+    return net_backward<kExp>(&q->base, q->base.pi, in, params, ws.feat, mws, grads_out, B, 0, st, ctx, false);
 }
 
 // per-variable clip_by_norm + Adam (deepq/deepq.py:205-208: tf.train.AdamOptimizer(lr), grad_norm_clipping=10)

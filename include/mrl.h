@@ -339,7 +339,7 @@ int mrl_vecnorm_rew(const float* rews, const uint8_t* news, int N, double* ret, 
  * When enabled every kernel launch of the library is bracketed by hipEvents recorded on the launch
  * stream, accumulated per label ("c1.fwd", "c2.wgrad", "heads", "clip+adam", ...) together with
  * the ALGORITHMIC flops / bytes of the launch.  Reading a label synchronises.
- * This is the only process-global state in the library and is off by default. */
+ * Off by default.  (Process-global state of the library: this table, the engine options and the tile-tuning overrides below.) */
 int mrl_prof_enable(int on);           /* on != 0: clear counters and start; 0: stop */
 int mrl_prof_num_labels(void);
 int mrl_prof_get(int i, char* name, int name_cap, long* count, double* total_ms,
@@ -350,41 +350,38 @@ int mrl_prof_get(int i, char* name, int name_cap, long* count, double* total_ms,
  * (e.g. "c1.fwd"); variant < 0 restores the built-in choice.  Results are identical for every
  * variant of the forward / data-gradient GEMMs; weight-gradient split-K changes summation order. */
 int mrl_tune_set(const char* label, int variant);
-/* Engine options (process-wide; defaults also settable through the environment variable in brackets):
- *   "u8_bf16x3"  [MRL_U8_BF16X3, 1]  first conv layer (uint8 pixels) on the bf16 pipe with an exact 3-way
- *                  bf16 split of the other operand; 0 = fp32 MFMA (bitwise fmaf chain)
- *   "f32_bf16x6" [MRL_F32_BF16X6, 2]  fp32 x fp32 GEMM sites that run on the bf16 pipe with both operands split
- *                  exactly into 3 bf16 planes: 2 = eight products per multiply (what is dropped is < 2^-29 of a
- *                  product, below one fp32 rounding: the default), 1 = six products (< 2^-21), 0 = fp32 MFMA
- *   "dgrad_x6"   [MRL_DGRAD_X6, 1]  conv data gradients on the tiled split engine (position-major tiles);
- *                  0 = LDS-resident fp32-MFMA engine
- *   "relu_bits"  [MRL_RELU_BITS, 1]  conv forward epilogues also write a 1-bit-per-element ReLU mask that the tiled data
- *                  gradient reads instead of the fp32 activations; 0 = fp32 activations
- *   "wgrad_x8"   [MRL_WGRAD_X8, 1]  weight gradients of the fp32-activation layers (conv2, conv3, fc1) on the bf16 pipe with
- *                  eight exact products per multiply (needs f32_bf16x6 = 2): 1 = layers with >= 128 outputs (fc1), 2 = conv2 / conv3
- *                  too (slower than their image-resident fp32 MFMA engine), 0 = fp32 MFMA engines
- *   "wgrad_tr"   [MRL_WGRAD_TR, 1]  conv2 / conv3 weight gradients of NatureCNN on the image-resident eight-product kernel
- *                  (wgradtr.hip.h: image and dz map split once, natural LDS layout, operands fetched with LDS transpose
- *                  reads; needs f32_bf16x6 = 2); 0 = image-resident fp32-MFMA engine (imgres.hip.h)
- *   "c1_wgrad2"  [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
- *                  (c1wgrad.hip.h): 2 = half-image work units, two workgroups per CU; 1 = whole images, one workgroup
- *                  per CU; 0 = per-byte gathers (imgres.hip.h).  Same products.
- *   "c1_lds"     [MRL_C1_LDS, 2]  first conv layer forward on the image-resident engines (whole images staged once in LDS,
- *                  double-buffered): 2 = pixels converted to bf16 while staged, two tiles per wave; 1 = uint8 images,
- *                  converted per fragment; 0 = weights-resident gather engine.  Same products, same sums.
- *   "act_planes" [MRL_ACT_PLANES, 76]  bit set for the eight-product split engines (planes.hip.h).  4 / 8 / 64: transposed-
- *                  accumulator epilogues (16-byte stores, in-lane ReLU mask words) of the hidden conv layers' forward / the
- *                  data gradients / the hidden fc layer's forward; 16: the same in the first conv layer's kernel (slower);
- *                  1 / 2 / 32: experiment -- producers also write pre-split bf16 plane tensors of the activations / of the
- *                  pre-activation gradients / of the last layer's gradient only, which the consumers stage without split
- *                  arithmetic (measured slower; the plane buffers are part of the workspace only if the bit is set when
- *                  mrl_model_workspace_bytes is called).  Same products in every mode.
- *   "x6_il"      [MRL_X6_IL, 1]  the split engines issue the next k tile's global loads between the MFMAs of the current one
- *                  (transposed-epilogue launches); 0 = in a phase of their own
- *   "fused_norm" [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
- *   "mlp_fused"  [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
- *   "heads_wave", "dgrad_async", "imgres_nacc", "mlp_dbg", "dgrad_dbg", "x6_dbg", "dgx6_dbg", "c1_dbg", "x6_spec", "x6_prio": experiment knobs
- * Returns MRL_EINVAL for unknown names.  mrl_get_option reports the value in effect. */
+/* Engine options (process-wide; defaults also settable through the environment variable in brackets).  Every option
+ * selects between engines that compute the SAME products (tests/test_gpu_kernels.py::test_engine_options_agree), except
+ * "f32_bf16x6", which selects the arithmetic of the fp32 x fp32 GEMM sites:
+ *   "f32_bf16x6"  [MRL_F32_BF16X6, 2]  fp32 x fp32 GEMM sites on the bf16 pipe with both operands split exactly into 3 bf16
+ *                  planes: 2 = eight products per multiply (what is dropped is < 2^-29 of a product, below one fp32
+ *                  rounding: the default), 1 = six products (< 2^-21), 0 = fp32 MFMA (bitwise fmaf chain)
+ *   "u8_bf16x3"   [MRL_U8_BF16X3, 1]  first conv layer (uint8 pixels) on the bf16 pipe with an exact 3-way bf16 split of the
+ *                  other operand; 0 = fp32 MFMA
+ *   "tr_epilogue" [MRL_TR_EPILOGUE, 1]  eight-product split engines (hidden conv / fc forward, data gradients) accumulate
+ *                  transposed (D^T = B A^T): a lane owns one output row, 16-byte stores, in-lane ReLU mask words;
+ *                  0 = row-major accumulators, ballot mask words
+ *   "relu_bits"   [MRL_RELU_BITS, 1]  conv forward epilogues also write a 1-bit-per-element ReLU mask that the data gradients
+ *                  read instead of the fp32 activations; 0 = fp32 activations
+ *   "dgrad_x6"    [MRL_DGRAD_X6, 1]  conv data gradients on the position-major tiled split engine; 0 = LDS-resident fp32-MFMA
+ *                  engine ("dgrad_async" [MRL_DGRAD_ASYNC, 1]: its LDS-DMA staging form for conv2)
+ *   "wgrad_tr"    [MRL_WGRAD_TR, 1]  weight gradients of conv2 / conv3 / fc1 on the eight-product transpose-read kernels
+ *                  (wgradtr.hip.h: operands staged in their natural layout, split once, fragments fetched with LDS transpose
+ *                  reads; needs f32_bf16x6 = 2); 0 = "wgrad_x8" / fp32-MFMA engines
+ *   "wgrad_x8"    [MRL_WGRAD_X8, 1]  (wgrad_tr = 0) weight gradients on the transposed-staging tiles of wgradx8.hip.h: 1 = layers
+ *                  with >= 128 outputs (fc1), 2 = conv2 / conv3 too, 0 = image-resident / tiled fp32-MFMA engines
+ *   "c1_wgrad2"   [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
+ *                  (c1wgrad.hip.h): 2 = half-image work units, two workgroups per CU; 1 = whole images; 0 = per-byte gathers
+ *   "c1_lds"      [MRL_C1_LDS, 2]  first conv layer forward on the image-resident engines: 2 = pixels converted to bf16 while
+ *                  staged, two tiles per wave; 1 = uint8 images converted per fragment; 0 = weights-resident gather engine
+ *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
+ *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
+ *   "fused_norm"  [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
+ *   "mlp_fused"   [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
+ *   "heads_wave"  [MRL_HEADS_WAVE, 1]  wave-per-sample loss / head-gradient kernel for the NatureCNN head shape; 0 = generic
+ * Builds with -DMRL_X6_EXPERIMENTS (MRL_BUILD_DEFINES, csrc/build.py) add the measured-and-dropped variants that
+ * profiles/README.md and scripts/ab_options.py refer to ("act_planes", "x6_il", "x6_spec", "*_dbg", ...); they are not part of
+ * the product library.  Returns MRL_EINVAL for unknown names.  mrl_get_option reports the value in effect. */
 int mrl_set_option(const char* name, int value);
 int mrl_get_option(const char* name, int* value_out);
 

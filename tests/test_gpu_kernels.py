@@ -295,53 +295,68 @@ def test_engine_options_agree():
         dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
         return g.cpu().numpy(), st.cpu().numpy()
 
-    defaults = {o: L.get_option(o) for o in ('u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'act_planes', 'x6_il', 'wgrad_tr')}
-    assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1, 'transposed epilogues + interleaved loads are the default'
+    names = ['u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'tr_epilogue',
+             'wgrad_tr', 'x6_pg']
+    # builds with -DMRL_X6_EXPERIMENTS also carry the measured-and-dropped variants (plane tensors, separate load phase)
+    experiments = True
+    try:
+        L.get_option('act_planes')
+        names += ['act_planes', 'x6_il']
+    except Exception:
+        experiments = False
+    defaults = {o: L.get_option(o) for o in names}
+    assert defaults['tr_epilogue'] == 1, 'transposed-accumulator epilogues are the default'
     assert defaults['f32_bf16x6'] == 2, 'the default arithmetic of the split engines is the 8-product mode'
-    assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 weight gradients: image-resident transpose-read kernel by default'
+    assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 / fc1 weight gradients: transpose-read kernels by default'
+    if experiments:
+        assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
     try:
         cnn = ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False)
         # ---- small batches: plain random data
-        for cfg, B, opt, on in [(cnn, 160, 'u8_bf16x3', 1), (cnn, 161, 'c1_lds', 1), (cnn, 163, 'c1_wgrad2', 1),
-                                (cnn, 165, 'act_planes', 76), (cnn, 32, 'act_planes', 79), (cnn, 166, 'act_planes', 28), (cnn, 167, 'x6_il', 1),
-                                (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused', 1),
-                                (('mlp', (4,), np.float32, 'categorical', 2, False), 96, 'mlp_fused', 1)]:
+        small = [(cnn, 160, 'u8_bf16x3', 1), (cnn, 161, 'c1_lds', 1), (cnn, 163, 'c1_wgrad2', 1), (cnn, 165, 'tr_epilogue', 1),
+                 (cnn, 168, 'x6_pg', 8),
+                 (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused', 1),
+                 (('mlp', (4,), np.float32, 'categorical', 2, False), 96, 'mlp_fused', 1)]
+        if experiments:
+            small += [(cnn, 32, 'act_planes', 79), (cnn, 166, 'act_planes', 28), (cnn, 167, 'x6_il', 1)]
+        for cfg, B, opt, on in small:
             g1, s1 = grads(*cfg, B, dict(defaults, **{opt: on}))
-            g0, s0 = grads(*cfg, B, dict(defaults, **{opt: 0}))
+            g0, s0 = grads(*cfg, B, dict(defaults, **{opt: 0 if opt != 'x6_pg' else 1}))
             scale = np.abs(g0).max()
             assert np.abs(g1 - g0).max() <= 2e-6 * scale + 1e-9, (opt, np.abs(g1 - g0).max(), scale)
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
         # ---- B = 1152 (tiled split engines everywhere they apply), screened minibatch: every entry
         B = 1152
         scr = _problem(B, 21)
-        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0, act_planes=0, x6_il=0, wgrad_tr=0)    # all fp32 x fp32 sites on the fp32 MFMA pipe
+        # reference: all fp32 x fp32 sites on the fp32 MFMA pipe
+        ref_opts = dict(defaults, f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0, tr_epilogue=0, wgrad_tr=0, x6_pg=1)
+        if experiments:
+            ref_opts.update(act_planes=0, x6_il=0)
         g0, s0 = grads(*cnn, B, ref_opts, scr)
         scale = np.abs(g0).max()
-        for name, opts, tol in [('8 products (default)', dict(defaults), 3e-6),
-                                ('6 products', dict(defaults, f32_bf16x6=1), 6e-6),
-                                ('8 products, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
-                                ('8 products, act\' from the fp32 activations instead of the ReLU bit masks',
-                                 dict(defaults, relu_bits=0), 3e-6),
-                                ('8 products, row-major accumulators and epilogues (no transposed epilogues)',
-                                 dict(defaults, act_planes=0), 3e-6),
-                                ('8 products, loads in a phase of their own instead of between the MFMAs', dict(defaults, x6_il=0), 3e-6),
-                                ('8 products, plane tensors of the forward activations only', dict(defaults, act_planes=1), 3e-6),
-                                ('8 products, plane tensors of the pre-activation gradients only', dict(defaults, act_planes=2), 3e-6),
-                                ('8 products, plane tensors of both', dict(defaults, act_planes=3), 3e-6),
-                                ('8 products, transposed-accumulator epilogues without plane tensors', dict(defaults, act_planes=28), 3e-6),
-                                ('8 products, transposed-accumulator epilogues incl. fc1 forward, planes of the last dz only', dict(defaults, act_planes=108), 3e-6),
-                                ('8 products, first conv layer on the gather engine instead of the image-resident one',
-                                 dict(defaults, c1_lds=0), 3e-6),
-                                ('8 products, first conv layer forward: the other image-resident kernel',
-                                 dict(defaults, c1_lds=3 - defaults['c1_lds']), 3e-6),
-                                ('8 products, conv1 weight gradient: whole-image workgroups',
-                                 dict(defaults, c1_wgrad2=1), 3e-6),
-                                ('8 products, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
-                                 dict(defaults, wgrad_x8=0, wgrad_tr=0), 3e-6),
-                                ('8 products, weight gradients of conv2 / conv3 on the fp32-MFMA image-resident engine',
-                                 dict(defaults, wgrad_tr=0), 3e-6),
-                                ('8 products, weight gradients of conv2 / conv3 on the split engine too',
-                                 dict(defaults, wgrad_x8=2, wgrad_tr=0), 3e-6)]:
+        cases = [('8 products (default)', dict(defaults), 3e-6),
+                 ('6 products', dict(defaults, f32_bf16x6=1), 6e-6),
+                 ('8 products, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
+                 ('8 products, act\' from the fp32 activations instead of the ReLU bit masks', dict(defaults, relu_bits=0), 3e-6),
+                 ('8 products, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
+                 ('8 products, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
+                 ('8 products, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
+                 ('8 products, first conv layer forward: the other image-resident kernel',
+                  dict(defaults, c1_lds=3 - defaults['c1_lds']), 3e-6),
+                 ('8 products, conv1 weight gradient: whole-image workgroups', dict(defaults, c1_wgrad2=1), 3e-6),
+                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
+                  dict(defaults, wgrad_x8=0, wgrad_tr=0), 3e-6),
+                 ('8 products, conv2 / conv3 weight gradients on the fp32-MFMA image-resident engine, fc1 on the transposed-staging tiles',
+                  dict(defaults, wgrad_tr=0), 3e-6),
+                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the transposed-staging tiles',
+                  dict(defaults, wgrad_x8=2, wgrad_tr=0), 3e-6)]
+        if experiments:
+            cases += [('loads in a phase of their own instead of between the MFMAs', dict(defaults, x6_il=0), 3e-6),
+                      ('plane tensors of the forward activations only', dict(defaults, act_planes=1), 3e-6),
+                      ('plane tensors of the pre-activation gradients only', dict(defaults, act_planes=2), 3e-6),
+                      ('plane tensors of both', dict(defaults, act_planes=3), 3e-6),
+                      ('transposed-accumulator epilogues incl. fc1 forward, planes of the last dz only', dict(defaults, act_planes=108), 3e-6)]
+        for name, opts, tol in cases:
             g1, s1 = grads(*cnn, B, opts, scr)
             d = np.abs(g1 - g0)
             assert d.max() <= tol * scale + 1e-9, (name, d.max(), scale, int(d.argmax()))
