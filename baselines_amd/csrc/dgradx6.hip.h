@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
         for (int p = 0; p < NAP; ++p) {
             const int b = min(b0 + p * 64 + (tid >> 2), B - 1);
-            app[p] = dzp + ((long)(b * OH + yy) * OW + xx) * NF + (tid & 3) * 8;
+            app[p] = dzp + (kPlanesInterleaved ? 3 : 1) * (((long)(b * OH + yy) * OW + xx) * NF) + (tid & 3) * 8;
         }
     } else {
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int p = 0; p < NAP; ++p) rp[pl * NAP + p] = *reinterpret_cast<const u32x4v*>(app[p] + pl * dz_ps + ko);
+                for (int p = 0; p < NAP; ++p) rp[pl * NAP + p] = *reinterpret_cast<const u32x4v*>(app[p] + plane_off(ko, pl, dz_ps));
         } else {
 #pragma unroll
         for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     if constexpr (PA) {
 #pragma unroll
         for (int p = 0; p < NAP; ++p)
-            app[p] = reinterpret_cast<const uint16_t*>(af.p) + af.row_base(min(m0 + p * 64 + (tid >> 2), M - 1)) + (tid & 3) * 8;
+            app[p] = reinterpret_cast<const uint16_t*>(af.p) + (kPlanesInterleaved ? 3 : 1) * af.row_base(min(m0 + p * 64 + (tid >> 2), M - 1)) + (tid & 3) * 8;
     } else {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int p = 0; p < NAP; ++p) rp[pl * NAP + p] = *reinterpret_cast<const u32x4v*>(app[p] + pl * a_pstride + ko);
+                for (int p = 0; p < NAP; ++p) rp[pl * NAP + p] = *reinterpret_cast<const u32x4v*>(app[p] + plane_off(ko, pl, a_pstride));
         } else {
 #pragma unroll
             for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ap[p] + ko);

@@ -33,6 +33,15 @@ __host__ __device__ __forceinline__ long kperm32(long k) { return (k & ~31L) | p
 
 typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
 
+// Plane-tensor addressing.  Planar (round 2): element e of plane pl at pl * pstride + e -- a (row, plane, 32-wide k tile) piece
+// is 64 bytes, half a cache line.  Block-interleaved (round 3): the three planes of each aligned 32-element block sit next
+// to each other, [block][plane][32] = 192 contiguous bytes per (row, k tile): element e of plane pl at
+// 3 * (e & ~31) + 32 * pl + (e & 31).
+constexpr bool kPlanesInterleaved = true;
+__host__ __device__ __forceinline__ long plane_off(long e32 /* offset of an aligned 32-block */, int pl, long pstride) {
+    return kPlanesInterleaved ? 3 * e32 + 32 * pl : pl * pstride + e32;
+}
+
 // ---- epilogue functors of the transposed accumulator layout ---------------------------------------------------------
 // o = element offset of the block's first output in the fp32 tensor (a multiple of 32; the same offset in each plane),
 // cb = its first column, h = lane >> 5.  A kernel's epilogue runs in two passes over its accumulators: first the
@@ -105,7 +114,7 @@ __device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& ac
     if (ef.hp && valid) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            uint16_t* d = ef.hp + pl * ef.pstride + o + 16 * h;
+            uint16_t* d = ef.hp + plane_off(o, pl, ef.pstride) + 16 * h;
             *reinterpret_cast<pl_u32x4*>(d) = pl_u32x4{pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]};
             *reinterpret_cast<pl_u32x4*>(d + 8) = pl_u32x4{pk[pl][4], pk[pl][5], pk[pl][6], pk[pl][7]};
         }
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
         }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            uint16_t* d = hp + pl * pstride + blk * 32 + 16 * hh;
+            uint16_t* d = hp + plane_off(blk * 32, pl, pstride) + 16 * hh;
             *reinterpret_cast<pl_u32x4*>(d) = pl_u32x4{pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]};
             *reinterpret_cast<pl_u32x4*>(d + 8) = pl_u32x4{pk[pl][4], pk[pl][5], pk[pl][6], pk[pl][7]};
         }

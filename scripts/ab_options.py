@@ -62,6 +62,8 @@ for kv in args:
     default = _lib.get_option(name)
     for v in vals.split(','):
         _lib.set_option(name, int(v))
+        model.dm.set_chunk(model.dm.chunk)          # some options change the workspace layout (plane tensors)
         measure('%s=%s' % (name, v))
     _lib.set_option(name, default)
+    model.dm.set_chunk(model.dm.chunk)
 measure('defaults (again)')
