@@ -79,7 +79,7 @@ SIGNATURES = {
     'mrl_qnet_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_qnet_td_grad': (c_int, [c_void_p] * 9 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
-    'mrl_qnet_adam_step': (c_int, [c_void_p] * 5 + [c_float] * 5 + [c_void_p, c_size_t, c_int, c_void_p]),
+    'mrl_qnet_adam_step': (c_int, [c_void_p] * 5 + [c_float, c_void_p] + [c_float] * 4 + [c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_synth_env_obs': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -89,6 +89,7 @@ SIGNATURES = {
     'mrl_segtree_init': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     'mrl_segtree_set': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
     'mrl_segtree_set_ring': (c_int, [c_void_p, c_void_p, c_long, c_long, c_long, c_int, c_double, c_void_p]),
+    'mrl_segtree_set_ring_dev': (c_int, [c_void_p, c_void_p, c_long, c_long, c_long, c_int, c_void_p, c_double, c_void_p]),
     'mrl_per_update_from_td': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_double, c_double, c_void_p,
                                        c_int, c_void_p]),
     'mrl_per_sample': (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_double, c_void_p, c_void_p,

@@ -417,6 +417,15 @@ struct EpiPartial {
     }
 };
 
+// split-K partial products of a FORWARD GEMM (no bias column sums): slab z holds sum over k range z of A[m][k] B[k][n]
+struct EpiPartialPlain {
+    static constexpr bool HAS_BIAS = false;
+    float* part; long slab; int N;
+    __device__ __forceinline__ long addr(int m, int n, int z) const { return (long)z * slab + (long)m * N + n; }
+    __device__ __forceinline__ float aux(long, int) const { return 0.f; }
+    __device__ __forceinline__ void put(long o, float acc, float) const { part[o] = acc; }
+};
+
 // ------------------------------------------------------------------------------------------
 template <class F, int R>
 struct Stage {

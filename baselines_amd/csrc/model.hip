@@ -555,6 +555,22 @@ static int reduce_slabs(const float* part, long slab, int nz, float* out, long n
     return 0;
 }
 
+// second half of a split-K forward layer: out[m][n] = act(bias[n] + sum_z part[z][m][n]), z in fixed order (deterministic)
+__global__ __launch_bounds__(256) void splitk_bias_act_kernel(const float* __restrict__ part, long slab, int nz,
+                                                              const float* __restrict__ bias, int act, float* __restrict__ out,
+                                                              long n, int N) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 3 < nz; z += 4) {
+            s0 += part[(long)z * slab + i]; s1 += part[(long)(z + 1) * slab + i];
+            s2 += part[(long)(z + 2) * slab + i]; s3 += part[(long)(z + 3) * slab + i];
+        }
+        for (; z < nz; ++z) s0 += part[(long)z * slab + i];
+        out[i] = act_fwd(((s0 + s1) + (s2 + s3)) + bias[i % N], act);
+    }
+}
+
 // env-major flat minibatch indices (ppo2.py:160-162, runner.py:69-74) -> time-major storage rows
 __global__ __launch_bounds__(256) void translate_idx_kernel(const int64_t* __restrict__ idx, int B, int T, int N,
                                                             int32_t* __restrict__ srow) {
@@ -1208,7 +1224,8 @@ template <bool EXP>
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
                          const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st,
                          uint32_t* mbits = nullptr, char* mwrote = nullptr, const uint16_t* hprev_p = nullptr,
-                         uint16_t* hp_out = nullptr, char* hpwrote = nullptr) {
+                         uint16_t* hp_out = nullptr, char* hpwrote = nullptr, float* part = nullptr, size_t part_floats = 0) {
+    // part: scratch for split-K partial products (small-batch fully connected layers), part_floats of it
     // hprev_p: plane tensor of hprev written by the layer below in THIS call (plane stride B * K elements for an fc layer,
     // B * H*W*C for a conv layer); hp_out: where this layer may leave the plane tensor of its own output
     if (mwrote) *mwrote = 0;
@@ -1325,6 +1342,27 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
     } else {
         int var = pick_variant(l.name, "fwd", B, l.N);
         EpiBiasAct ef{hout, l.N, bias, l.act};
+        // Small batch, long rows (the Q-network heads at batch 32: 32 x 7744 @ 7744 x 256): an unsplit GEMM is TWO workgroups
+        // walking K = 7744 (0.7 ms).  Split K over ~512 workgroups into partial slabs, then one pass adds them in fixed order,
+        // adds the bias and applies the activation.
+        const RowKC af0{first ? (const float*)in.obs : hprev, l.K, B, l.K, is_vec(first ? in.obs : (const void*)hprev, l.K),
+                        first ? in.srow : nullptr};
+        if (part && B <= 64 && l.K >= 1024 && !tuned(l, "fwd")) {
+            const int ntile = (l.N + 31) / 32;
+            int ns = std::max(1, std::min(512 / ntile, l.K / 128));
+            const int ksplit = ((l.K + ns - 1) / ns + 31) / 32 * 32;
+            ns = (l.K + ksplit - 1) / ksplit;
+            const long slab = (long)B * l.N;
+            if (ns > 1 && (size_t)ns * slab <= part_floats) {
+                EpiPartialPlain ep{part, slab, l.N};
+                int rc = gemm_dispatch(l.name, "fwd", V_128x32, af0, bf, ep, B, l.N, l.K, ns, ksplit, st, 2.0 * B * (double)l.K * l.N);
+                if (rc) return rc;
+                ProfScope ps("splitk_bias_act", 0.0, 4.0 * slab * (ns + 1), st);
+                hipLaunchKernelGGL(splitk_bias_act_kernel, dim3((unsigned)std::min<long>((slab + 255) / 256, 1024)), dim3(256), 0, st,
+                                   part, slab, ns, bias, l.act, hout, slab, l.N);
+                return (int)hipGetLastError();
+            }
+        }
         if (first) {
             RowKC af{(const float*)in.obs, l.K, B, l.K, is_vec(in.obs, l.K), in.srow};
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, B, l.N, l.K, 1, l.K, st);
@@ -1370,7 +1408,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
 }
 
 static int net_forward(const mrl_model* m, const Net& net, const In& in, const float* params, NetWs& nw, int B,
-                       hipStream_t st) {
+                       hipStream_t st, float* part = nullptr, size_t part_floats = 0) {
     for (size_t i = 0; i < net.L.size(); ++i) {
         // bit masks only where a consumer exists: the layer above is a conv whose data gradient the tiled engine computes
         const bool hb = i < nw.mbits.size() && i + 1 < net.L.size() && net.L[i + 1].kind == 0;
@@ -1378,7 +1416,7 @@ static int net_forward(const mrl_model* m, const Net& net, const In& in, const f
         const uint16_t* hprev_p = (i && i - 1 < nw.hp.size() && nw.hpvalid[i - 1]) ? nw.hp[i - 1] : nullptr;
         int rc = layer_forward<kExp>(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
                                hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr, hprev_p, hpi ? nw.hp[i] : nullptr,
-                               hpi ? &nw.hpvalid[i] : nullptr);
+                               hpi ? &nw.hpvalid[i] : nullptr, part, part_floats);
         if (rc) return rc;
     }
     return 0;

@@ -223,9 +223,11 @@ __global__ __launch_bounds__(256) void q_sumsq_kernel(const float* __restrict__ 
 // per-variable tf.clip_by_norm (build_graph.py:416-421: t * clip / max(||t||, clip)) then TF-1 ApplyAdam
 __global__ __launch_bounds__(256) void q_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, QTensorTable tt, const double* __restrict__ part,
-                                                     int npart, float alpha, float beta1, float beta2, float eps, float clip) {
+                                                     int npart, float alpha, const float* __restrict__ alpha_dev, float beta1,
+                                                     float beta2, float eps, float clip) {
     __shared__ float s_scale;
     const int t = blockIdx.y;
+    if (alpha_dev) alpha = alpha_dev[0];      // step size kept in device memory (replayable launch graphs)
     if (threadIdx.x == 0) {
         float scale = 1.f;
         if (clip > 0.f) {
@@ -252,21 +254,22 @@ __global__ __launch_bounds__(256) void q_adam_kernel(float* __restrict__ p, floa
 
 // ---- forward --------------------------------------------------------------------------------------------------------
 static int q_heads_forward(const mrl_qnet* q, const Net& net, const float* lat, const float* params, NetWs& nw, int B,
-                           hipStream_t st) {
+                           hipStream_t st, float* part, size_t part_floats) {
     In in{lat, nullptr};
     for (size_t i = 0; i < net.L.size(); ++i) {
-        int rc = layer_forward<kExp>(&q->base, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st);
+        int rc = layer_forward<kExp>(&q->base, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, part, part_floats);
         if (rc) return rc;
     }
     return 0;
 }
 static int q_forward(const mrl_qnet* q, const float* params, const void* obs, int B, QWs& ws, float* q_out, hipStream_t st) {
     In in{obs, nullptr};
-    int rc = net_forward(&q->base, q->base.pi, in, params, ws.feat, B, st);
+    int rc = net_forward(&q->base, q->base.pi, in, params, ws.feat, B, st, ws.part, ws.part_floats);
     if (rc) return rc;
     const float* lat = ws.feat.h.back();
-    if ((rc = q_heads_forward(q, q->av, lat, params, ws.av, B, st))) return rc;
-    if (q->dueling && (rc = q_heads_forward(q, q->sv, lat, params, ws.sv, B, st))) return rc;
+    if ((rc = q_heads_forward(q, q->av, lat, params, ws.av, B, st, ws.part, ws.part_floats))) return rc;
+    if (q->dueling && (rc = q_heads_forward(q, q->sv, lat, params, ws.sv, B, st, ws.part, ws.part_floats))) return rc;
     hipLaunchKernelGGL(q_dueling_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.av.h.back(),
                        q->dueling ? ws.sv.h.back() : nullptr, q_out, B, q->qd.nact);
     MRL_LAUNCH_CHECK();
@@ -368,8 +371,8 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
 
 // per-variable clip_by_norm + Adam (deepq/deepq.py:205-208: tf.train.AdamOptimizer(lr), grad_norm_clipping=10)
 extern "C" int mrl_qnet_adam_step(const mrl_qnet* q, float* params, float* grads, float* adam_m, float* adam_v, float alpha,
-                                  float beta1, float beta2, float eps, float grad_norm_clipping, void* workspace,
-                                  size_t workspace_bytes, int batch, void* stream) {
+                                  const float* alpha_dev, float beta1, float beta2, float eps, float grad_norm_clipping,
+                                  void* workspace, size_t workspace_bytes, int batch, void* stream) {
     if (!q || !params || !grads || !adam_m || !adam_v || !workspace) return MRL_EINVAL;
     QWs ws;
     q_carve(q, batch, (char*)workspace, ws);
@@ -389,7 +392,7 @@ extern "C" int mrl_qnet_adam_step(const mrl_qnet* q, float* params, float* grads
         MRL_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(q_adam_kernel, dim3(Q_SQ_BLOCKS, tt.n), dim3(256), 0, st, params, grads, adam_m, adam_v, tt, ws.sqpart,
-                       Q_SQ_BLOCKS, alpha, beta1, beta2, eps, grad_norm_clipping);
+                       Q_SQ_BLOCKS, alpha, alpha_dev, beta1, beta2, eps, grad_norm_clipping);
     MRL_LAUNCH_CHECK();
     return 0;
 }

@@ -91,14 +91,26 @@ __global__ __launch_bounds__(256) void tree_fill_kernel(double* __restrict__ sum
 // loop): leaf j is written unless a later entry names the same leaf; then every touched ancestor is
 // recomputed level by level from its two children.  The final tree equals the sequential result
 // because an inner node is always exactly op(left, right) of its current children.
-// One workgroup (levels are separated by __syncthreads); entries are strided over the threads.
 // leaf_mode 0: leaf[j] given (f64); 1: leaf = pow(|td[j]| + eps, alpha) computed here (device pow);
-// ring_mode: idx == nullptr -> leaves (start + j) % maxsize all get leaf_const.
+// ring_mode: idx == nullptr -> leaves (start + j) % maxsize all get leaf_const / max_priority ** alpha.
+//
+// Launch shapes (tree_update below):
+//   * whole tree, one workgroup (sub_shift < 0): small batches, ring ranges, small trees.  Levels are separated by
+//     __syncthreads.
+//   * scattered batch of >= 512 entries into a large tree: the bottom `sub_shift` levels are 2^k independent SUBTREES --
+//     phase 1 gives each subtree to its own workgroup (it filters the batch for its leaves; no inter-workgroup
+//     dependency, 256 CUs issue the scattered 8-byte accesses instead of one), phase 2 (a second launch, one workgroup)
+//     recomputes the few levels above the subtree roots densely and folds the running maximum.  One CU's L2 request rate
+//     was what the single-workgroup form waited for: 16 k scattered loads per level (batch 4096: 230 -> ~40 us).
+// Within a level no two threads write the same node: dense levels name every node once (node = width + t; an untouched
+// node is op(left, right) of unchanged children and keeps its value), ring updates walk index ranges, scattered entries
+// in deep levels are almost always distinct (entries that do share an ancestor recompute it to the same value).
 __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, double* min_tree, long capacity,
                                                            const int32_t* __restrict__ idx, const double* __restrict__ leaf,
                                                            const float* __restrict__ td, double eps, double alpha,
                                                            double* __restrict__ max_priority, long ring_start,
-                                                           long ring_maxsize, double leaf_const, int n) {
+                                                           long ring_maxsize, double leaf_const, int n, int sub_shift,
+                                                           int phase) {
     // 64 KB of LDS: first the duplicate table (open-addressing hash leaf index -> largest entry j that names it), later
     // reused for the running-max reduction
     constexpr int HS = 8192;
@@ -107,12 +119,42 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
     int* hval = hs + HS;
     double* smax = reinterpret_cast<double*>(hs);
     const int tid = threadIdx.x, nt = blockDim.x;
+    const bool sub = phase == 1;                             // this workgroup owns the leaves i with (i >> sub_shift) == blockIdx.x
+    auto mine = [&](long i) { return !sub || (i >> sub_shift) == (long)blockIdx.x; };
+    constexpr int TU = 4;
+    const long DENSE = (long)TU * nt;
+    auto combine = [&](long node) {
+        const double a = tload(sum_tree + 2 * node), b = tload(sum_tree + 2 * node + 1);
+        const double c = tload(min_tree + 2 * node), d = tload(min_tree + 2 * node + 1);
+        tstore(sum_tree + node, __dadd_rn(a, b));
+        tstore(min_tree + node, d < c ? d : c);              // python min(a, b): b only if b < a
+    };
+    if (phase == 2) {
+        // ---- levels above the subtree roots, dense; running maximum over ALL entries (replay_buffer.py:191)
+        if (td && max_priority) {
+            double lmax = 0.0;
+            for (int j = tid; j < n; j += nt) lmax = fmax(lmax, fabs((double)td[j]) + eps);
+            smax[tid] = lmax;
+            __syncthreads();
+            for (int s2 = nt >> 1; s2 > 0; s2 >>= 1) {
+                if (tid < s2) smax[tid] = fmax(smax[tid], smax[tid + s2]);
+                __syncthreads();
+            }
+            if (tid == 0) max_priority[0] = fmax(max_priority[0], smax[0]);
+        }
+        for (long width = capacity >> (sub_shift + 1); width >= 1; width >>= 1) {
+            for (long node = width + tid; node < 2 * width; node += nt) combine(node);
+            __syncthreads();
+        }
+        return;
+    }
     const bool hashed = idx && n <= HS / 2;                 // larger batches: O(n^2) scan below
     if (hashed) {
         for (int e = tid; e < HS; e += nt) { hkey[e] = -1; hval[e] = -1; }
         __syncthreads();
         for (int j = tid; j < n; j += nt) {
             const int key = idx[j];
+            if (!mine(key)) continue;
             int slot = (int)(((unsigned)key * 2654435761u) >> 19) & (HS - 1);
             while (true) {
                 const int prev = atomicCAS(&hkey[slot], -1, key);
@@ -129,6 +171,7 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
         bool write = true;
         if (idx) {
             i = idx[j];
+            if (!mine(i)) continue;
             if (td) {
                 double p = fabs((double)td[j]) + eps;       // deepq.py:302  new_priorities = |td| + eps
                 v = pow(p, alpha);
@@ -146,7 +189,8 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
             }
         } else {
             i = (ring_start + j) % ring_maxsize;
-            v = leaf_const;
+            // device fast path: the leaf is max_priority ** alpha of the RUNNING maximum kept on the device (no host read-back)
+            v = max_priority ? pow(max_priority[0], alpha) : leaf_const;
             // a wrapped ring range cannot name a slot twice unless n > maxsize (rejected on the host)
         }
         if (write) {
@@ -154,25 +198,57 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
             tstore(min_tree + capacity + i, v);
         }
     }
-    if (td && max_priority) {                                // replay_buffer.py:191 running max
+    if (td && max_priority && !sub) {                        // replay_buffer.py:191 running max (phase 2 does it for subtrees)
         __syncthreads();                                     // the duplicate table is dead: its LDS becomes smax
         smax[tid] = lmax;
         __syncthreads();
-        for (int s = nt >> 1; s > 0; s >>= 1) {
-            if (tid < s) smax[tid] = fmax(smax[tid], smax[tid + s]);
+        for (int s2 = nt >> 1; s2 > 0; s2 >>= 1) {
+            if (tid < s2) smax[tid] = fmax(smax[tid], smax[tid + s2]);
             __syncthreads();
         }
         if (tid == 0) max_priority[0] = fmax(max_priority[0], smax[0]);
     }
     __syncthreads();
-    for (long width = capacity >> 1, shift = 1; width >= 1; width >>= 1, ++shift) {
-        for (int j = tid; j < n; j += nt) {
-            long i = idx ? (long)idx[j] : (ring_start + j) % ring_maxsize;
-            long node = (capacity + i) >> shift;
-            double a = tload(sum_tree + 2 * node), b = tload(sum_tree + 2 * node + 1);
-            tstore(sum_tree + node, __dadd_rn(a, b));
-            double c = tload(min_tree + 2 * node), d = tload(min_tree + 2 * node + 1);
-            tstore(min_tree + node, d < c ? d : c);          // python min(a, b): b only if b < a
+    // ring mode: leaves [ring_start, ring_start + n) mod ring_maxsize = up to two leaf ranges
+    const long r0_lo = ring_start, r0_hi = min(ring_start + n, ring_maxsize) - 1;       // inclusive
+    const long r1_hi = ring_start + n - ring_maxsize - 1;                                // second range [0, r1_hi] if >= 0
+    const long top_width = sub ? (capacity >> sub_shift) : 1;                            // last level this launch computes
+    for (long width = capacity >> 1, shift = 1; width >= top_width; width >>= 1, ++shift) {
+        if (!sub && width <= DENSE) {
+            for (long node = width + tid; node < 2 * width; node += nt) combine(node);
+        } else if (!idx) {
+            const long lo0 = (capacity + r0_lo) >> shift, hi0 = (capacity + r0_hi) >> shift;
+            for (long node = lo0 + tid; node <= hi0; node += nt) combine(node);
+            if (r1_hi >= 0) {
+                const long lo1 = capacity >> shift, hi1 = (capacity + r1_hi) >> shift;
+                for (long node = lo1 + tid; node <= hi1; node += nt)
+                    if (node < lo0 || node > hi0) combine(node);
+            }
+        } else {
+            for (int j0 = tid; j0 < n; j0 += TU * nt) {
+                long node[TU];
+                double a[TU], b[TU], c[TU], d[TU];
+                bool on[TU];
+#pragma unroll
+                for (int u = 0; u < TU; ++u) {
+                    const int j = min(j0 + u * nt, n - 1);            // clamped duplicates recompute the last entry's nodes
+                    const long i = idx[j];
+                    on[u] = mine(i);
+                    node[u] = (capacity + i) >> shift;
+                }
+#pragma unroll
+                for (int u = 0; u < TU; ++u)
+                    if (on[u]) {
+                        a[u] = tload(sum_tree + 2 * node[u]); b[u] = tload(sum_tree + 2 * node[u] + 1);
+                        c[u] = tload(min_tree + 2 * node[u]); d[u] = tload(min_tree + 2 * node[u] + 1);
+                    }
+#pragma unroll
+                for (int u = 0; u < TU; ++u)
+                    if (on[u]) {
+                        tstore(sum_tree + node[u], __dadd_rn(a[u], b[u]));
+                        tstore(min_tree + node[u], d[u] < c[u] ? d[u] : c[u]);
+                    }
+            }
         }
         __syncthreads();
     }
@@ -327,10 +403,24 @@ static int tree_update(double* sum_tree, double* min_tree, long capacity, const 
                        const float* td, double eps, double alpha, double* max_priority, long ring_start,
                        long ring_maxsize, double leaf_const, int n, hipStream_t st) {
     if (n <= 0) return 0;
-    int threads = n >= 1024 ? 1024 : (n > 256 ? 512 : 256);
     ProfScope ps("segtree_update", 0.0, 2.0 * n * 16.0 * 21.0, st);
+    constexpr int NSUB_LOG2 = 8;                                  // 256 subtrees
+    if (idx && n >= 512 && capacity >= (1L << (NSUB_LOG2 + 10))) {
+        // scattered batch into a large tree: one workgroup per subtree, then the levels above the subtree roots
+        int levels = 0;
+        while ((1L << levels) < capacity) ++levels;
+        const int sub_shift = levels - NSUB_LOG2;                 // leaves per subtree = 2^sub_shift
+        hipLaunchKernelGGL(tree_update_kernel, dim3(1 << NSUB_LOG2), dim3(256), 0, st, sum_tree, min_tree, capacity, idx, leaf, td,
+                           eps, alpha, max_priority, ring_start, ring_maxsize, leaf_const, n, sub_shift, 1);
+        MRL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(256), 0, st, sum_tree, min_tree, capacity, idx, leaf, td, eps, alpha,
+                           max_priority, ring_start, ring_maxsize, leaf_const, n, sub_shift, 2);
+        MRL_LAUNCH_CHECK();
+        return 0;
+    }
+    int threads = n >= 1024 ? 1024 : (n > 256 ? 512 : 256);
     hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(threads), 0, st, sum_tree, min_tree, capacity, idx, leaf, td, eps,
-                       alpha, max_priority, ring_start, ring_maxsize, leaf_const, n);
+                       alpha, max_priority, ring_start, ring_maxsize, leaf_const, n, -1, 0);
     MRL_LAUNCH_CHECK();
     return 0;
 }
@@ -348,6 +438,17 @@ extern "C" int mrl_segtree_set_ring(double* sum_tree, double* min_tree, long cap
         return MRL_EINVAL;
     return tree_update(sum_tree, min_tree, capacity, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr, start, maxsize, leaf, n,
                        (hipStream_t)stream);
+}
+
+// replay_buffer.py:100-105 `add` on the device fast path: the new slots get max_priority ** alpha with the running maximum
+// that mrl_per_update_from_td maintains in device memory
+extern "C" int mrl_segtree_set_ring_dev(double* sum_tree, double* min_tree, long capacity, long start, long maxsize, int n,
+                                        const double* max_priority, double alpha, void* stream) {
+    if (!sum_tree || !min_tree || !pow2(capacity) || maxsize <= 0 || maxsize > capacity || start < 0 || start >= maxsize ||
+        n < 0 || n > maxsize || !max_priority)
+        return MRL_EINVAL;
+    return tree_update(sum_tree, min_tree, capacity, nullptr, nullptr, nullptr, 0.0, alpha, const_cast<double*>(max_priority),
+                       start, maxsize, 0.0, n, (hipStream_t)stream);
 }
 
 extern "C" int mrl_per_update_from_td(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,

@@ -63,11 +63,58 @@ def load_act(path):
     return ActWrapper.load_act(path)
 
 
+class _Checkpointer(object):
+    """Best-mean-reward snapshot of the reference's loop (deepq.py:237-258, 315-333): every `checkpoint_freq` steps the
+    variables are saved when the 100-episode mean improved; at the end the best snapshot is restored.  The reference
+    round-trips through a file in a temporary directory; here the snapshot also stays in memory, and a model file found in
+    `checkpoint_path` at start-up counts as a saved model (it is what gets reloaded at the end unless a better one is
+    written, like the reference's `load_variables(model_file)`)."""
+
+    def __init__(self, model, act, checkpoint_path, verbose):
+        self.model, self.act, self.verbose = model, act, verbose
+        self.model_file = os.path.join(checkpoint_path, 'model') if checkpoint_path else None
+        self.best_mean_reward = None
+        self.snapshot = None
+
+    def load_existing(self, load_path):
+        import joblib
+        if self.model_file and os.path.exists(self.model_file):
+            self.model.load_variables(joblib.load(self.model_file))
+            self.snapshot = self.model.variables()
+            logger.info('Loaded model from {}'.format(self.model_file))
+        elif load_path is not None:
+            self.model.load_variables(joblib.load(os.path.expanduser(load_path)))
+            logger.info('Loaded model from {}'.format(load_path))
+
+    def maybe_save(self, mean_reward):
+        if self.best_mean_reward is not None and not mean_reward > self.best_mean_reward:
+            return
+        if self.verbose:
+            logger.info('Saving model due to mean reward increase: {} -> {}'.format(self.best_mean_reward, mean_reward))
+        self.snapshot = self.model.variables()
+        if self.model_file:
+            self.act.save(self.model_file)
+        self.best_mean_reward = mean_reward
+
+    def restore_best(self):
+        if self.snapshot is None:
+            return
+        if self.verbose:
+            logger.info('Restored model with mean reward: {}'.format(self.best_mean_reward))
+        self.model.load_variables(self.snapshot)
+
+
 def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=50000, exploration_fraction=0.1,
           exploration_final_eps=0.02, train_freq=1, batch_size=32, print_freq=100, checkpoint_freq=10000,
           checkpoint_path=None, learning_starts=1000, gamma=1.0, target_network_update_freq=500, prioritized_replay=False,
           prioritized_replay_alpha=0.6, prioritized_replay_beta0=0.4, prioritized_replay_beta_iters=None,
           prioritized_replay_eps=1e-6, param_noise=False, callback=None, load_path=None, **network_kwargs):
+    """deepq/deepq.py:95-333.  The local names the reference exposes to `callback(locals(), globals())` (t, obs, action,
+    rew, new_obs, done, episode_rewards, replay_buffer, exploration, ...) keep their names.
+
+    Data path of a train step: everything stays in HBM -- `sample_dev` gathers the minibatch on the device,
+    `QModel.train_dev` replays the captured optimizer step and leaves the TD errors on the device, and
+    `update_priorities_from_td` turns them into priorities there (deepq.py:291-303 without the reference's host arrays)."""
     if param_noise:
         raise NotImplementedError('parameter-space noise is outside the supported hot path')
     set_global_seeds(seed)
@@ -90,72 +137,45 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
     model.update_target()
 
     episode_rewards = [0.0]
-    saved_mean_reward = None
     obs = env.reset()
-    model_file = os.path.join(checkpoint_path, 'model') if checkpoint_path else None
-    model_saved = False
-    saved_variables = None
-    if model_file and os.path.exists(model_file):
-        import joblib
-        model.load_variables(joblib.load(model_file))
-        logger.info('Loaded model from {}'.format(model_file))
-        model_saved = True
-    elif load_path is not None:
-        import joblib
-        model.load_variables(joblib.load(os.path.expanduser(load_path)))
-        logger.info('Loaded model from {}'.format(load_path))
+    checkpoints = _Checkpointer(model, act, checkpoint_path, print_freq is not None)
+    checkpoints.load_existing(load_path)
+
+    def train_step(t):
+        if prioritized_replay:
+            o1, a, r, o2, d, w, idx = replay_buffer.sample_dev(batch_size, beta=beta_schedule.value(t))
+            td = model.train_dev(o1, a, r, o2, d, w)
+            replay_buffer.update_priorities_from_td(idx, td, eps=prioritized_replay_eps)
+        else:
+            o1, a, r, o2, d = replay_buffer.sample_dev(batch_size)
+            model.train_dev(o1, a, r, o2, d, model.ones(batch_size))
 
     for t in range(total_timesteps):
-        if callback is not None:
-            if callback(locals(), globals()):
-                break
-        update_eps = exploration.value(t)
-        action = act(np.array(obs)[None], update_eps=update_eps)[0]
+        if callback is not None and callback(locals(), globals()):
+            break
+        action = act(np.array(obs)[None], update_eps=exploration.value(t))[0]
         new_obs, rew, done, _ = env.step(action)
         replay_buffer.add(obs, action, rew, new_obs, float(done))
         obs = new_obs
-
         episode_rewards[-1] += rew
         if done:
             obs = env.reset()
             episode_rewards.append(0.0)
 
-        if t > learning_starts and t % train_freq == 0:
-            if prioritized_replay:
-                experience = replay_buffer.sample(batch_size, beta=beta_schedule.value(t))
-                (obses_t, actions, rewards, obses_tp1, dones, weights, batch_idxes) = experience
-            else:
-                obses_t, actions, rewards, obses_tp1, dones = replay_buffer.sample(batch_size)
-                weights, batch_idxes = np.ones_like(rewards), None
-            td_errors = model.train(obses_t, actions, rewards, obses_tp1, dones, weights)
-            if prioritized_replay:
-                new_priorities = np.abs(td_errors) + prioritized_replay_eps
-                replay_buffer.update_priorities(batch_idxes, new_priorities)
-
-        if t > learning_starts and t % target_network_update_freq == 0:
+        learning = t > learning_starts
+        if learning and t % train_freq == 0:
+            train_step(t)
+        if learning and t % target_network_update_freq == 0:
             model.update_target()
 
-        mean_100ep_reward = round(np.mean(episode_rewards[-101:-1]), 1) if len(episode_rewards) > 1 else float('nan')
         num_episodes = len(episode_rewards)
-        if done and print_freq is not None and len(episode_rewards) % print_freq == 0:
-            logger.record_tabular('steps', t)
-            logger.record_tabular('episodes', num_episodes)
-            logger.record_tabular('mean 100 episode reward', mean_100ep_reward)
-            logger.record_tabular('% time spent exploring', int(100 * exploration.value(t)))
+        mean_100ep_reward = round(np.mean(episode_rewards[-101:-1]), 1) if num_episodes > 1 else float('nan')
+        if done and print_freq is not None and num_episodes % print_freq == 0:
+            for key, value in (('steps', t), ('episodes', num_episodes), ('mean 100 episode reward', mean_100ep_reward),
+                               ('% time spent exploring', int(100 * exploration.value(t)))):
+                logger.record_tabular(key, value)
             logger.dump_tabular()
-
-        if checkpoint_freq is not None and t > learning_starts and num_episodes > 100 and t % checkpoint_freq == 0:
-            if saved_mean_reward is None or mean_100ep_reward > saved_mean_reward:
-                if print_freq is not None:
-                    logger.info('Saving model due to mean reward increase: {} -> {}'.format(saved_mean_reward,
-                                                                                           mean_100ep_reward))
-                saved_variables = model.variables()
-                if model_file:
-                    act.save(model_file)
-                model_saved = True
-                saved_mean_reward = mean_100ep_reward
-    if model_saved and saved_variables is not None:
-        if print_freq is not None:
-            logger.info('Restored model with mean reward: {}'.format(saved_mean_reward))
-        model.load_variables(saved_variables)
+        if checkpoint_freq is not None and learning and num_episodes > 100 and t % checkpoint_freq == 0:
+            checkpoints.maybe_save(mean_100ep_reward)
+    checkpoints.restore_best()
     return act

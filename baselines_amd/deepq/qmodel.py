@@ -9,6 +9,7 @@
 Parameters, Adam slots and the target copy are flat fp32 device buffers in TF variable-creation order; the work is done
 by libmrl's C ABI (mrl_qnet_values / mrl_qnet_act / mrl_qnet_td_grad / mrl_qnet_adam_step, include/mrl.h)."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -83,6 +84,8 @@ class QModel(object):
         self._set_batch(max_batch)
         self._td = torch.empty(self.max_batch, dtype=torch.float32, device=self.device)
         self._loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._graphs = {}                                # batch size -> captured optimizer step (train_dev)
+        self._ones = {}
 
     def _initial_parameters(self):
         """common.models networks: orthogonal init from the global NumPy stream like the reference (a2c/utils.py:20-35);
@@ -162,29 +165,87 @@ class QModel(object):
             self.eps = float(update_eps)
         return a.cpu().numpy().astype(np.int64)
 
-    def train(self, obs_t, action, reward, obs_tp1, done, weight):
-        """one optimizer step; returns td_errors f32 [B] (build_graph.py:430-441)"""
-        o1, o2 = self._obs(obs_t), self._obs(obs_tp1)
-        B = o1.shape[0]
-        self._set_batch(B)
-        f = lambda x, dt: (x.to(self.device, dt) if isinstance(x, torch.Tensor)
-                           else torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(self.device).to(dt)).contiguous()
-        a, r, d, w = f(action, torch.int32), f(reward, torch.float32), f(done, torch.float32), f(weight, torch.float32)
-        td = torch.empty(B, dtype=torch.float32, device=self.device)
+    def _next_alpha(self):
+        """TF-1 Adam step size of this step + the beta-power update (host f32 arithmetic like the slot variables)"""
+        one = np.float32(1)
+        alpha = np.float32(self.lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
+        self.beta1_power = np.float32(self.beta1_power * self.beta1)
+        self.beta2_power = np.float32(self.beta2_power * self.beta2)
+        return alpha
+
+    def _step_launches(self, o1, a, r, o2, d, w, td, B, alpha, alpha_dev):
+        """the launches of one optimizer step (build_graph.py:380-421) on the current stream"""
         check(self.lib.mrl_qnet_td_grad(self.handle, ptr(self.params), ptr(self.target), ptr(o1), ptr(a), ptr(r), ptr(o2),
                                         ptr(d), ptr(w), self.gamma, int(self.double_q), B, ptr(self.grads), ptr(td),
                                         ptr(self._loss), ptr(self.workspace), self.workspace.numel(), stream_ptr()),
               'mrl_qnet_td_grad')
-        one = np.float32(1)
-        alpha = np.float32(self.lr) * np.sqrt(one - self.beta2_power) / (one - self.beta1_power)
         check(self.lib.mrl_qnet_adam_step(self.handle, ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
-                                          float(alpha), float(self.beta1), float(self.beta2), float(self.epsilon),
-                                          self.grad_norm_clipping, ptr(self.workspace), self.workspace.numel(),
-                                          self.max_batch, stream_ptr()), 'mrl_qnet_adam_step')
-        self.beta1_power = np.float32(self.beta1_power * self.beta1)
-        self.beta2_power = np.float32(self.beta2_power * self.beta2)
-        self.last_td = td
-        return td.cpu().numpy()
+                                          float(alpha), ptr(alpha_dev), float(self.beta1), float(self.beta2),
+                                          float(self.epsilon), self.grad_norm_clipping, ptr(self.workspace),
+                                          self.workspace.numel(), self.max_batch, stream_ptr()), 'mrl_qnet_adam_step')
+
+    def train_dev(self, obs_t, action, reward, obs_tp1, done, weight, graph=True):
+        """One optimizer step on DEVICE tensors (obs in the network's dtype, action int32, the rest f32); returns the device
+        td_errors f32 [B] without a host round trip -- `PrioritizedReplayBuffer.update_priorities_from_td` consumes them.
+
+        The ~70 small launches of a batch-32 step (three forward passes, one backward, per-variable clip, Adam) are
+        launch-latency-bound, so by default the step is captured ONCE per batch size as a hipGraph that reads its inputs
+        from static device buffers and its Adam step size from a device word, and is replayed afterwards."""
+        obs_t, obs_tp1 = self._obs(obs_t), self._obs(obs_tp1)     # one-hot / dtype / shape as the network wants them (no-ops else)
+        B = int(obs_t.shape[0])
+        self._set_batch(B)
+        if not graph or os.environ.get('MRL_DQN_GRAPH', '1') == '0' or _lib.prof_enabled():
+            td = torch.empty(B, dtype=torch.float32, device=self.device)
+            self._step_launches(obs_t, action, reward, obs_tp1, done, weight, td, B, self._next_alpha(), None)
+            self.last_td = td
+            return td
+        g = self._graphs.get(B)
+        if g is None:
+            g = dict(o1=torch.empty_like(obs_t), o2=torch.empty_like(obs_tp1),
+                     a=torch.empty(B, dtype=torch.int32, device=self.device),
+                     r=torch.empty(B, dtype=torch.float32, device=self.device),
+                     d=torch.empty(B, dtype=torch.float32, device=self.device),
+                     w=torch.empty(B, dtype=torch.float32, device=self.device),
+                     td=torch.empty(B, dtype=torch.float32, device=self.device),
+                     alpha=torch.zeros(1, dtype=torch.float32, device=self.device), graph=None, ws=self.workspace.data_ptr())
+            self._graphs[B] = g
+        for k, src in (('o1', obs_t), ('o2', obs_tp1), ('a', action), ('r', reward), ('d', done), ('w', weight)):
+            g[k].copy_(src)
+        g['alpha'].fill_(float(self._next_alpha()))
+        if g['graph'] is None or g['ws'] != self.workspace.data_ptr():
+            # first step at this batch size: run it eagerly from the static buffers (also warms every kernel up), capture the
+            # launch sequence for the following steps
+            self._step_launches(g['o1'], g['a'], g['r'], g['o2'], g['d'], g['w'], g['td'], B, 0.0, g['alpha'])
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            try:                                         # (stream capture records the launches, it does not execute them)
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    self._step_launches(g['o1'], g['a'], g['r'], g['o2'], g['d'], g['w'], g['td'], B, 0.0, g['alpha'])
+                g['graph'], g['ws'] = graph, self.workspace.data_ptr()
+            except Exception as exc:                     # capture unsupported here: stay eager
+                import warnings
+                warnings.warn('DQN step graph capture failed (%s); using eager launches' % (exc,))
+                g['graph'], g['ws'] = False, self.workspace.data_ptr()
+        elif g['graph'] is False:
+            self._step_launches(g['o1'], g['a'], g['r'], g['o2'], g['d'], g['w'], g['td'], B, 0.0, g['alpha'])
+        else:
+            g['graph'].replay()
+        self.last_td = g['td']
+        return g['td']
+
+    def train(self, obs_t, action, reward, obs_tp1, done, weight):
+        """one optimizer step; returns td_errors f32 [B] on the host (build_graph.py:430-441)"""
+        f = lambda x, dt: (x.to(self.device, dt) if isinstance(x, torch.Tensor)
+                           else torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(self.device).to(dt)).contiguous()
+        a, r, d, w = f(action, torch.int32), f(reward, torch.float32), f(done, torch.float32), f(weight, torch.float32)
+        return self.train_dev(obs_t, a, r, obs_tp1, d, w).cpu().numpy()
+
+    def ones(self, n):
+        """importance weights of uniform replay (deepq.py:297: np.ones_like(rewards)) as a cached device tensor"""
+        t = self._ones.get(n)
+        if t is None:
+            t = self._ones[n] = torch.ones(n, dtype=torch.float32, device=self.device)
+        return t
 
     def update_target(self):
         self.target.copy_(self.params)

@@ -109,6 +109,12 @@ class ReplayBuffer(object):
         idxes = [random.randint(0, self._len - 1) for _ in range(batch_size)]
         return self._encode_sample(idxes)
 
+    def sample_dev(self, batch_size):
+        """the same draw (same `random` stream, same indices) with the minibatch left on the device:
+        -> (obs_t, actions int32, rewards f32, obs_tp1, dones f32) device tensors"""
+        idxes = [random.randint(0, self._len - 1) for _ in range(batch_size)]
+        return self._gather_dev(torch.as_tensor(np.asarray(idxes, dtype=np.int32), device=self.device))
+
 
 class PrioritizedReplayBuffer(ReplayBuffer):
     def __init__(self, size, alpha, device=None):
@@ -133,7 +139,14 @@ class PrioritizedReplayBuffer(ReplayBuffer):
 
     def add_batch(self, *args):
         start, n = super().add_batch(*args)
-        leaf = self._current_max_priority() ** self._alpha            # replay_buffer.py:100-105
+        if self._max_priority_dev is not None:
+            # device fast path in use: the running maximum lives in device memory (update_priorities_from_td); the new
+            # leaves are computed from it there -- no host read-back per `add`
+            check(_lib.load().mrl_segtree_set_ring_dev(ptr(self._sum), ptr(self._min), self._capacity, start, self._maxsize,
+                                                       n, ptr(self._max_priority_dev), float(self._alpha), stream_ptr()),
+                  'mrl_segtree_set_ring_dev')
+            return start, n
+        leaf = self._max_priority ** self._alpha                      # replay_buffer.py:100-105
         check(_lib.load().mrl_segtree_set_ring(ptr(self._sum), ptr(self._min), self._capacity, start, self._maxsize, n,
                                                float(leaf), stream_ptr()), 'mrl_segtree_set_ring')
         return start, n
@@ -172,6 +185,9 @@ class PrioritizedReplayBuffer(ReplayBuffer):
             assert 0 <= i < self._len
             leaves.append(p ** self._alpha)
             self._max_priority = max(self._max_priority, p)
+        if self._max_priority_dev is not None:                         # both paths in one run: one running maximum
+            self._max_priority = max(self._max_priority, float(self._max_priority_dev.item()))
+            self._max_priority_dev.fill_(self._max_priority)
         idx = torch.as_tensor(np.asarray(idxes, dtype=np.int32), device=self.device)
         leaf = torch.as_tensor(np.asarray(leaves, dtype=np.float64), device=self.device)
         check(_lib.load().mrl_segtree_set(ptr(self._sum), ptr(self._min), self._capacity, ptr(idx), ptr(leaf),

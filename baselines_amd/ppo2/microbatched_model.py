@@ -57,7 +57,8 @@ class MicrobatchedModel(Model):
         self._train_calls += 1
         return stats
 
-    def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None):
+    def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None, states=None):
+        assert states is None, 'microbatches with recurrent models are not supported yet'     # microbatched_model.py:38
         B = idx_dev.numel()
 
         def call(mb0, mbn, row):

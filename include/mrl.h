@@ -231,7 +231,9 @@ int mrl_replay_gather(const void* obs_t_buf, const void* obs_tp1_buf, const int3
  *   mrl_segtree_set_ring  n consecutive ring slots from `start` (mod maxsize) all get `leaf`
  *                         (PrioritizedReplayBuffer.add of a batch: max_priority**alpha)
  *   mrl_per_update_from_td  device fast path: leaf = pow(|td|+eps, alpha) (ocml pow, <= 2 ulp off
- *                         libm) and *max_priority = max(*max_priority, |td|+eps)  (deepq.py:302) */
+ *                         libm) and *max_priority = max(*max_priority, |td|+eps)  (deepq.py:302)
+ *   mrl_segtree_set_ring_dev  mrl_segtree_set_ring with leaf = pow(*max_priority, alpha) read from the device
+ *                         word mrl_per_update_from_td maintains (no host read-back per `add`) */
 int mrl_segtree_init(double* sum_tree, double* min_tree, long capacity, void* stream);
 int mrl_segtree_set(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,
                     const double* leaf, int n, void* stream);
@@ -240,6 +242,8 @@ int mrl_segtree_set_ring(double* sum_tree, double* min_tree, long capacity, long
 int mrl_per_update_from_td(double* sum_tree, double* min_tree, long capacity, const int32_t* idx,
                            const float* td, double eps, double alpha, double* max_priority, int n,
                            void* stream);
+int mrl_segtree_set_ring_dev(double* sum_tree, double* min_tree, long capacity, long start, long maxsize, int n,
+                             const double* max_priority, double alpha, void* stream);
 /* stratified proportional sampling + importance weights --- deepq/replay_buffer.py:107-115, 155-165
  * uniforms f64 [B] are the `random.random()` draws; p_total = sum(0, length-1) EXCLUDES the newest
  * element (reference quirk, segment_tree.py:69-74); idx_out int32 [B] bit-exact vs the reference;
@@ -296,10 +300,12 @@ int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const float* target
                      float gamma, int double_q, int B, float* grads_out, float* td_out, float* loss_out, void* workspace,
                      size_t workspace_bytes, void* stream);
 /* train, optimizer part (build_graph.py:416-421, deepq.py:205): every variable's gradient clipped by ITS OWN norm
- * (tf.clip_by_norm; grad_norm_clipping <= 0: none), then TF-1 ApplyAdam with alpha = lr*sqrt(1-b2^t)/(1-b1^t) */
+ * (tf.clip_by_norm; grad_norm_clipping <= 0: none), then TF-1 ApplyAdam with alpha = lr*sqrt(1-b2^t)/(1-b1^t).
+ * alpha_dev != NULL: the step size is read from device memory instead of `alpha` (launch graphs that are replayed
+ * with a step size that changes from step to step) */
 int mrl_qnet_adam_step(const mrl_qnet* q, float* params, float* grads, float* adam_m, float* adam_v, float alpha,
-                       float beta1, float beta2, float eps, float grad_norm_clipping, void* workspace,
-                       size_t workspace_bytes, int batch, void* stream);
+                       const float* alpha_dev, float beta1, float beta2, float eps, float grad_norm_clipping,
+                       void* workspace, size_t workspace_bytes, int batch, void* stream);
 
 /* ---- synthetic device-resident VecEnv (bench/test data source) ----------------------------
  * Stands where gym environments stand in the reference (common/vec_env/): lock-step stepping with

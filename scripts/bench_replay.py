@@ -82,18 +82,33 @@ np.random.seed(0)
 qm = QModel(build_q_func('conv_only'), Box(0, 255, SHAPE, np.uint8), NA, lr=1e-4, gamma=0.99, max_batch=32)
 
 
-def dqn_step(B=32, beta=0.4):
+def dqn_step(B=32, beta=0.4, graph=True):
     o1, a, r, o2, d, w, idx = buf.sample_dev(B, beta)
-    qm.train(o1, a, r, o2, d, w.float())
-    buf.update_priorities_from_td(idx, qm.last_td)
+    td = qm.train_dev(o1, a, r, o2, d, w, graph=graph)       # device TD errors, no host round trip
+    buf.update_priorities_from_td(idx, td)
 
 
-for _ in range(5):
-    dqn_step()
+def timed(n, **kw):
+    for _ in range(5):
+        dqn_step(**kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dqn_step(**kw)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+# the optimizer step replayed as one hipGraph (the default), then launched kernel by kernel with HIP events around each
+res['dqn_learner_step_batch32_us'] = round(timed(200), 1)
+res['dqn_learner_step_batch32_eager_us'] = round(timed(100, graph=False), 1)
+_lib.prof_enable(True)
+for _ in range(20):
+    dqn_step(graph=False)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(100):
-    dqn_step()
-torch.cuda.synchronize()
-res['dqn_learner_step_batch32_us'] = round((time.perf_counter() - t0) / 100 * 1e6, 1)
+_lib.prof_enable(False)
+rep = _lib.prof_report()
+res['dqn_learner_step_batch32_kernels_us'] = {k: {'us': round(v['ms'] / v['count'] * 1e3, 2), 'calls_per_step': v['count'] / 20.0}
+                                              for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms'])}
+res['dqn_learner_step_batch32_kernel_sum_us'] = round(sum(v['ms'] for v in rep.values()) / 20 * 1e3, 1)
 print(json.dumps(res))

@@ -105,7 +105,7 @@ def test_q_values_td_gradient_and_clipped_adam_vs_oracle(name):
         one = np.float32(1)
         alpha = np.float32(1e-3) * np.sqrt(one - om.beta2_power) / (one - om.beta1_power)
         _lib.check(qm.lib.mrl_qnet_adam_step(qm.handle, _lib.ptr(qm.params), _lib.ptr(qm.grads), _lib.ptr(qm.adam_m),
-                                             _lib.ptr(qm.adam_v), float(alpha), 0.9, 0.999, 1e-8, 10.0, _lib.ptr(qm.workspace),
+                                             _lib.ptr(qm.adam_v), float(alpha), None, 0.9, 0.999, 1e-8, 10.0, _lib.ptr(qm.workspace),
                                              qm.workspace.numel(), qm.max_batch, _lib.stream_ptr()), 'mrl_qnet_adam_step')
         om.apply_grads(g)
         np.testing.assert_allclose(qm.get_flat_params(), om.flat_params(), rtol=0, atol=3e-7)
@@ -221,3 +221,57 @@ def test_deepq_train_step_sequence_matches_oracle_with_prioritized_replay():
             om.update_target()
     diff = np.abs(qm.get_flat_params() - om.flat_params())
     assert diff.mean() < 2e-5 and np.percentile(diff, 99) < 3e-4, (diff.mean(), np.percentile(diff, 99))
+
+
+@pytest.mark.parametrize('name', ['mlp_dueling', 'conv_only_small'])
+def test_train_dev_graph_replay_is_bit_identical_to_eager_launches(name):
+    """`QModel.train_dev` replays the optimizer step as ONE captured launch graph (inputs in static device buffers, the Adam
+    step size in a device word).  Same kernels, same order: TD errors, parameters and Adam slots of a graph-replayed run
+    equal those of an eagerly launched run bit for bit over several steps (first step eager + capture, then replays)."""
+    B = 16
+    qa, _, _, batch = _pair(name, B, 31)
+    qb, _, _, _ = _pair(name, B, 31)
+    assert torch.equal(qa.params, qb.params) and torch.equal(qa.target, qb.target)
+    rng = np.random.RandomState(2)
+    dev = lambda x, dt=None: (torch.from_numpy(np.ascontiguousarray(x)).cuda() if dt is None
+                              else torch.from_numpy(np.ascontiguousarray(x)).cuda().to(dt))
+    for step in range(5):
+        perm = rng.permutation(B)
+        args = (dev(batch['obs_t'][perm]), dev(batch['act'][perm], torch.int32), dev(batch['rew'][perm]),
+                dev(batch['obs_tp1'][perm]), dev(batch['done'][perm]), dev(batch['w'][perm]))
+        ta = qa.train_dev(*args, graph=True).clone()
+        tb = qb.train_dev(*args, graph=False).clone()
+        assert torch.equal(ta, tb), step
+        assert torch.equal(qa.params, qb.params) and torch.equal(qa.adam_m, qb.adam_m) and torch.equal(qa.adam_v, qb.adam_v), step
+        if step == 2:
+            qa.update_target()
+            qb.update_target()
+    assert qa._graphs[B]['graph'] not in (None, False), 'the step was captured and replayed'
+    assert float((qa.params - torch.from_numpy(qa.get_flat_params()).cuda()).abs().max()) == 0.0
+
+
+def test_prioritized_buffer_device_path_keeps_the_running_max_on_the_device():
+    """`add` after `update_priorities_from_td`: the new leaves are max_priority ** alpha with the maximum the device path
+    maintains (replay_buffer.py:100-105, 191) -- no host read-back; the trees equal the host path's to 1e-12 relative."""
+    from baselines_amd.deepq import PrioritizedReplayBuffer
+    rng = np.random.RandomState(4)
+    bufs = [PrioritizedReplayBuffer(32, alpha=0.7) for _ in range(2)]
+    ob = lambda: rng.randint(0, 256, (4, 4, 1)).astype(np.uint8)
+    for _ in range(20):
+        o1, o2, a, r = ob(), ob(), int(rng.randint(3)), float(rng.randn())
+        for b in bufs:
+            b.add(o1, a, r, o2, 0.0)
+    idx = np.array([3, 7, 7, 11, 19], dtype=np.int32)
+    td = np.array([0.5, -2.5, 1.25, 0.01, -0.75], dtype=np.float32)
+    bufs[0].update_priorities_from_td(torch.from_numpy(idx).cuda(), torch.from_numpy(td).cuda(), eps=1e-6)
+    bufs[1].update_priorities([int(i) for i in idx], np.abs(td).astype(np.float64) + 1e-6)
+    for _ in range(6):                                   # these slots get max_priority ** alpha = 2.500001 ** 0.7
+        o1, o2 = ob(), ob()
+        for b in bufs:
+            b.add(o1, 1, 0.5, o2, 0.0)
+    (s0, m0), (s1, m1) = bufs[0].trees_numpy(), bufs[1].trees_numpy()
+    np.testing.assert_allclose(s0, s1, rtol=1e-12, atol=0)
+    fin = np.isfinite(m1)
+    assert (np.isfinite(m0) == fin).all()
+    np.testing.assert_allclose(m0[fin], m1[fin], rtol=1e-12, atol=0)
+    assert abs(s0[32 + 25] - 2.500001 ** 0.7) < 1e-12
