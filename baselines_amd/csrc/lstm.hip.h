@@ -35,91 +35,95 @@ struct LstmFwdArgs {
 };
 
 __device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+typedef float lstm_v4f __attribute__((ext_vector_type(4)));
 
+// Index arithmetic is 32-bit on purpose (B * 4 nh elements < 2^32, checked by the launcher): with 64-bit element offsets the
+// compiler keeps a 64-bit address pair per (array, environment) alive across the scan -- ~100 VGPRs next to the nh weights,
+// which made the nh = 128 instantiation spill 305 registers.  Unsigned 32-bit offsets against the uniform base pointers
+// become scalar-base + vector-offset accesses.
 template <int NH, int E>
 __global__ __launch_bounds__(4 * NH) void lstm_fwd_kernel(LstmFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float h_s[E][NH];
     __shared__ float c_s[E][NH];
     __shared__ float g_s[E][4 * NH];
-    const int j = threadIdx.x;
+    const unsigned j = threadIdx.x;
+    constexpr unsigned N4 = 4u * NH;
     float w[NH];
 #pragma unroll
-    for (int k = 0; k < NH; ++k) w[k] = a.wh[k * 4 * NH + j];
+    for (int k = 0; k < NH; ++k) w[k] = a.wh[(unsigned)k * N4 + j];
     const float bj = a.bias[j];
-    const int T = a.T;
-    for (int g0 = blockIdx.x * E; g0 < a.nenv; g0 += gridDim.x * E) {
-        for (int q = j; q < E * NH; q += 4 * NH) {
-            const int e = q / NH, k = q - e * NH, env = g0 + e;
-            const bool ok = env < a.nenv && a.s0;
-            c_s[e][k] = ok ? a.s0[(long)env * 2 * NH + k] : 0.f;
-            h_s[e][k] = ok ? a.s0[(long)env * 2 * NH + NH + k] : 0.f;
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    // this thread's (environment, unit) of the element-wise phases: E * NH elements over 4 NH threads
+    static_assert(E == 4, "one element-wise item per thread");
+    const unsigned ee = j / NH, ek = j - ee * NH;
+    for (unsigned g0 = blockIdx.x * E; g0 < nenv; g0 += gridDim.x * E) {
+        const unsigned env = g0 + ee;
+        const bool live = env < nenv;
+        {
+            const bool ok = live && a.s0;
+            c_s[ee][ek] = ok ? a.s0[env * 2u * NH + ek] : 0.f;
+            h_s[ee][ek] = ok ? a.s0[env * 2u * NH + NH + ek] : 0.f;
         }
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
+        for (unsigned t = 0; t < T; ++t) {
             float zxv[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int env = min(g0 + e, a.nenv - 1);
-                zxv[e] = a.zx[((long)env * T + t) * 4 * NH + j];            // in flight during the mask phase
+                const unsigned en = min(g0 + (unsigned)e, nenv - 1u);
+                zxv[e] = a.zx[(en * T + t) * N4 + j];                          // in flight during the mask phase
             }
-            for (int q = j; q < E * NH; q += 4 * NH) {
-                const int e = q / NH, k = q - e * NH, env = g0 + e;
-                if (env < a.nenv) {
-                    const long b = (long)env * T + t;
-                    const float keep = a.mask[a.srow ? a.srow[b] : b] ? 0.f : 1.f;
-                    const float cv = c_s[e][k] * keep, hv = h_s[e][k] * keep;
-                    c_s[e][k] = cv;
-                    h_s[e][k] = hv;
-                    if (a.cm) { a.cm[b * NH + k] = cv; a.hm[b * NH + k] = hv; }
-                }
+            const unsigned b = env * T + t;                                    // sample of this thread's element-wise item
+            if (live) {
+                const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                const float cv = c_s[ee][ek] * keep, hv = h_s[ee][ek] * keep;
+                c_s[ee][ek] = cv;
+                h_s[ee][ek] = hv;
+                if (a.cm) { a.cm[b * NH + ek] = cv; a.hm[b * NH + ek] = hv; }
             }
             __syncthreads();
-            float acc[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = 0.f;
+            // z[e][j] = sum_k h[e][k] * wh[k][j] for the E = 4 environments at once: v_mfma_f32_4x4x1_16b_f32 is 16 independent
+            // 4 x 4 rank-1 updates -- block = 4 consecutive lanes, A row i = environment i (supplied by lane 4*block + i),
+            // B column = the lane's own gate column, D[r] = accumulator of environment r in that lane.  One instruction does
+            // the four fmaf of a (k, column) pair (same fp32 fma, same k order: bitwise the scalar chain), and the h operand
+            // is a per-lane register: a lane reads h[lane & 3][k4 .. k4+3] with ONE 16-byte LDS read per 4 k -- a quarter of
+            // the broadcast reads of the fmaf form, which were what a step waited for (128 x E ds_read_b128 per wave).
+            lstm_v4f acc4 = {0.f, 0.f, 0.f, 0.f};
+            const float* hrow = &h_s[j & 3u][0];
 #pragma unroll
             for (int k4 = 0; k4 < NH; k4 += 4) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float4 hv = *reinterpret_cast<const float4*>(&h_s[e][k4]);      // broadcast read
-                    acc[e] = fmaf(hv.x, w[k4], acc[e]);
-                    acc[e] = fmaf(hv.y, w[k4 + 1], acc[e]);
-                    acc[e] = fmaf(hv.z, w[k4 + 2], acc[e]);
-                    acc[e] = fmaf(hv.w, w[k4 + 3], acc[e]);
-                }
+                const float4 hv = *reinterpret_cast<const float4*>(hrow + k4);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.x, w[k4], acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.y, w[k4 + 1], acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.z, w[k4 + 2], acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(hv.w, w[k4 + 3], acc4, 0, 0, 0);
             }
+            const float acc[E] = {acc4[0], acc4[1], acc4[2], acc4[3]};
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const float z = (zxv[e] + acc[e]) + bj;                      // (x@wx + h@wh) + b, the reference's order
                 const float gv = j < 3 * NH ? lstm_sigmoid(z) : tanhf(z);
                 g_s[e][j] = gv;
-                if (a.gates && g0 + e < a.nenv) a.gates[((long)(g0 + e) * T + t) * 4 * NH + j] = gv;
+                if (a.gates && g0 + e < nenv) a.gates[((g0 + e) * T + t) * N4 + j] = gv;
             }
             __syncthreads();
-            for (int q = j; q < E * NH; q += 4 * NH) {
-                const int e = q / NH, k = q - e * NH, env = g0 + e;
-                const float iv = g_s[e][k], fv = g_s[e][NH + k], ov = g_s[e][2 * NH + k], uv = g_s[e][3 * NH + k];
-                const float c = fv * c_s[e][k] + iv * uv;
+            {
+                const float iv = g_s[ee][ek], fv = g_s[ee][NH + ek], ov = g_s[ee][2 * NH + ek], uv = g_s[ee][3 * NH + ek];
+                const float c = fv * c_s[ee][ek] + iv * uv;
                 const float tcv = tanhf(c);
                 const float h = ov * tcv;
-                c_s[e][k] = c;
-                h_s[e][k] = h;
-                if (env < a.nenv) {
-                    const long b = (long)env * T + t;
-                    if (a.tc) a.tc[b * NH + k] = tcv;
-                    a.hout[b * NH + k] = h;
+                c_s[ee][ek] = c;
+                h_s[ee][ek] = h;
+                if (live) {
+                    if (a.tc) a.tc[b * NH + ek] = tcv;
+                    a.hout[b * NH + ek] = h;
                 }
             }
             __syncthreads();
         }
-        if (a.s_out)
-            for (int q = j; q < E * NH; q += 4 * NH) {
-                const int e = q / NH, k = q - e * NH, env = g0 + e;
-                if (env < a.nenv) {
-                    a.s_out[(long)env * 2 * NH + k] = c_s[e][k];
-                    a.s_out[(long)env * 2 * NH + NH + k] = h_s[e][k];
-                }
-            }
+        if (a.s_out && live) {
+            a.s_out[env * 2u * NH + ek] = c_s[ee][ek];
+            a.s_out[env * 2u * NH + NH + ek] = h_s[ee][ek];
+        }
         __syncthreads();
     }
 }
@@ -135,6 +139,7 @@ struct LstmBwdArgs {
 
 template <int NH, int E>
 __global__ __launch_bounds__(4 * NH) void lstm_bwd_kernel(LstmBwdArgs a) {
+    static_assert(E == 4 && NH % 4 == 0, "4x4x1 MFMA blocks: four environments, four lanes of a block in one gate quarter");
     __shared__ float dh_s[E][NH];
     __shared__ float dc_s[E][NH];
     __shared__ __attribute__((aligned(16))) float dz_s[E][4 * NH];
@@ -173,20 +178,19 @@ __global__ __launch_bounds__(4 * NH) void lstm_bwd_kernel(LstmBwdArgs a) {
                 dc_s[e][kk] = dcm;
             }
             __syncthreads();
-            float acc[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = 0.f;
+            // p[e][q4][k] = sum_jj dz[e][q4*NH + jj] * wh[k][q4*NH + jj] on the 4x4x1 MFMA (see lstm_fwd_kernel): the four lanes
+            // of a block share q4 (NH % 4 == 0) and supply dz of environments 0..3
+            lstm_v4f acc4 = {0.f, 0.f, 0.f, 0.f};
+            const float* drow = &dz_s[tid & 3][q4 * NH];
 #pragma unroll
             for (int j4 = 0; j4 < NH; j4 += 4) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float4 dv = *reinterpret_cast<const float4*>(&dz_s[e][q4 * NH + j4]);
-                    acc[e] = fmaf(dv.x, w[j4], acc[e]);
-                    acc[e] = fmaf(dv.y, w[j4 + 1], acc[e]);
-                    acc[e] = fmaf(dv.z, w[j4 + 2], acc[e]);
-                    acc[e] = fmaf(dv.w, w[j4 + 3], acc[e]);
-                }
+                const float4 dv = *reinterpret_cast<const float4*>(drow + j4);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.x, w[j4], acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.y, w[j4 + 1], acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.z, w[j4 + 2], acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.w, w[j4 + 3], acc4, 0, 0, 0);
             }
+            const float acc[E] = {acc4[0], acc4[1], acc4[2], acc4[3]};
 #pragma unroll
             for (int e = 0; e < E; ++e) p_s[e][q4][k] = acc[e];
             __syncthreads();
@@ -204,13 +208,167 @@ __global__ __launch_bounds__(4 * NH) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
 }
 
-inline bool lstm_nh_ok(int nh) { return nh == 32 || nh == 64 || nh == 128; }
+// ---- any width: the same scans with wh STREAMED from L2 every step instead of held in registers (nh = 256 is 1 MB of
+// weights, more than a CU's whole register file) -- the path of `nlstm` values other than 32 / 64 / 96 / 128 (e.g. the 256 of
+// the reference's impala_cnn_lstm, common/models.py:212-214).  Same arithmetic, same order of the fmaf chains.
+template <int E>
+__global__ __launch_bounds__(1024) void lstm_fwd_generic_kernel(LstmFwdArgs a, int nh) {
+    extern __shared__ __attribute__((aligned(16))) float lg_s[];
+    float* h_s = lg_s;                       // [E][nh]
+    float* c_s = h_s + E * nh;               // [E][nh]
+    float* g_s = c_s + E * nh;               // [E][4nh]
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    const unsigned NH = (unsigned)nh, N4 = 4u * NH;
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    for (unsigned g0 = blockIdx.x * E; g0 < nenv; g0 += gridDim.x * E) {
+        for (unsigned q = tid; q < E * NH; q += nt) {
+            const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+            const bool ok = env < nenv && a.s0;
+            c_s[q] = ok ? a.s0[env * 2u * NH + k] : 0.f;
+            h_s[q] = ok ? a.s0[env * 2u * NH + NH + k] : 0.f;
+        }
+        __syncthreads();
+        for (unsigned t = 0; t < T; ++t) {
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                    const float cv = c_s[q] * keep, hv = h_s[q] * keep;
+                    c_s[q] = cv;
+                    h_s[q] = hv;
+                    if (a.cm) { a.cm[b * NH + k] = cv; a.hm[b * NH + k] = hv; }
+                }
+            }
+            __syncthreads();
+            for (unsigned j = tid; j < N4; j += nt) {
+                float acc[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = 0.f;
+                for (unsigned k = 0; k < NH; ++k) {
+                    const float w = a.wh[k * N4 + j];                       // coalesced over j, L2-resident
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] = fmaf(h_s[e * NH + k], w, acc[e]);
+                }
+                const float bj = a.bias[j];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned env = min(g0 + (unsigned)e, nenv - 1u);
+                    const float z = (a.zx[(env * T + t) * N4 + j] + acc[e]) + bj;
+                    const float gv = j < 3 * NH ? lstm_sigmoid(z) : tanhf(z);
+                    g_s[e * N4 + j] = gv;
+                    if (a.gates && g0 + e < nenv) a.gates[((g0 + e) * T + t) * N4 + j] = gv;
+                }
+            }
+            __syncthreads();
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                const float* g = g_s + e * N4;
+                const float c = g[NH + k] * c_s[q] + g[k] * g[3 * NH + k];
+                const float tcv = tanhf(c);
+                const float h = g[2 * NH + k] * tcv;
+                c_s[q] = c;
+                h_s[q] = h;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    if (a.tc) a.tc[b * NH + k] = tcv;
+                    a.hout[b * NH + k] = h;
+                }
+            }
+            __syncthreads();
+        }
+        if (a.s_out)
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                if (env < nenv) {
+                    a.s_out[env * 2u * NH + k] = c_s[q];
+                    a.s_out[env * 2u * NH + NH + k] = h_s[q];
+                }
+            }
+        __syncthreads();
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void lstm_bwd_generic_kernel(LstmBwdArgs a, int nh) {
+    extern __shared__ __attribute__((aligned(16))) float lg_s[];
+    float* dh_s = lg_s;                      // [E][nh]
+    float* dc_s = dh_s + E * nh;             // [E][nh]
+    float* dz_s = dc_s + E * nh;             // [E][4nh]
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    const unsigned NH = (unsigned)nh, N4 = 4u * NH;
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    for (unsigned g0 = blockIdx.x * E; g0 < nenv; g0 += gridDim.x * E) {
+        for (unsigned q = tid; q < E * NH; q += nt) { dh_s[q] = 0.f; dc_s[q] = 0.f; }
+        __syncthreads();
+        for (int ti = (int)T - 1; ti >= 0; --ti) {
+            const unsigned t = (unsigned)ti;
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, kk = q - e * NH, env = g0 + e;
+                float dzi = 0.f, dzf = 0.f, dzo = 0.f, dzu = 0.f, dcm = 0.f;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    const float* gr = a.gates + b * N4;
+                    const float iv = gr[kk], fv = gr[NH + kk], ov = gr[2 * NH + kk], uv = gr[3 * NH + kk];
+                    const float tcv = a.tc[b * NH + kk], cmv = a.cm[b * NH + kk];
+                    const float dh = dh_s[q] + a.dhout[b * NH + kk];
+                    const float dov = dh * tcv;
+                    const float dc = dc_s[q] + dh * ov * (1.f - tcv * tcv);
+                    dzi = (dc * uv) * iv * (1.f - iv);
+                    dzf = (dc * cmv) * fv * (1.f - fv);
+                    dzo = dov * ov * (1.f - ov);
+                    dzu = (dc * iv) * (1.f - uv * uv);
+                    const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                    dcm = (dc * fv) * keep;
+                    float* dst = a.dzg + b * N4;
+                    dst[kk] = dzi; dst[NH + kk] = dzf; dst[2 * NH + kk] = dzo; dst[3 * NH + kk] = dzu;
+                }
+                float* dz = dz_s + e * N4;
+                dz[kk] = dzi; dz[NH + kk] = dzf; dz[2 * NH + kk] = dzo; dz[3 * NH + kk] = dzu;
+                dc_s[q] = dcm;
+            }
+            __syncthreads();
+            // dh_prev[e][k] = sum over the 4 gate blocks q4 (in the fixed order of the register kernel: ((p0 + p1) + (p2 + p3)))
+            // of sum_jj dz[e][q4*nh + jj] * wh[k][q4*nh + jj]
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                float pq[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float* wrow = a.wh + k * N4 + q4 * NH;
+                    const float* dz = dz_s + e * N4 + q4 * NH;
+                    float acc = 0.f;
+                    for (unsigned jj = 0; jj < NH; ++jj) acc = fmaf(dz[jj], wrow[jj], acc);
+                    pq[q4] = acc;
+                }
+                float keep = 0.f;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                }
+                dh_s[q] = ((pq[0] + pq[1]) + (pq[2] + pq[3])) * keep;      // read back by this thread only (next step)
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// widths the register-resident kernels are compiled for; any other positive width takes the streamed form
+inline bool lstm_nh_fast(int nh) { return nh == 32 || nh == 64 || nh == 96 || nh == 128; }
+inline bool lstm_nh_ok(int nh) { return nh >= 1 && nh <= 1024; }
 
 inline hipError_t launch_lstm_fwd(const LstmFwdArgs& a, int nh, int num_cus, hipStream_t st) {
     constexpr int E = 4;
     const int groups = (a.nenv + E - 1) / E;
     const int blocks = std::max(1, std::min(groups, 2 * num_cus));
+    if (!lstm_nh_fast(nh)) {
+        if (!lstm_nh_ok(nh)) return hipErrorInvalidValue;
+        const int threads = std::min(1024, (4 * nh + 63) / 64 * 64);
+        hipLaunchKernelGGL((lstm_fwd_generic_kernel<E>), dim3(blocks), dim3(threads), (size_t)E * nh * 6 * sizeof(float), st, a, nh);
+        return hipGetLastError();
+    }
     if (nh == 128) hipLaunchKernelGGL((lstm_fwd_kernel<128, E>), dim3(blocks), dim3(512), 0, st, a);
+    else if (nh == 96) hipLaunchKernelGGL((lstm_fwd_kernel<96, E>), dim3(blocks), dim3(384), 0, st, a);
     else if (nh == 64) hipLaunchKernelGGL((lstm_fwd_kernel<64, E>), dim3(blocks), dim3(256), 0, st, a);
     else if (nh == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32, E>), dim3(blocks), dim3(128), 0, st, a);
     else return hipErrorInvalidValue;
@@ -220,7 +378,14 @@ inline hipError_t launch_lstm_bwd(const LstmBwdArgs& a, int nh, int num_cus, hip
     constexpr int E = 4;
     const int groups = (a.nenv + E - 1) / E;
     const int blocks = std::max(1, std::min(groups, 2 * num_cus));
+    if (!lstm_nh_fast(nh)) {
+        if (!lstm_nh_ok(nh)) return hipErrorInvalidValue;
+        const int threads = std::min(1024, (E * nh + 63) / 64 * 64);
+        hipLaunchKernelGGL((lstm_bwd_generic_kernel<E>), dim3(blocks), dim3(threads), (size_t)E * nh * 6 * sizeof(float), st, a, nh);
+        return hipGetLastError();
+    }
     if (nh == 128) hipLaunchKernelGGL((lstm_bwd_kernel<128, E>), dim3(blocks), dim3(512), 0, st, a);
+    else if (nh == 96) hipLaunchKernelGGL((lstm_bwd_kernel<96, E>), dim3(blocks), dim3(384), 0, st, a);
     else if (nh == 64) hipLaunchKernelGGL((lstm_bwd_kernel<64, E>), dim3(blocks), dim3(256), 0, st, a);
     else if (nh == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, E>), dim3(blocks), dim3(128), 0, st, a);
     else return hipErrorInvalidValue;

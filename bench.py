@@ -245,9 +245,13 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
     from baselines_amd.ppo2 import Model, Runner
 
-    if workload == 'atari':
-        hp = dict(noptepochs=4, nminibatches=4, ent_coef=0.01, lr=2.5e-4, cliprange=0.1, network='cnn', value_network=None)
-        flops_per_sample_visit = 49.526e6      # SURVEY.md App. B (fwd+bwd)
+    recurrent = workload == 'atari_lstm'
+    if workload in ('atari', 'atari_lstm'):
+        hp = dict(noptepochs=4, nminibatches=4, ent_coef=0.01, lr=2.5e-4, cliprange=0.1,
+                  network='cnn_lstm' if recurrent else 'cnn', value_network=None)
+        flops_per_sample_visit = 49.526e6      # SURVEY.md App. B (fwd+bwd); cnn_lstm: + 6 * (512 + 128) * 512 per sample-visit
+        if recurrent:
+            flops_per_sample_visit += 6.0 * (512 + 128) * 512
     else:
         hp = dict(noptepochs=10, nminibatches=32, ent_coef=0.0, lr=3e-4, cliprange=0.2, network='mlp', value_network='copy')
         flops_per_sample_visit = 248.6e3
@@ -257,7 +261,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     nbatch_train = nbatch // hp['nminibatches']
 
     set_global_seeds(0)
-    env = SyntheticVecEnv(workload, N, seed=1000 + rank)
+    env = SyntheticVecEnv('atari' if recurrent else workload, N, seed=1000 + rank)
     policy = build_policy(env, hp['network'], value_network=hp['value_network'])
     model = Model(policy=policy, ob_space=env.observation_space, ac_space=env.action_space, nbatch_act=N,
                   nbatch_train=nbatch_train, nsteps=T, ent_coef=hp['ent_coef'], vf_coef=0.5, max_grad_norm=0.5,
@@ -276,11 +280,13 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         runner.run()
     sync()
     t0 = time.perf_counter()
-    runner.run()
+    rollout_out = runner.run()
     sync()
     t_rollout = time.perf_counter() - t0
     ro = runner.rollout
-    last_values = model.value_dev(runner.obs)
+    mb_states = rollout_out[6] if recurrent else None          # LSTM state of every env BEFORE the rollout (runner.py:23)
+    last_values = (model.value_dev(runner.obs, runner._states_dev, runner._dones_dev) if recurrent
+                   else model.value_dev(runner.obs))
 
     # self-check: gradient + statistics of one minibatch of the benched shape, computed in the benched
     # chunking (one 131072-sample chunk) and again in 8192-sample chunks -- the size the parity suite verifies against the
@@ -311,6 +317,17 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
         inds = np.arange(nbatch)
         stats = []
+        if recurrent:
+            # env-wise minibatches (ppo2.py:167-180): whole trajectories of N / nminibatches shuffled envs, BPTT over nsteps
+            per = N // hp['nminibatches']
+            envinds, flat = np.arange(N), np.arange(N * T).reshape(N, T)
+            for _ in range(hp['noptepochs']):
+                np.random.shuffle(envinds)
+                for lo in range(0, N, per):
+                    mbe = envinds[lo:lo + per]
+                    stats.append(model.train_indexed(hp['lr'], hp['cliprange'], ro, torch.from_numpy(flat[mbe].ravel()).to(model.device),
+                                                     states=mb_states[torch.from_numpy(mbe).to(mb_states.device)]))
+            return torch.stack(stats).mean(dim=0)
         for _ in range(hp['noptepochs']):
             np.random.shuffle(inds)
             inds_dev = torch.from_numpy(inds).to(model.device)
@@ -415,7 +432,7 @@ def dominant_roofline(res, sites, workload):
     prof = res['prof']
     if not prof:
         return None, {}
-    atari = workload == 'atari'
+    atari = workload == 'atari'          # per-site algorithmic bytes / pipes are tabulated for the feed-forward NatureCNN step
     pmc, pmc_src = load_pmc(res['nbatch_train']) if atari else ({}, None)
     per = kernel_rooflines(prof, sites if atari else {}, nature_cnn_alg_bytes(res['nbatch_train']) if atari else None, pmc)
     tot_ms = sum(v['ms'] for v in prof.values())
@@ -461,7 +478,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='atari', choices=['atari', 'mujoco'])
+    ap.add_argument('--workload', default='atari', choices=['atari', 'mujoco', 'atari_lstm'])
     ap.add_argument('--num-envs', type=int, default=None, help='whole-job num_envs (default 4096 atari / 1024 mujoco)')
     ap.add_argument('--nsteps', type=int, default=128)
     ap.add_argument('--chunk', type=int, default=None)
@@ -559,11 +576,11 @@ def main():
         if default_run and not args.no_other_configs:
             # BASELINE.json's other single-GPU configurations, short runs (3 timed updates each), own rooflines
             others = []
-            for wl, n_envs in (('mujoco', 1024), ('atari', 256)):
+            for wl, n_envs in (('mujoco', 1024), ('atari', 256), ('atari_lstm', 256)):
                 r = run_ppo2(wl, n_envs, 128, 3, 1, None, 1, 0, None, not args.no_prof)
                 rf, _ = dominant_roofline(r, sites, wl)
                 others.append({'workload': 'ppo2 update-only %s-shaped %s num_envs=%d nsteps=128'
-                                           % (wl, r['hp']['network'], n_envs),
+                                           % (wl.split('_')[0], r['hp']['network'], n_envs),
                                'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['dt'] / 3 * 1e3, 'steps': 3,
                                'device_state': r.get('device_state'),          # this configuration's own rocm-smi samples
                                'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / 3),
@@ -572,7 +589,7 @@ def main():
                                                       sorted(r['prof'].items(), key=lambda kv: -kv[1]['ms'])}})
             others.append(replay_config())
             out['other_configs'] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ('atari', 'mujoco'):
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if world > 1:

@@ -74,7 +74,8 @@ typedef struct mrl_model_desc {
     int value_copy;       /* policies.py:154-166: 0 = shared latent, 1 = value_network='copy' */
     int pd_kind;          /* MRL_PD_*  (distributions.py:278-290) */
     int nact;             /* Discrete.n or Box.shape[0] */
-    int nlstm;            /* lstm / cnn_lstm: hidden state size (models.py:132, default 128; 32, 64 or 128 here) */
+    int nlstm;            /* lstm / cnn_lstm: hidden state size (models.py:132, default 128).  32 / 64 / 96 / 128: recurrent weights
+                           * register-resident for the whole scan; any other width up to 1024 (e.g. impala_cnn_lstm's 256): streamed from L2 */
 } mrl_model_desc;
 
 typedef struct mrl_model mrl_model;   /* host-side layout object; owns no device memory */

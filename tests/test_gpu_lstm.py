@@ -21,6 +21,10 @@ def dev(x):
 CASES = {
     'lstm_nh32': dict(network='lstm', ob_shape=(12,), ob_dtype=np.float32, nlstm=32, nseq=6, T=5),
     'lstm_nh128': dict(network='lstm', ob_shape=(376,), ob_dtype=np.float32, nlstm=128, nseq=9, T=16),
+    'lstm_nh96': dict(network='lstm', ob_shape=(20,), ob_dtype=np.float32, nlstm=96, nseq=5, T=7),
+    # widths without a register-resident instantiation: recurrent weights streamed from L2 (a2c/utils.py:81-102, any nh)
+    'lstm_nh48_streamed': dict(network='lstm', ob_shape=(12,), ob_dtype=np.float32, nlstm=48, nseq=6, T=5),
+    'lstm_nh256_streamed': dict(network='lstm', ob_shape=(24,), ob_dtype=np.float32, nlstm=256, nseq=5, T=6),
     'cnn_lstm': dict(network='cnn_lstm', ob_shape=(84, 84, 4), ob_dtype=np.uint8, nlstm=128, nseq=3, T=4),
 }
 
