@@ -178,8 +178,15 @@ struct ConvGeom {
     }
     __host__ __device__ bool padded() const { return (pad_t | pad_l) != 0 || (OH - 1) * stride + rf > H || (OW - 1) * stride + rf > W; }
 };
-template <bool U8> __device__ __forceinline__ float4 conv_ld(const void* p, long off) {
-    if (U8) {
+// SRC: what a conv loader reads -- 0: fp32 activations; 1: uint8 pixels -> /255; 2: fp32 pixels -> /255
+// (`tf.cast(unscaled_images, tf.float32) / 255.` of common/models.py:19 applies to every image dtype)
+template <int SRC> __device__ __forceinline__ float4 conv_ld(const void* p, long off) {
+    if (SRC == 2) {
+        float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(p) + off);
+        v.x = v.x / 255.f; v.y = v.y / 255.f; v.z = v.z / 255.f; v.w = v.w / 255.f;
+        return v;
+    }
+    if (SRC == 1) {
         uint32_t u = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p) + off);
         float4 v;
         v.x = u8_over_255((float)(u & 0xff));
@@ -191,7 +198,7 @@ template <bool U8> __device__ __forceinline__ float4 conv_ld(const void* p, long
         return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + off);
     }
 }
-template <bool U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixel, GEMM k = conv-k
+template <int U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixel, GEMM k = conv-k
     static constexpr bool KC = true;
     template <int NV> struct State { long base[NV]; int iy0[NV], ix0[NV]; int k, ky, kr; };
     template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {
@@ -231,7 +238,7 @@ template <bool U8> struct ConvPatchKC : ConvGeom {   // forward: GEMM row = pixe
         while (s.kr >= rowk) { s.kr -= rowk; ++s.ky; }
     }
 };
-template <bool U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k, GEMM k = pixel
+template <int U8> struct ConvPatchMC : ConvGeom {   // wgrad: GEMM row = conv-k, GEMM k = pixel
     static constexpr bool KC = false;
     template <int NV> struct State { long koff; int m; int b[NV]; int r[NV]; bool rvalid; int ky, kx; };
     template <int NV> __device__ __forceinline__ void init(State<NV>& s, int r0, int k0, int, int tid) const {

@@ -134,7 +134,9 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
         return 0;
     }
     if (d.network == MRL_NET_NATURE_CNN) {
-        if (d.ob_ndim != 3 || d.ob_dtype != MRL_OB_U8 || d.ob_shape[2] % 4 != 0) return MRL_EUNSUP;
+        // any image dtype / channel count (models.py:19 casts and scales whatever comes); uint8 with 4 channels (Atari frame
+        // stacks) takes the image-resident first-layer kernels, everything else the generic tiled engine
+        if (d.ob_ndim != 3 || d.ob_shape[2] < 1) return MRL_EUNSUP;
         int H = d.ob_shape[0], W = d.ob_shape[1], C = d.ob_shape[2];
         const int nf[3] = {32, 64, 64}, rf[3] = {8, 4, 3}, st[3] = {4, 2, 1};
         const char* nm[3] = {"c1", "c2", "c3"};
@@ -1239,7 +1241,8 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
     if (l.kind == 0) {
         int npix = B * l.OH * l.OW;
         const void* src = first ? in.obs : (const void*)hprev;
-        const bool wok = wres_fwd_ok(l, first, src);
+        const bool u8in = first && m->d.ob_dtype == MRL_OB_U8, f32in = first && !u8in;     // f32in: float image, scaled by 1/255 in the loader
+        const bool wok = !f32in && wres_fwd_ok(l, u8in, src);
         int var = pick_variant(l.name, "fwd", npix, l.NF, wok);
         if (var >= V_WRES16 && wok) {
             const long tiles = ((long)npix + 31) / 32;
@@ -1330,8 +1333,12 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
         }
         if (var >= V_WRES16) var = l.NF <= 32 ? V_128x32 : V_128x64_W41;
         EpiBiasAct ef{hout, l.NF, bias, l.act};
-        if (first) {
-            ConvPatchKC<true> af;
+        if (f32in) {
+            ConvPatchKC<2> af;
+            fill_conv(af, l, in.obs, npix, in.srow);
+            return gemm_dispatch(l.name, "fwd", var, af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
+        } else if (first) {
+            ConvPatchKC<1> af;
             fill_conv(af, l, in.obs, npix, in.srow);
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
         } else {
@@ -1567,8 +1574,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         EpiPartial ep{ws.part, slab, l.N, (long)l.K * l.N};
         RowMC bfm{dz, l.N, l.N, (int)rows, is_vec(dz, l.N), nullptr};
         if (l.kind == 0) {
-            if (first) {
-                ConvPatchMC<true> af;
+            if (first && m->d.ob_dtype != MRL_OB_U8) {
+                ConvPatchMC<2> af;
+                fill_conv(af, l, in.obs, (int)rows, in.srow);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+            } else if (first) {
+                ConvPatchMC<1> af;
                 fill_conv(af, l, in.obs, (int)rows, in.srow);
                 rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
             } else {

@@ -104,6 +104,14 @@ CONFIGS = {
                       value_network=None, kind='atari', T=4, N=8, B=24, chunk=16),
     'mlp_matching_fc': dict(network='mlp', ob_shape=(11,), ob_dtype=np.float32, pd_kind='gaussian', nact=64,
                             value_network=None, kind=None, T=8, N=8, B=32, chunk=32),
+    # nature_cnn on images that are not Atari frame stacks (common/models.py:19 casts and scales any image): RGB uint8,
+    # single-channel float, 4-channel float -- first layer on the generic tiled engine, /255 in its loader
+    'cnn_rgb_u8': dict(network='cnn', ob_shape=(44, 48, 3), ob_dtype=np.uint8, pd_kind='categorical', nact=4,
+                       value_network=None, kind='image', T=3, N=6, B=12, chunk=8),
+    'cnn_gray_f32': dict(network='cnn', ob_shape=(36, 40, 1), ob_dtype=np.float32, pd_kind='categorical', nact=3,
+                         value_network=None, kind='image', T=3, N=6, B=12, chunk=16),
+    'cnn_f32_4ch': dict(network='cnn', ob_shape=(40, 40, 4), ob_dtype=np.float32, pd_kind='gaussian', nact=2,
+                        value_network=None, kind='image', T=2, N=8, B=16, chunk=16),
 }
 
 
@@ -112,7 +120,11 @@ def _rollout(cfg, om, seed):
     itself with teacher-forced noise, like a real Runner.run -> ratios near 1, realistic loss scale."""
     rng = np.random.RandomState(seed)
     T, N = cfg['T'], cfg['N']
-    if cfg['kind']:
+    if cfg['kind'] == 'image':
+        ro = O.synthetic_rollout('cartpole', T, N, seed)
+        px = rng.randint(0, 256, (T, N) + cfg['ob_shape'])
+        ro['obs'] = px.astype(np.uint8) if cfg['ob_dtype'] == np.uint8 else (px + rng.rand(*px.shape)).astype(np.float32)
+    elif cfg['kind']:
         ro = O.synthetic_rollout(cfg['kind'], T, N, seed)
     else:
         ro = O.synthetic_rollout('cartpole', T, N, seed)
