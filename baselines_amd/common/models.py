@@ -41,10 +41,10 @@ def _activation_name(activation):
 
 @register('mlp')
 def mlp(num_layers=2, num_hidden=64, activation=None, layer_norm=False):
-    if layer_norm:
-        raise NotImplementedError('layer_norm is outside the supported hot path (SURVEY.md 2.1 row 2)')
+    """models.py:74-103; layer_norm=True: tf.contrib.layers.layer_norm(h, center=True, scale=True) between every fc and its
+    activation (models.py:97-98)"""
     return NetworkDesc('mlp', num_layers=int(num_layers), num_hidden=int(num_hidden),
-                       activation=_activation_name(activation))
+                       activation=_activation_name(activation), layer_norm=bool(layer_norm))
 
 
 @register('cnn')

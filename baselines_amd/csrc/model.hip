@@ -57,6 +57,8 @@ struct Layer {
     long w_off, b_off;
     long out_elems;                        // per sample
     char name[16];                         // c1, c2, c3, fc1, mlp_fc0, ...
+    bool ln = false;                       // layer normalisation between the affine map and the activation (mlp(layer_norm=True))
+    long beta_off = -1, gamma_off = -1;    // [N] each, gamma right behind beta
 };
 
 struct Net {
@@ -173,6 +175,16 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
             snprintf(nm, sizeof nm, "/mlp_fc%d", i);
             f.w_off = add_tensor(m, prefix + nm + "/w", {f.K, f.N}, s2);
             f.b_off = add_tensor(m, prefix + nm + "/b", {f.N}, -1.0);
+            if (d.layer_norm) {
+                // models.py:97-98: tf.contrib.layers.layer_norm(h, center=True, scale=True) in the enclosing scope -> variables
+                // LayerNorm/beta, LayerNorm/gamma (LayerNorm_1/..., ... for the following layers), created beta first
+                char ln[40];
+                if (i == 0) snprintf(ln, sizeof ln, "/LayerNorm");
+                else snprintf(ln, sizeof ln, "/LayerNorm_%d", i);
+                f.ln = true;
+                f.beta_off = add_tensor(m, prefix + ln + "/beta", {f.N}, -1.0);      // zeros
+                f.gamma_off = add_tensor(m, prefix + ln + "/gamma", {f.N}, -2.0);    // ones
+            }
             f.out_elems = f.N;
             snprintf(f.name, sizeof f.name, "mlp_fc%d", i);
             net.L.push_back(f);
@@ -253,6 +265,8 @@ struct NetWs {
     // hpvalid[l] / dzpvalid[l] are set by THIS call's producer (plane stride = rows * width of that call's batch)
     std::vector<uint16_t*> hp, dzp;
     std::vector<char> hpvalid, dzpvalid;
+    // layer normalisation: normalised pre-activations xhat[l] [chunk][N] and 1 / sqrt(var + eps) per row (nullptr: no LN)
+    std::vector<float*> xhat, istd;
     float* lat() const { return hout ? hout : h.back(); }
     float* dlat() const { return dhout ? dhout : dz.back(); }
 };
@@ -273,6 +287,7 @@ constexpr int ADV_G = 256;
 constexpr int SQ_MAX_PART = 8192;            // sum-of-squares partial slots per step
 constexpr int SQ_BLOCKS_PER_LAUNCH = 1024;   // reduce_slabs blocks (= slots) per launch while they are collected
 constexpr int HEAD_MAXBLK = 512;
+constexpr int LN_MAXBLK = 1024;             // layer-norm backward: partial (dbeta | dgamma) slabs
 constexpr int SPART_MAX = 2048;             // stat partials: max(HEAD_MAXBLK, MLP_MAX_TILES)
 constexpr int WGRAD_TARGET_WGS = 1536;
 constexpr int IMGRES_MAX_BLOCKS = 256;      // one persistent workgroup (one partial slab) per CU
@@ -406,7 +421,11 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
     auto do_net = [&](const Net& net, NetWs& nw) {
         nw.h.clear(); nw.dz.clear(); nw.mbits.clear(); nw.mvalid.clear();
         nw.hp.clear(); nw.dzp.clear(); nw.hpvalid.clear(); nw.dzpvalid.clear();
+        nw.xhat.clear(); nw.istd.clear();
         for (const Layer& l : net.L) {
+            nw.xhat.push_back(l.ln ? (float*)take((size_t)chunk * l.out_elems * 4) : nullptr);
+            nw.istd.push_back(l.ln ? (float*)take((size_t)chunk * 4) : nullptr);
+            if (l.ln) part_floats = std::max(part_floats, (size_t)LN_MAXBLK * 2 * l.N);
             const size_t li = nw.h.size();
             // planes of h[l]: a ReLU conv output feeding another layer of the split engines; planes of dz[l]: the A operand of
             // layer l's data gradient (l >= 1)
@@ -1089,6 +1108,69 @@ __global__ __launch_bounds__(256) void heads_act_kernel(HeadArgs a) {
 }
 
 // ============================================================================================
+// layer normalisation of mlp(layer_norm=True) --- common/models.py:97-98: tf.contrib.layers.layer_norm(h, center=True,
+// scale=True): moments over the features of a row (biased variance), y = (z - mean) * rsqrt(var + 1e-12) * gamma + beta,
+// then the activation.  One wave per row; xhat and 1/sqrt(var + eps) are kept for the backward pass.
+// ============================================================================================
+constexpr float LN_EPS = 1e-12f;
+__global__ __launch_bounds__(256) void ln_fwd_kernel(float* __restrict__ h /* in: z, out: act(y) */, float* __restrict__ xhat,
+                                                     float* __restrict__ istd, const float* __restrict__ beta,
+                                                     const float* __restrict__ gamma, int rows, int N, int act) {
+    const int lane = threadIdx.x & 63;
+    for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4L) {
+        float* z = h + r * N;
+        float s = 0.f;
+        for (int c = lane; c < N; c += 64) s += z[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)N;
+        float q = 0.f;
+        for (int c = lane; c < N; c += 64) { const float d = z[c] - mean; q += d * d; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float inv = 1.f / sqrtf(q / (float)N + LN_EPS);
+        if (lane == 0 && istd) istd[r] = inv;
+        for (int c = lane; c < N; c += 64) {
+            const float xh = (z[c] - mean) * inv;
+            if (xhat) xhat[r * N + c] = xh;
+            z[c] = act_fwd(xh * gamma[c] + beta[c], act);
+        }
+    }
+}
+// dy (gradient w.r.t. the normalised, scaled and shifted value) -> dz (w.r.t. the affine map's output), in place, and this
+// block's partial sums of dbeta[c] = sum_r dy[r][c], dgamma[c] = sum_r dy[r][c] * xhat[r][c] (rows in fixed order)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dz, const float* __restrict__ xhat,
+                                                     const float* __restrict__ istd, const float* __restrict__ gamma, int rows,
+                                                     int N, float* __restrict__ part /* [gridDim.x][2N] */) {
+    extern __shared__ float ln_s[];                       // [4 waves][2N]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = ln_s + (long)wave * 2 * N;
+    for (int c = lane; c < 2 * N; c += 64) mine[c] = 0.f;
+    for (long r = blockIdx.x * 4L + wave; r < rows; r += (long)gridDim.x * 4L) {
+        float* g = dz + r * N;
+        const float* xh = xhat + r * N;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            const float gy = g[c] * gamma[c];
+            s1 += gy;
+            s2 += gy * xh[c];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+        const float m1 = s1 / (float)N, m2 = s2 / (float)N, inv = istd[r];
+        for (int c = lane; c < N; c += 64) {
+            const float dy = g[c], x = xh[c];
+            mine[c] += dy;
+            mine[N + c] += dy * x;
+            g[c] = inv * ((dy * gamma[c] - m1) - x * m2);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * N; c += 256)
+        part[(long)blockIdx.x * 2 * N + c] = ((ln_s[c] + ln_s[2 * N + c]) + ln_s[4 * N + c]) + ln_s[6 * N + c];
+}
+
+// ============================================================================================
 // layer launches
 // ============================================================================================
 struct In {               // layer-0 input description
@@ -1421,10 +1503,21 @@ static int net_forward(const mrl_model* m, const Net& net, const In& in, const f
         const bool hb = i < nw.mbits.size() && i + 1 < net.L.size() && net.L[i + 1].kind == 0;
         const bool hpi = i < nw.hp.size();
         const uint16_t* hprev_p = (i && i - 1 < nw.hp.size() && nw.hpvalid[i - 1]) ? nw.hp[i - 1] : nullptr;
-        int rc = layer_forward<kExp>(m, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
+        Layer lcopy;
+        const Layer* lp = &net.L[i];
+        if (lp->ln) { lcopy = *lp; lcopy.act = ACT_NONE; lp = &lcopy; }          // the affine map alone; LN + activation below
+        int rc = layer_forward<kExp>(m, *lp, i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nw.planes, nw.dbg, B, st,
                                hb ? nw.mbits[i] : nullptr, hb ? &nw.mvalid[i] : nullptr, hprev_p, hpi ? nw.hp[i] : nullptr,
                                hpi ? &nw.hpvalid[i] : nullptr, part, part_floats);
         if (rc) return rc;
+        if (net.L[i].ln) {
+            const Layer& l = net.L[i];
+            ProfScope ps("layer_norm.fwd", 0.0, 12.0 * B * l.N, st);
+            const int blocks = (int)std::min<long>(((long)B + 3) / 4, 2048);
+            hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, nw.h[i], i < nw.xhat.size() ? nw.xhat[i] : nullptr,
+                               i < nw.istd.size() ? nw.istd[i] : nullptr, params + l.beta_off, params + l.gamma_off, B, l.N, l.act);
+            MRL_LAUNCH_CHECK();
+        }
     }
     return 0;
 }
@@ -1448,6 +1541,20 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
     for (auto& v : nw.dzpvalid) v = 0;
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
+        if (l.ln) {
+            // nw.dz[i] arrives as the gradient w.r.t. the activation's input = the layer-norm output; turn it into the gradient
+            // w.r.t. the affine map's output (in place) and reduce dbeta | dgamma over the rows
+            const int blocks = (int)std::min<long>(std::min<long>(((long)B + 3) / 4, LN_MAXBLK), (long)(ws.part_floats / (2 * l.N)));
+            if (blocks < 1 || (size_t)i >= nw.xhat.size() || !nw.xhat[i]) return MRL_ENOSPC;
+            {
+                ProfScope ps("layer_norm.bwd", 0.0, 16.0 * B * l.N, st);
+                hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)8 * l.N * sizeof(float), st, nw.dz[i], nw.xhat[i],
+                                   nw.istd[i], params + l.gamma_off, B, l.N, ws.part);
+                MRL_LAUNCH_CHECK();
+            }
+            int rcl = reduce_slabs(ws.part, 2L * l.N, blocks, grads + l.beta_off, 2L * l.N, accumulate, st, &ctx);
+            if (rcl) return rcl;
+        }
         const float* dz = nw.dz[i];
         // plane tensor of dz[i] (the A operand of this layer's data gradient): written by the data gradient of the layer
         // above, or -- for the last layer, whose dz comes from the heads kernel -- by a conversion pass
@@ -1968,7 +2075,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
     const bool mlp_fused = [&] {
         const mrl_model_desc& d = m->d;
         const int K0 = (int)m->ob_elems, nets = m->vf_copy ? 2 : 1, ntiles = (B0 + 31) / 32;
-        return get_option("mlp_fused", "MRL_MLP_FUSED", 1) && d.network == MRL_NET_MLP && d.num_layers == 2 &&
+        return get_option("mlp_fused", "MRL_MLP_FUSED", 1) && d.network == MRL_NET_MLP && d.num_layers == 2 && !d.layer_norm &&
                d.num_hidden == MLP_NH && d.activation == MRL_ACT_TANH && m->has_pi_head && d.nact <= 32 && K0 % 4 == 0 &&
                B0 <= chunk && ntiles <= MLP_MAX_TILES && mlp_step_lds_bytes(K0, nets) <= 160 * 1024 &&
                (size_t)ntiles * m->P <= ws.part_floats && (uintptr_t)params % 16 == 0 && (uintptr_t)obs % 16 == 0;

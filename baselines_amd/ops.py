@@ -82,7 +82,7 @@ class DeviceModel(object):
     """Handle on an `mrl_model` layout object + the device buffers it works on."""
 
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_copy=False, num_layers=2,
-                 num_hidden=64, activation='tanh', nlstm=128, chunk=None, device=None):
+                 num_hidden=64, activation='tanh', nlstm=128, layer_norm=False, chunk=None, device=None):
         _lib.require_gpu()
         lib = _lib.load()
         d = _lib.ModelDesc()
@@ -92,6 +92,7 @@ class DeviceModel(object):
         if d.network in (_lib.NET_MLP, _lib.NET_LSTM):
             ob_shape = (int(np.prod(ob_shape)),)
         d.nlstm = int(nlstm)
+        d.layer_norm = 1 if layer_norm else 0
         d.ob_ndim = len(ob_shape)
         for i, s in enumerate(ob_shape):
             d.ob_shape[i] = s
@@ -123,7 +124,8 @@ class DeviceModel(object):
                                             ctypes.byref(sc)), 'mrl_model_tensor_info')
             shape = tuple(shp[k] for k in range(nd.value))
             self.tensors.append(dict(name=name.value.decode(), shape=shape, offset=off.value,
-                                     size=int(np.prod(shape)), init_scale=(None if sc.value < 0 else sc.value)))
+                                     size=int(np.prod(shape)), init_scale=(None if sc.value < 0 else sc.value),
+                                     init_const=(1.0 if sc.value == -2.0 else 0.0)))     # -2: ones (layer-norm gamma)
         self.device = torch.device(device or 'cuda')
         self.chunk = None
         self.workspace = None

@@ -72,6 +72,8 @@ class Model(object):
         for t in self.dm.tensors:
             if t['init_scale'] is not None:
                 flat[t['offset']:t['offset'] + t['size']] = ortho_init(t['shape'], t['init_scale']).reshape(-1)
+            elif t.get('init_const'):
+                flat[t['offset']:t['offset'] + t['size']] = t['init_const']      # layer-norm gamma: ones
         self.params = torch.from_numpy(flat).to(self.device)
         self.grads = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.adam_m = torch.zeros(P, dtype=torch.float32, device=self.device)

@@ -76,6 +76,8 @@ typedef struct mrl_model_desc {
     int nact;             /* Discrete.n or Box.shape[0] */
     int nlstm;            /* lstm / cnn_lstm: hidden state size (models.py:132, default 128).  32 / 64 / 96 / 128: recurrent weights
                            * register-resident for the whole scan; any other width up to 1024 (e.g. impala_cnn_lstm's 256): streamed from L2 */
+    int layer_norm;       /* mlp(layer_norm=True), models.py:97-98: tf.contrib.layers.layer_norm(h, center=True, scale=True)
+                           * between fc and activation; variables <scope>/LayerNorm[_i]/{beta,gamma} after each layer's w, b */
 } mrl_model_desc;
 
 typedef struct mrl_model mrl_model;   /* host-side layout object; owns no device memory */

@@ -27,7 +27,7 @@ from .ppo2_numpy import ortho_init
 
 
 def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
-                      num_layers=2, num_hidden=64, nlstm=128):
+                      num_layers=2, num_hidden=64, nlstm=128, layer_norm=False):
     """Ordered (name, shape, init_scale|None) list in TF variable-creation order
     (SURVEY.md App. A.6): policy net -> value net copy -> pi head -> [logstd] -> vf head."""
     specs = []
@@ -75,6 +75,12 @@ def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
             for i in range(num_layers):
                 specs.append((prefix + '/mlp_fc%d/w' % i, (nin, num_hidden), math.sqrt(2)))
                 specs.append((prefix + '/mlp_fc%d/b' % i, (num_hidden,), None))
+                if layer_norm:
+                    # common/models.py:97-98: tf.contrib.layers.layer_norm(h, center=True, scale=True) -- variables
+                    # LayerNorm[_i]/beta (zeros), LayerNorm[_i]/gamma (ones), created in that order in the enclosing scope
+                    ln = prefix + ('/LayerNorm' if i == 0 else '/LayerNorm_%d' % i)
+                    specs.append((ln + '/beta', (num_hidden,), None))
+                    specs.append((ln + '/gamma', (num_hidden,), 'ones'))
                 nin = num_hidden
             return nin
         raise ValueError('Unknown network type: {}'.format(network))
@@ -103,6 +109,8 @@ def init_params(specs):
     for name, shape, scale in specs:
         if scale is None:
             out[name] = np.zeros(shape, np.float32)
+        elif scale == 'ones':
+            out[name] = np.ones(shape, np.float32)
         else:
             out[name] = ortho_init(shape, scale)
     return out
@@ -120,15 +128,16 @@ class OracleModel(object):
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_network=None,
                  ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float32,
                  params=None, num_layers=2, num_hidden=64, total_weight=1.0, rank_weight=1.0,
-                 allreduce=None, nlstm=128):
+                 allreduce=None, nlstm=128, layer_norm=False):
         self.network, self.ob_shape, self.ob_dtype = network, tuple(ob_shape), np.dtype(ob_dtype)
         self.pd_kind, self.nact, self.value_network = pd_kind, nact, value_network
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.dtype = dtype
         self.num_layers, self.num_hidden, self.nlstm = num_layers, num_hidden, nlstm
+        self.layer_norm = layer_norm
         self.recurrent = network in ('lstm', 'cnn_lstm')
         self.specs, self.has_pi_head = build_param_specs(network, ob_shape, pd_kind, nact, value_network,
-                                                         num_layers, num_hidden, nlstm)
+                                                         num_layers, num_hidden, nlstm, layer_norm)
         if params is None:
             params = init_params(self.specs)
         self.names = [s[0] for s in self.specs]
@@ -187,7 +196,15 @@ class OracleModel(object):
         else:
             h = x.to(self.dtype).reshape(x.shape[0], -1)
             for i in range(self.num_layers):
-                h = torch.tanh(h @ p[prefix + '/mlp_fc%d/w' % i] + p[prefix + '/mlp_fc%d/b' % i])
+                h = h @ p[prefix + '/mlp_fc%d/w' % i] + p[prefix + '/mlp_fc%d/b' % i]
+                if self.layer_norm:
+                    # tf.contrib.layers.layer_norm: tf.nn.moments over the features (biased variance), variance_epsilon 1e-12,
+                    # tf.nn.batch_normalization(x, mean, var, offset=beta, scale=gamma, eps)
+                    ln = prefix + ('/LayerNorm' if i == 0 else '/LayerNorm_%d' % i)
+                    mean = h.mean(dim=1, keepdim=True)
+                    var = ((h - mean) ** 2).mean(dim=1, keepdim=True)
+                    h = (h - mean) * torch.rsqrt(var + 1e-12) * p[ln + '/gamma'] + p[ln + '/beta']
+                h = torch.tanh(h)
             return h
 
     def forward(self, obs, S=None, M=None, nenv=None):

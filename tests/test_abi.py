@@ -111,10 +111,30 @@ def test_layout_mlp_variants(lib):
     lib.mrl_model_destroy(h)
 
 
+def test_layout_mlp_layer_norm_variable_names(lib):
+    """mlp(layer_norm=True), common/models.py:97-98: tf.contrib.layers.layer_norm variables in creation order"""
+    d = _lib.ModelDesc()
+    d.network, d.ob_ndim, d.ob_dtype, d.num_layers, d.num_hidden = _lib.NET_MLP, 1, _lib.OB_F32, 2, 64
+    d.ob_shape[0] = 8
+    d.activation, d.value_copy, d.pd_kind, d.nact, d.layer_norm = _lib.ACT_TANH, 1, _lib.PD_DIAG_GAUSSIAN, 3, 1
+    h = ctypes.c_void_p()
+    assert lib.mrl_model_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    names = [x[0] for x in _tensors(lib, h)]
+    assert names[:8] == ['ppo2_model/pi/mlp_fc0/w', 'ppo2_model/pi/mlp_fc0/b', 'ppo2_model/pi/LayerNorm/beta',
+                         'ppo2_model/pi/LayerNorm/gamma', 'ppo2_model/pi/mlp_fc1/w', 'ppo2_model/pi/mlp_fc1/b',
+                         'ppo2_model/pi/LayerNorm_1/beta', 'ppo2_model/pi/LayerNorm_1/gamma']
+    assert 'ppo2_model/vf/LayerNorm_1/gamma' in names
+    lib.mrl_model_destroy(h)
+
+
 def test_layout_rejects_unsupported(lib):
-    rc, _ = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 3), ob_dtype=_lib.OB_U8,
+    rc, h = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 3), ob_dtype=_lib.OB_U8,
                     pd_kind=_lib.PD_CATEGORICAL, nact=6)
-    assert rc == -3            # MRL_EUNSUP: channel count must be a multiple of 4
+    assert rc == 0             # any channel count / image dtype (common/models.py:19 casts whatever comes)
+    lib.mrl_model_destroy(h)
+    rc, _ = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(20, 20, 4), ob_dtype=_lib.OB_U8,
+                    pd_kind=_lib.PD_CATEGORICAL, nact=6)
+    assert rc == -3            # MRL_EUNSUP: image too small for the 8x8/4, 4x4/2, 3x3/1 VALID stack
     rc, _ = _layout(lib, network=_lib.NET_MLP, ob_shape=(4,), ob_dtype=_lib.OB_F32, pd_kind=7, nact=2)
     assert rc == -3
 

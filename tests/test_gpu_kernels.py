@@ -76,12 +76,14 @@ def _make_pair(network, ob_shape, ob_dtype, pd_kind, nact, value_network, seed, 
                      max_grad_norm=kw.pop('max_grad_norm', 0.5), **kw)
     dm = ops.DeviceModel(network=network, ob_shape=ob_shape, ob_dtype=ob_dtype, pd_kind=pd_kind, nact=nact,
                          value_copy=(value_network == 'copy'), chunk=chunk,
-                         num_layers=kw.get('num_layers', 2), num_hidden=kw.get('num_hidden', 64))
+                         num_layers=kw.get('num_layers', 2), num_hidden=kw.get('num_hidden', 64),
+                         layer_norm=kw.get('layer_norm', False))
     # layout must equal the reference's variable order / shapes
     assert [t['name'] for t in dm.tensors] == om.names
     for t, (nm, shp, sc) in zip(dm.tensors, om.specs):
         assert tuple(t['shape']) == tuple(shp), (nm, t['shape'], shp)
-        assert (t['init_scale'] is None) == (sc is None)
+        assert (t['init_scale'] is None) == (sc is None or sc == 'ones')
+        assert (t['init_const'] == 1.0) == (sc == 'ones')
     flat = om.flat_params()
     assert flat.size == dm.P
     return om, dm, dev(flat.astype(np.float32))
@@ -104,6 +106,9 @@ CONFIGS = {
                       value_network=None, kind='atari', T=4, N=8, B=24, chunk=16),
     'mlp_matching_fc': dict(network='mlp', ob_shape=(11,), ob_dtype=np.float32, pd_kind='gaussian', nact=64,
                             value_network=None, kind=None, T=8, N=8, B=32, chunk=32),
+    # mlp(layer_norm=True) (common/models.py:97-98), separate value network, three layers of 48 units
+    'mlp_layer_norm': dict(network='mlp', ob_shape=(11,), ob_dtype=np.float32, pd_kind='gaussian', nact=3,
+                           value_network='copy', kind=None, T=8, N=8, B=48, chunk=32, layer_norm=True, num_layers=3, num_hidden=48),
     # nature_cnn on images that are not Atari frame stacks (common/models.py:19 casts and scales any image): RGB uint8,
     # single-channel float, 4-channel float -- first layer on the generic tiled engine, /255 in its loader
     'cnn_rgb_u8': dict(network='cnn', ob_shape=(44, 48, 3), ob_dtype=np.uint8, pd_kind='categorical', nact=4,
@@ -154,7 +159,7 @@ def test_model_act_grad_train_vs_oracle(name):
     om64 = OracleModel(network=cfg['network'], ob_shape=cfg['ob_shape'], ob_dtype=cfg['ob_dtype'],
                        pd_kind=cfg['pd_kind'], nact=cfg['nact'], value_network=cfg['value_network'],
                        ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float64,
-                       params=om.params_numpy())
+                       params=om.params_numpy(), **{k: cfg[k] for k in ('layer_norm', 'num_layers', 'num_hidden') if k in cfg})
     returns, _ = O.gae(ro['rewards'], ro['values'], ro['dones'], ro['last_values'], ro['last_dones'], 0.99, 0.95)
 
     # ---- act side (teacher-forced noise) ----
