@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r03d}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-gpu}
 cd $R; mkdir -p $O
 t0=$(date +%s)
 timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "engine_options" > $O/${TAG}_pytest.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r03j}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-gpu}
 cd $R; mkdir -p $O
 t0=$(date +%s)
 timeout 900 python -m pytest $2 -m gpu -x -q --durations=5 > $O/${TAG}_pytest.log 2>&1

@@ -19,7 +19,7 @@ LABELS = {
     'c1.wgrad': 'c1wgrad_half_kernel',
     'c2.wgrad': 'wgrad_tr_kernel<20, 20, 32',
     'c3.wgrad': 'wgrad_tr_kernel<9, 9, 64',
-    'fc1.wgrad': 'wgrad_x8_kernel<mrl::X6DenseA',
+    'fc1.wgrad': 'wgrad_tr_dense_kernel',
     'fc1.dgrad': 'gemm_x6_kernel<mrl::X6DenseA, mrl::TrMaskRelu',      # transposed-accumulator epilogue (planes.hip.h)
 }
 
