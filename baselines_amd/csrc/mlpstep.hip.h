@@ -43,11 +43,35 @@ struct MlpStepArgs {
 
 constexpr int MLP_NH = 64;             // hidden width
 constexpr int MLP_LD = MLP_NH + 4;     // LDS row stride of the 64-wide activations
+// Workgroup = 8 waves (round 3; 4 before).  The step is a chain of LATENCY-bound phases on a 32-sample tile -- 128 workgroups
+// for a 4096-sample minibatch, half the chip idle whatever the workgroup size -- so the waves of a workgroup are what
+// shortens a phase: the k range of the two forward GEMMs is split over two wave groups (partial accumulators combined
+// through LDS in a fixed order), the 12 + 48 weight-gradient tiles and every thread-strided loop are spread over twice
+// the waves.
+
+// deterministic block-wide sum of doubles (MLP_NW waves), result valid in thread 0
+template <int MLP_NW>
+__device__ __forceinline__ double mlp_block_sum(double v, double* sh /* >= MLP_NW doubles */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < MLP_NW; ++q) r += sh[q];
+    }
+    return r;
+}
 
 #define MRL_MLP_HALF_LOG_2PI 0.9189385332046727f
 #define MRL_MLP_HALF_LOG_2PIE 1.4189385332046727f
 
-__global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
+template <int MLP_NT>
+__global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
+    constexpr int MLP_NW = MLP_NT / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -80,6 +104,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
     float* wpi_s = dv_s + 32;                            // [64][nact] policy head weights
     float* wvf_s = wpi_s + 64 * 32;                      // [64] value head weights
     long* row_s = reinterpret_cast<long*>(wvf_s + 64);   // [32] storage rows (-1: beyond the minibatch)
+    float* kp_s = reinterpret_cast<float*>(row_s + 32);  // [4 waves][16][64] partial accumulators of the second k half
 
     // ---- P0: rows + observation tile
     if (tid < 32) {
@@ -95,12 +120,12 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
         double s1 = 0.0, s2 = 0.0;
         // batches of 8 samples per thread: all index loads, then all gathers in flight together (one wave per SIMD here:
         // every dependent load would otherwise expose its full latency, 2 per sample)
-        for (int b0 = tid; b0 < a.Bstat; b0 += 8 * 256) {
+        for (int b0 = tid; b0 < a.Bstat; b0 += 8 * MLP_NT) {
             long r[8];
             float rv[8], vv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int b = min(b0 + u * 256, a.Bstat - 1);
+                const int b = min(b0 + u * MLP_NT, a.Bstat - 1);
                 r[u] = a.stat_idx ? (long)a.stat_idx[b] : (long)b;
             }
 #pragma unroll
@@ -111,24 +136,24 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (b0 + u * 256 < a.Bstat) {
+                if (b0 + u * MLP_NT < a.Bstat) {
                     const float x = __fsub_rn(rv[u], vv[u]);
                     s1 += (double)x;
                     s2 += (double)x * (double)x;
                 }
         }
-        const double t1 = block_sum_256(s1, red);
-        const double t2 = block_sum_256(s2, red + 4);
+        const double t1 = mlp_block_sum<MLP_NW>(s1, red);
+        const double t2 = mlp_block_sum<MLP_NW>(s2, red + MLP_NW);
         if (tid == 0) {
             const double mean = t1 / a.Bstat;
             double var = t2 / a.Bstat - mean * mean;
             if (var < 0) var = 0;
-            red[8] = (double)(float)mean;
-            red[9] = (double)(float)sqrt(var);
+            red[2 * MLP_NW] = (double)(float)mean;
+            red[2 * MLP_NW + 1] = (double)(float)sqrt(var);
         }
         __syncthreads();
-        adv_mean = (float)red[8];
-        adv_sd = (float)red[9] + 1e-8f;
+        adv_mean = (float)red[2 * MLP_NW];
+        adv_sd = (float)red[2 * MLP_NW + 1] + 1e-8f;
     } else {
         adv_mean = a.advstat[0];
         adv_sd = a.advstat[1] + 1e-8f;
@@ -137,11 +162,11 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
     // one wave per SIMD: every memory latency is exposed, so loads are issued in batches of 8 before use
     {
         const int nv = 32 * (KP / 4);
-        for (int e0 = tid; e0 < nv; e0 += 8 * 256) {
+        for (int e0 = tid; e0 < nv; e0 += 8 * MLP_NT) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * 256;
+                const int e = e0 + u * MLP_NT;
                 v[u] = f4zero();
                 if (e < nv) {
                     const int s = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * 256;
+                const int e = e0 + u * MLP_NT;
                 if (e < nv) {
                     const int s = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
                     *reinterpret_cast<float4*>(obs_s + s * KP + c4) = v[u];
@@ -160,15 +185,16 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
             }
         }
         // small weights -> LDS (coalesced): pi head, value head, biases, logstd
-        for (int e = tid; e < 64 * nact; e += 256) wpi_s[e] = P[a.wpi + e];
-        for (int e = tid; e < 64; e += 256) wvf_s[e] = P[a.wvf + e];
+        for (int e = tid; e < 64 * nact; e += MLP_NT) wpi_s[e] = P[a.wpi + e];
+        for (int e = tid; e < 64; e += MLP_NT) wvf_s[e] = P[a.wvf + e];
     }
     __syncthreads();
 
     stamp(1);
-    // ---- P1: fc0 forward.  wave -> (net, 32-column tile); nets == 1: waves 2,3 idle
+    // ---- P1: fc0 forward.  wave -> (k half, net, 32-column tile); nets == 1: waves 2, 3, 6, 7 idle
     {
-        const int net = wave >> 1, n0 = (wave & 1) * 32;
+        const int wq = wave & 3, khalf = wave >> 2;
+        const int net = wq >> 1, n0 = (wq & 1) * 32;
         if (net < nets) {
             const float* W = P + W0(net);
             f32x16 acc;
@@ -201,10 +227,12 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
                     }
                 }
             };
-            const int NG = (KB0 + 3) / 4;
+            // groups of 4 k blocks: [0, NGH) for the first wave group, [NGH, NGT) for the second
+            const int NGT = (KB0 + 3) / 4, NGH = MLP_NW > 4 ? (NGT + 1) / 2 : NGT;
+            const int gb = khalf ? NGH : 0, NG = khalf ? NGT : NGH;
             float fb0[16], fb1[16];
-            loadg(0, fb0);
-            for (int g = 0; g < NG; g += 2) {
+            if (gb < NG) loadg(gb, fb0);
+            for (int g = gb; g < NG; g += 2) {
                 if (g + 1 < NG) loadg(g + 1, fb1);
                 mmag(g, fb0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -212,21 +240,31 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
                 if (g + 1 < NG) mmag(g + 1, fb1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float bias = P[B0(net) + n0 + i];
+            if (khalf) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                h0_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(acc[r] + bias);
+                for (int r = 0; r < 16; ++r) kp_s[(wq * 16 + r) * 64 + lane] = acc[r];
             }
+            __syncthreads();                                     // (waves of the same net: both halves arrive here)
+            if (!khalf) {
+                const float bias = P[B0(net) + n0 + i];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float part = MLP_NW > 4 ? kp_s[(wq * 16 + r) * 64 + lane] : 0.f;
+                    h0_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(MLP_NW > 4 ? (acc[r] + part) + bias : acc[r] + bias);
+                }
+            }
+        } else {
+            __syncthreads();
         }
     }
     __syncthreads();
 
     stamp(2);
-    // ---- P2: fc1 forward
+    // ---- P2: fc1 forward (K = 64: 32 MFMAs per tile, the first four waves)
     {
         const int net = wave >> 1, n0 = (wave & 1) * 32;
-        if (net < nets) {
+        if (wave < 4 && net < nets) {
             const float* W = P + W1(net);
             f32x16 acc;
 #pragma unroll
@@ -258,7 +296,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
     // ---- P3a: pdparam (mean / logits) and value, same fmaf order as heads_train_kernel
     const float* lat = h1_s;                                 // policy latent
     const float* vlat = shared ? h1_s : h1_s + 32 * MLP_LD;  // value latent
-    for (int q = tid; q < 32 * (nact + 1); q += 256) {
+    for (int q = tid; q < 32 * (nact + 1); q += MLP_NT) {
         const int s = q / (nact + 1), j = q - s * (nact + 1);
         if (j < nact) {
             float acc = 0.f;
@@ -371,7 +409,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
     // ---- P4: head parameter gradients (slab) + dz of the last hidden layer (LDS)
     {
         const int HPn = 64 * nact + nact;            // pi/w, pi/b
-        for (int e = tid; e < HPn; e += 256) {
+        for (int e = tid; e < HPn; e += MLP_NT) {
             float g = 0.f;
             if (e < 64 * nact) {
                 const int k = e / nact, j = e - k * nact;
@@ -384,12 +422,12 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
             }
         }
         if (a.logstd >= 0)
-            for (int j = tid; j < nact; j += 256) {
+            for (int j = tid; j < nact; j += MLP_NT) {
                 float g = 0.f;
                 for (int s = 0; s < 32; ++s) g += dls_s[s * 32 + j];
                 slab[a.logstd + j] = g;
             }
-        for (int k = tid; k < 65; k += 256) {
+        for (int k = tid; k < 65; k += MLP_NT) {
             float g = 0.f;
             if (k < 64) {
                 for (int s = 0; s < 32; ++s) g = fmaf(vlat[s * MLP_LD + k], dv_s[s], g);
@@ -399,7 +437,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
                 slab[a.bvf] = g;
             }
         }
-        for (int q = tid; q < 32 * 64; q += 256) {
+        for (int q = tid; q < 32 * 64; q += MLP_NT) {
             const int s = q >> 6, k = q & 63;
             float g = 0.f;
             const float* w = wpi_s + k * nact;
@@ -418,7 +456,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
 
     stamp(5);
     // ---- P5: fc1 backward.  Tiles per net: dW1 (2x2 tiles, K = 32 samples) and dh0 (2 tiles, K = 64)
-    for (int t = wave; t < 6 * nets; t += 4) {
+    for (int t = wave; t < 6 * nets; t += MLP_NW) {
         const int net = t / 6, q = t % 6;
         f32x16 acc;
 #pragma unroll
@@ -459,7 +497,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
         }
     }
     // bias gradients of fc1: column sums of dz1 (sample order)
-    for (int e = tid; e < 64 * nets; e += 256) {
+    for (int e = tid; e < 64 * nets; e += MLP_NT) {
         const int net = e >> 6, n = e & 63;
         float g = 0.f;
         for (int s = 0; s < 32; ++s) g += dz1_s[(net * 32 + s) * MLP_LD + n];
@@ -500,15 +538,15 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
         };
         float a0[16], b0v[16], a1[16], b1v[16];
         if (wave < ntile) ldtile(wave, a0, b0v);
-        for (int t = wave; t < ntile; t += 8) {
-            if (t + 4 < ntile) ldtile(t + 4, a1, b1v);
+        for (int t = wave; t < ntile; t += 2 * MLP_NW) {
+            if (t + MLP_NW < ntile) ldtile(t + MLP_NW, a1, b1v);
             dotile(t, a0, b0v);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 8 < ntile) ldtile(t + 8, a0, b0v);
-            if (t + 4 < ntile) dotile(t + 4, a1, b1v);
+            if (t + 2 * MLP_NW < ntile) ldtile(t + 2 * MLP_NW, a0, b0v);
+            if (t + MLP_NW < ntile) dotile(t + MLP_NW, a1, b1v);
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (int e = tid; e < 64 * nets; e += 256) {
+        for (int e = tid; e < 64 * nets; e += MLP_NT) {
             const int net = e >> 6, n = e & 63;
             float g = 0.f;
             for (int s = 0; s < 32; ++s) g += dz0_s[(net * 32 + s) * MLP_LD + n];
@@ -522,7 +560,7 @@ __global__ __launch_bounds__(256) void mlp_step_kernel(MlpStepArgs a) {
 inline size_t mlp_step_lds_bytes(int K0, int nets) {
     const int KP = (K0 + 7) / 8 * 8 + 4;
     size_t floats = (size_t)32 * KP + (size_t)4 * nets * 32 * MLP_LD + 3 * 32 * 32 + 64 + 64 * 32 + 64;
-    return floats * 4 + 32 * sizeof(long) + 64;
+    return floats * 4 + 32 * sizeof(long) + (size_t)4 * 16 * 64 * sizeof(float) + 64;
 }
 
 }  // namespace mrl
