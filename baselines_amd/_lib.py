@@ -27,7 +27,8 @@ class QNetDesc(ctypes.Structure):
     """mirror of mrl_qnet_desc (include/mrl.h)"""
     _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
                 ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('nconv', c_int),
-                ('convs', (c_int * 3) * 4), ('nhidden', c_int), ('hiddens', c_int * 4), ('dueling', c_int), ('nact', c_int)]
+                ('convs', (c_int * 3) * 4), ('nhidden', c_int), ('hiddens', c_int * 4), ('dueling', c_int), ('nact', c_int),
+                ('layer_norm', c_int)]
 
 PD_CATEGORICAL, PD_DIAG_GAUSSIAN = 0, 1
 OB_F32, OB_U8 = 0, 1
@@ -79,6 +80,7 @@ SIGNATURES = {
     'mrl_qnet_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_qnet_td_grad': (c_int, [c_void_p] * 9 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    'mrl_qnet_policy_kl': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'mrl_qnet_adam_step': (c_int, [c_void_p] * 5 + [c_float, c_void_p] + [c_float] * 4 + [c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_synth_env_obs': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mrl_synth_env_step': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

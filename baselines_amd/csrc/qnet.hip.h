@@ -41,6 +41,14 @@ static int q_build_heads(mrl_qnet* q, Net& net, const std::string& scope, int no
         std::string nm = scope + (i ? "/fully_connected_" + std::to_string(i) : std::string("/fully_connected"));
         f.w_off = q_add_tensor(q, nm + "/weights", {f.K, f.N}, 2, 1.0);
         f.b_off = q_add_tensor(q, nm + "/biases", {f.N}, 0, -1.0);
+        if (q->qd.layer_norm && !last) {
+            // deepq/models.py:27-29, 37-39: layers.layer_norm(out, center=True, scale=True) between the affine map and the
+            // ReLU of every hidden head layer -> LayerNorm/beta, LayerNorm/gamma (LayerNorm_1/... for the next) in the scope
+            std::string ln = scope + (i ? "/LayerNorm_" + std::to_string(i) : std::string("/LayerNorm"));
+            f.ln = true;
+            f.beta_off = q_add_tensor(q, ln + "/beta", {f.N}, 0, -1.0);
+            f.gamma_off = q_add_tensor(q, ln + "/gamma", {f.N}, 3, -2.0);
+        }
         f.out_elems = f.N;
         snprintf(f.name, sizeof f.name, "%s%d", scope.find("action") != std::string::npos ? "av" : "sv", i);
         net.L.push_back(f);
@@ -130,8 +138,11 @@ static void q_carve(const mrl_qnet* q, int B, char* base, QWs& ws) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     size_t part_floats = 1;
     auto do_net = [&](const Net& net, NetWs& nw) {
-        nw.h.clear(); nw.dz.clear();
+        nw.h.clear(); nw.dz.clear(); nw.xhat.clear(); nw.istd.clear();
         for (const Layer& l : net.L) {
+            nw.xhat.push_back(l.ln ? (float*)take((size_t)B * l.out_elems * 4) : nullptr);
+            nw.istd.push_back(l.ln ? (float*)take((size_t)B * 4) : nullptr);
+            if (l.ln) part_floats = std::max(part_floats, (size_t)LN_MAXBLK * 2 * l.N);
             nw.h.push_back((float*)take((size_t)B * l.out_elems * 4));
             nw.dz.push_back((float*)take((size_t)B * l.out_elems * 4));
             part_floats = std::max(part_floats, (size_t)max_split_floats(l.K, l.N, layer_rows(l, B)));
@@ -198,6 +209,30 @@ __global__ __launch_bounds__(256) void q_act_kernel(const float* __restrict__ q,
         if (r[j] > bv) { bv = r[j]; best = j; }
     act[b] = (u && u[b] < eps) ? rnd[b] : best;
 }
+// mean over the batch of KL(softmax(qa) || softmax(qb)) (build_graph.py:283-284: the distance between the greedy policies of
+// the unperturbed and the adaptively perturbed network that steers the parameter-noise scale); one workgroup, fixed order
+__global__ __launch_bounds__(256) void q_policy_kl_kernel(const float* __restrict__ qa, const float* __restrict__ qb, int B, int nA,
+                                                          float* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* a = qa + (long)b * nA;
+        const float* c = qb + (long)b * nA;
+        float ma = a[0], mb = c[0];
+        for (int j = 1; j < nA; ++j) { ma = fmaxf(ma, a[j]); mb = fmaxf(mb, c[j]); }
+        float za = 0.f, zb = 0.f;
+        for (int j = 0; j < nA; ++j) { za += expf(a[j] - ma); zb += expf(c[j] - mb); }
+        const float la = logf(za), lb = logf(zb);
+        float kl = 0.f;
+        for (int j = 0; j < nA; ++j) {
+            const float lpa = (a[j] - ma) - la, lpb = (c[j] - mb) - lb;      // log softmax
+            kl += expf(lpa) * (lpa - lpb);
+        }
+        s += (double)kl;
+    }
+    const double t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[0] = (float)(t / (double)B);
+}
 // out = (out_prev + acc) * act'(h): second half of a two-source data gradient
 struct EpiAddMaskAct {
     static constexpr bool HAS_BIAS = false;
@@ -257,9 +292,19 @@ static int q_heads_forward(const mrl_qnet* q, const Net& net, const float* lat, 
                            hipStream_t st, float* part, size_t part_floats) {
     In in{lat, nullptr};
     for (size_t i = 0; i < net.L.size(); ++i) {
-        int rc = layer_forward<kExp>(&q->base, net.L[i], i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st,
+        Layer lcopy;
+        const Layer* lp = &net.L[i];
+        if (lp->ln) { lcopy = *lp; lcopy.act = ACT_NONE; lp = &lcopy; }          // the affine map alone; LN + ReLU below
+        int rc = layer_forward<kExp>(&q->base, *lp, i == 0, in, i ? nw.h[i - 1] : nullptr, params, nw.h[i], nullptr, nullptr, B, st,
                                      nullptr, nullptr, nullptr, nullptr, nullptr, part, part_floats);
         if (rc) return rc;
+        if (net.L[i].ln) {
+            const Layer& l = net.L[i];
+            const int blocks = (int)std::min<long>(((long)B + 3) / 4, 2048);
+            hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, nw.h[i], nw.xhat[i], nw.istd[i], params + l.beta_off,
+                               params + l.gamma_off, B, l.N, l.act);
+            MRL_LAUNCH_CHECK();
+        }
     }
     return 0;
 }
@@ -304,6 +349,13 @@ extern "C" int mrl_qnet_act(const mrl_qnet* q, const float* params, const void* 
     if (rc) return rc;
     hipLaunchKernelGGL(q_act_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, qo, uniforms, rand_actions, eps,
                        actions_out, n, q->qd.nact);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mrl_qnet_policy_kl(const float* q_a, const float* q_b, int n, int nact, float* mean_kl_out, void* stream) {
+    if (!q_a || !q_b || !mean_kl_out || n <= 0 || nact <= 0) return MRL_EINVAL;
+    hipLaunchKernelGGL(q_policy_kl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q_a, q_b, n, nact, mean_kl_out);
     MRL_LAUNCH_CHECK();
     return 0;
 }

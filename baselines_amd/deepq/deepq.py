@@ -115,13 +115,11 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
     Data path of a train step: everything stays in HBM -- `sample_dev` gathers the minibatch on the device,
     `QModel.train_dev` replays the captured optimizer step and leaves the TD errors on the device, and
     `update_priorities_from_td` turns them into priorities there (deepq.py:291-303 without the reference's host arrays)."""
-    if param_noise:
-        raise NotImplementedError('parameter-space noise is outside the supported hot path')
     set_global_seeds(seed)
     q_func = build_q_func(network, **network_kwargs)
     act_params = dict(q_func=q_func, observation_space=env.observation_space, num_actions=env.action_space.n)
     # deepq.py:205-213: AdamOptimizer(learning_rate=lr) (epsilon 1e-8), gamma, grad_norm_clipping=10, double_q (default)
-    model = QModel(lr=lr, gamma=gamma, grad_norm_clipping=10, max_batch=batch_size, **act_params)
+    model = QModel(lr=lr, gamma=gamma, grad_norm_clipping=10, max_batch=batch_size, param_noise=param_noise, **act_params)
     act = ActWrapper(model, act_params)
 
     if prioritized_replay:
@@ -138,6 +136,7 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
 
     episode_rewards = [0.0]
     obs = env.reset()
+    reset = True
     checkpoints = _Checkpointer(model, act, checkpoint_path, print_freq is not None)
     checkpoints.load_existing(load_path)
 
@@ -153,7 +152,19 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
     for t in range(total_timesteps):
         if callback is not None and callback(locals(), globals()):
             break
-        action = act(np.array(obs)[None], update_eps=exploration.value(t))[0]
+        kwargs = {}
+        if not param_noise:
+            update_eps = exploration.value(t)
+        else:
+            # deepq.py:263-275: eps-greedy off; the perturbation is sized so that the KL between the perturbed and the
+            # unperturbed policy matches that of eps-greedy exploration at the current eps (Plappert et al. 2017, app. C.1)
+            update_eps = 0.
+            update_param_noise_threshold = -np.log(1. - exploration.value(t) + exploration.value(t) / float(env.action_space.n))
+            kwargs['reset'] = reset
+            kwargs['update_param_noise_threshold'] = update_param_noise_threshold
+            kwargs['update_param_noise_scale'] = True
+        action = act(np.array(obs)[None], update_eps=update_eps, **kwargs)[0]
+        reset = False
         new_obs, rew, done, _ = env.step(action)
         replay_buffer.add(obs, action, rew, new_obs, float(done))
         obs = new_obs
@@ -161,6 +172,7 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
         if done:
             obs = env.reset()
             episode_rewards.append(0.0)
+            reset = True
 
         learning = t > learning_starts
         if learning and t % train_freq == 0:

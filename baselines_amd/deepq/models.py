@@ -1,7 +1,7 @@
 """`build_q_func` with the reference's signature (deepq/models.py:5-45).  Where the reference returns a TF graph
 builder, this returns a *description* (`QFuncDesc`) that the device layout in libmrl (csrc/qnet.hip.h) understands:
 
-    q = network(X) -> flatten -> action_value: [fc(h) -> relu for h in hiddens] -> fc(num_actions)
+    q = network(X) -> flatten -> action_value: [fc(h) -> [layer_norm] -> relu for h in hiddens] -> fc(num_actions)
         dueling:     state_value: [fc(h) -> relu ...] -> fc(1);   q = V + (A - mean_a A)
 
 `network`: 'mlp' / 'cnn' (common/models.py, via our registry) or 'conv_only' (common/models.py:222-249:
@@ -17,16 +17,15 @@ def conv_only(convs=((32, 8, 4), (64, 4, 2), (64, 3, 1)), **conv_kwargs):
 
 
 class QFuncDesc(object):
-    def __init__(self, network, hiddens, dueling):
+    def __init__(self, network, hiddens, dueling, layer_norm=False):
         self.network, self.hiddens, self.dueling = network, tuple(int(h) for h in hiddens), bool(dueling)
+        self.layer_norm = bool(layer_norm)
 
     def __repr__(self):
-        return 'QFuncDesc(%r, hiddens=%r, dueling=%r)' % (self.network, self.hiddens, self.dueling)
+        return 'QFuncDesc(%r, hiddens=%r, dueling=%r, layer_norm=%r)' % (self.network, self.hiddens, self.dueling, self.layer_norm)
 
 
 def build_q_func(network, hiddens=(256,), dueling=True, layer_norm=False, **network_kwargs):
-    if layer_norm:
-        raise NotImplementedError('layer_norm in the Q heads is outside the supported hot path')
     if isinstance(network, str):
         network = get_network_builder(network)(**network_kwargs)
     if not isinstance(network, NetworkDesc):
@@ -35,4 +34,4 @@ def build_q_func(network, hiddens=(256,), dueling=True, layer_norm=False, **netw
         raise NotImplementedError('DQN is not compatible with recurrent policies yet')     # deepq/models.py:14-16
     if network.kind not in ('mlp', 'cnn', 'conv_only'):
         raise ValueError('Unknown network type: {}'.format(network.kind))
-    return QFuncDesc(network, hiddens, dueling)
+    return QFuncDesc(network, hiddens, dueling, layer_norm)

@@ -2,6 +2,7 @@
 (deepq/build_graph.py:317-449):
 
     act(ob, stochastic=True, update_eps=-1)            eps-greedy actions (:146-199)
+    act(ob, reset, update_param_noise_threshold, update_param_noise_scale, ...)   with param_noise=True (:202-315)
     train(obs_t, action, reward, obs_tp1, done, weight) -> td_errors   one Adam step on the weighted Huber TD loss (:380-444)
     update_target()                                    target <- online (:423-428)
     debug['q_values'](obs)
@@ -19,9 +20,15 @@ from .._lib import c_void_p, check, ptr, stream_ptr
 from ..ppo2.model import ortho_init
 
 
+def default_param_noise_filter(name):
+    """build_graph.py:131-143 on variable NAMES (every variable of the Q-network is trainable): only the
+    tf.contrib.layers.fully_connected layers -- the action-value / state-value heads -- are perturbed"""
+    return 'fully_connected' in name
+
+
 class QModel(object):
     def __init__(self, q_func, observation_space, num_actions, lr=5e-4, gamma=1.0, grad_norm_clipping=10, double_q=True,
-                 max_batch=32, adam_epsilon=1e-8, device=None):
+                 max_batch=32, adam_epsilon=1e-8, device=None, param_noise=False, param_noise_filter_func=None):
         _lib.require_gpu()
         lib = self.lib = _lib.load()
         self.device = torch.device(device or ('cuda:%d' % torch.cuda.current_device()))
@@ -56,6 +63,7 @@ class QModel(object):
             d.hiddens[i] = int(h)
         d.dueling = 1 if q_func.dueling else 0
         d.nact = self.num_actions
+        d.layer_norm = 1 if getattr(q_func, 'layer_norm', False) else 0
         self.ob_shape, self.torch_ob_dtype = ob_shape, (torch.uint8 if d.ob_dtype == _lib.OB_U8 else torch.float32)
         h = c_void_p()
         check(lib.mrl_qnet_create(ctypes.byref(d), ctypes.byref(h)), 'mrl_qnet_create')
@@ -86,6 +94,24 @@ class QModel(object):
         self._loss = torch.empty(1, dtype=torch.float32, device=self.device)
         self._graphs = {}                                # batch size -> captured optimizer step (train_dev)
         self._ones = {}
+        self.param_noise = bool(param_noise)
+        if self.param_noise:
+            # build_graph.py:241-262: two more copies of q_func -- the one that acts (re-perturbed on `reset`) and the one
+            # the scale adaptation probes; noise goes to the variables the filter accepts (default_param_noise_filter,
+            # :131-143: the tf.contrib 'fully_connected' layers, i.e. the Q heads)
+            flt = param_noise_filter_func or default_param_noise_filter
+            mask = np.zeros(self.P, np.float32)
+            for t in self.tensors:
+                if flt(t['name']):
+                    mask[t['offset']:t['offset'] + t['size']] = 1.0
+            self._noise_mask = torch.from_numpy(mask).to(self.device)
+            # TF initialises the copies with their own random draws; they are overwritten by the first reset=True call
+            # (deepq.py:223 starts with reset=True), so they start as plain copies here
+            self.perturbed = self.params.clone()
+            self.adaptive = self.params.clone()
+            self.param_noise_scale = np.float32(0.01)        # build_graph.py:238
+            self.param_noise_threshold = np.float32(0.05)    # build_graph.py:239
+            self._kl = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def _initial_parameters(self):
         """common.models networks: orthogonal init from the global NumPy stream like the reference (a2c/utils.py:20-35);
@@ -102,6 +128,8 @@ class QModel(object):
                 fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive
                 lim = np.sqrt(6.0 / (fan_in + fan_out))
                 flat[sl] = np.random.uniform(-lim, lim, size=t['size']).astype(np.float32)
+            elif t['init_kind'] == 3:
+                flat[sl] = 1.0                                    # LayerNorm gamma
         return flat
 
     def _set_batch(self, n):
@@ -146,8 +174,73 @@ class QModel(object):
               'mrl_qnet_values')
         return out.cpu().numpy()
 
-    def act(self, ob, stochastic=True, update_eps=-1):
-        """build_graph.py:146-199; returns int64 actions [n] like tf.argmax"""
+    def _perturb(self, dst):
+        """perturb_vars (build_graph.py:264-277): dst <- params + N(0, scale) on the filtered variables, a copy elsewhere"""
+        noise = torch.randn(self.P, generator=self._gen, device=self.device, dtype=torch.float32)
+        torch.addcmul(self.params, noise, self._noise_mask, value=float(self.param_noise_scale), out=dst)
+
+    def _values_with(self, params, obs, n):
+        out = torch.empty((n, self.num_actions), dtype=torch.float32, device=self.device)
+        check(self.lib.mrl_qnet_values(self.handle, ptr(params), ptr(obs), n, ptr(out), ptr(self.workspace),
+                                       self.workspace.numel(), self.max_batch, stream_ptr()), 'mrl_qnet_values')
+        return out
+
+    def _act_param_noise(self, ob, reset, update_param_noise_threshold, update_param_noise_scale, stochastic, update_eps):
+        """build_graph.py:202-315.  One session.run of the reference: the outputs (greedy actions of the PERTURBED network,
+        eps-random otherwise) are computed from the variables as they were before the run's update ops; the updates are
+        eps.assign, the re-perturbation on `reset`, the scale adaptation and the threshold assign (:300-307)."""
+        obs = self._obs(ob)
+        n = obs.shape[0]
+        self._set_batch(n)
+        u = rnd = None
+        if stochastic:
+            u = torch.rand(n, generator=self._gen, device=self.device, dtype=torch.float32)
+            rnd = torch.randint(0, self.num_actions, (n,), generator=self._gen, device=self.device, dtype=torch.int32)
+        a = torch.empty(n, dtype=torch.int32, device=self.device)
+        check(self.lib.mrl_qnet_act(self.handle, ptr(self.perturbed), ptr(obs), n, float(self.eps), ptr(u), ptr(rnd), ptr(a),
+                                    None, ptr(self.workspace), self.workspace.numel(), self.max_batch, stream_ptr()),
+              'mrl_qnet_act')
+        if update_eps >= 0:
+            self.eps = float(update_eps)
+        if reset:
+            self._perturb(self.perturbed)
+        if update_param_noise_scale:
+            # update_scale (:279-291): perturb the adaptive copy, measure the action-space distance to the unperturbed
+            # policy on this observation batch, grow the scale by 1 % when it is below the threshold, shrink it otherwise
+            self._perturb(self.adaptive)
+            qa, qb = self._values_with(self.params, obs, n), self._values_with(self.adaptive, obs, n)
+            check(self.lib.mrl_qnet_policy_kl(ptr(qa), ptr(qb), n, self.num_actions, ptr(self._kl), stream_ptr()),
+                  'mrl_qnet_policy_kl')
+            self.last_kl = float(self._kl.item())
+            if self.last_kl < float(self.param_noise_threshold):
+                self.param_noise_scale = np.float32(self.param_noise_scale * np.float32(1.01))
+            else:
+                self.param_noise_scale = np.float32(self.param_noise_scale / np.float32(1.01))
+        # :305: tf.cond(ph >= 0, assign ph, keep) -- a Python False arrives as 0.0 and IS assigned, like the reference
+        if float(update_param_noise_threshold) >= 0:
+            self.param_noise_threshold = np.float32(update_param_noise_threshold)
+        return a.cpu().numpy().astype(np.int64)
+
+    def act(self, ob, *args, **kwargs):
+        """act(ob, stochastic=True, update_eps=-1) -- build_graph.py:146-199; returns int64 actions [n] like tf.argmax.
+        On a model built with param_noise=True the signature is the one of build_act_with_param_noise (:202-315):
+        act(ob, reset=False, update_param_noise_threshold=False, update_param_noise_scale=False, stochastic=True, update_eps=-1)"""
+        if self.param_noise:
+            names = ('reset', 'update_param_noise_threshold', 'update_param_noise_scale', 'stochastic', 'update_eps')
+            kw = dict(reset=False, update_param_noise_threshold=False, update_param_noise_scale=False, stochastic=True, update_eps=-1)
+        else:
+            names, kw = ('stochastic', 'update_eps'), dict(stochastic=True, update_eps=-1)
+        if len(args) > len(names):
+            raise TypeError('act() takes at most %d arguments after ob' % len(names))
+        given = dict(zip(names, args))
+        for k, v in kwargs.items():
+            if k not in kw or k in given:
+                raise TypeError('act() got an unexpected or repeated argument %r' % k)
+            given[k] = v
+        kw.update(given)
+        if self.param_noise:
+            return self._act_param_noise(ob, **kw)
+        stochastic, update_eps = kw['stochastic'], kw['update_eps']
         obs = self._obs(ob)
         n = obs.shape[0]
         self._set_batch(n)
@@ -260,6 +353,14 @@ class QModel(object):
                 nm = t['name'].replace('deepq/q_func', scope, 1) + suffix + ':0'
                 out[nm] = host[t['offset']:t['offset'] + t['size']].reshape(t['shape']).copy()
         out['beta1_power:0'], out['beta2_power:0'] = np.float32(self.beta1_power), np.float32(self.beta2_power)
+        if self.param_noise:
+            out['deepq/param_noise_scale:0'] = np.float32(self.param_noise_scale)
+            out['deepq/param_noise_threshold:0'] = np.float32(self.param_noise_threshold)
+            for buf, scope in ((self.perturbed, 'deepq/perturbed_q_func'), (self.adaptive, 'deepq/adaptive_q_func')):
+                host = buf.detach().cpu().numpy()
+                for t in self.tensors:
+                    nm = t['name'].replace('deepq/q_func', scope, 1) + ':0'
+                    out[nm] = host[t['offset']:t['offset'] + t['size']].reshape(t['shape']).copy()
         return out
 
     def load_variables(self, d):
@@ -276,6 +377,18 @@ class QModel(object):
             buf.copy_(torch.from_numpy(host))
         if 'deepq/eps:0' in d:
             self.eps = float(d['deepq/eps:0'])
+        if self.param_noise:
+            for buf, scope in ((self.perturbed, 'deepq/perturbed_q_func'), (self.adaptive, 'deepq/adaptive_q_func')):
+                host = self.params.detach().cpu().numpy().copy()         # absent in the file: unperturbed
+                for t in self.tensors:
+                    nm = t['name'].replace('deepq/q_func', scope, 1) + ':0'
+                    if nm in d:
+                        host[t['offset']:t['offset'] + t['size']] = np.asarray(d[nm], np.float32).reshape(-1)
+                buf.copy_(torch.from_numpy(host))
+            if 'deepq/param_noise_scale:0' in d:
+                self.param_noise_scale = np.float32(d['deepq/param_noise_scale:0'])
+            if 'deepq/param_noise_threshold:0' in d:
+                self.param_noise_threshold = np.float32(d['deepq/param_noise_threshold:0'])
         if 'beta1_power:0' in d:
             self.beta1_power, self.beta2_power = np.float32(d['beta1_power:0']), np.float32(d['beta2_power:0'])
 

@@ -270,7 +270,7 @@ int mrl_dqn_td(const float* q_t, const float* q_tp1_target, const float* q_tp1_o
  * MRL_NET_CONV_ONLY (models.py:222-249: tf.contrib convolution2d, SAME padding, ReLU, xavier-uniform init).
  * Parameters: ONE flat f32 buffer per network copy (online / target) in TF variable-creation order; tensor i is
  * described by mrl_qnet_tensor_info (TF names "deepq/q_func/..."; init_kind 0 zeros, 1 orthogonal * init_scale,
- * 2 xavier uniform).  `update_target` (build_graph.py:423-428) is a device copy of that buffer by the caller. */
+ * 2 xavier uniform, 3 ones).  `update_target` (build_graph.py:423-428) is a device copy of that buffer by the caller. */
 typedef struct mrl_qnet_desc {
     int network;            /* MRL_NET_MLP | MRL_NET_NATURE_CNN | MRL_NET_CONV_ONLY */
     int ob_ndim;  int ob_shape[3];  int ob_dtype;
@@ -279,6 +279,7 @@ typedef struct mrl_qnet_desc {
     int nhidden;  int hiddens[4];                /* build_q_func(hiddens=[256]) */
     int dueling;                                 /* build_q_func(dueling=True) */
     int nact;
+    int layer_norm;                              /* build_q_func(layer_norm=True): LayerNorm before the ReLU of the hidden head layers */
 } mrl_qnet_desc;
 typedef struct mrl_qnet mrl_qnet;
 int  mrl_qnet_create(const mrl_qnet_desc* desc, mrl_qnet** out);
@@ -296,6 +297,10 @@ int mrl_qnet_values(const mrl_qnet* q, const float* params, const void* obs, int
 int mrl_qnet_act(const mrl_qnet* q, const float* params, const void* obs, int n, float eps, const float* uniforms,
                  const int32_t* rand_actions, int32_t* actions_out, float* q_out, void* workspace,
                  size_t workspace_bytes, int batch, void* stream);
+/* parameter-space noise (build_graph.py:202-315): mean over n rows of KL(softmax(q_a) || softmax(q_b)), q_* f32 [n][nact] --
+ * the action-space distance between the unperturbed and an adaptively perturbed network that steers the noise scale
+ * (:283-291).  Perturbed parameter copies are ordinary flat parameter buffers passed to mrl_qnet_values / mrl_qnet_act. */
+int mrl_qnet_policy_kl(const float* q_a, const float* q_b, int n, int nact, float* mean_kl_out, void* stream);
 /* train, gradient part (build_graph.py:380-413): td_out f32 [B] = q_t(s,a) - (r + gamma (1-done) q_tp1_best),
  * loss_out f32 [1] = mean(w * huber(td)), grads_out f32 [P] = d loss / d online params (un-clipped) */
 int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const float* target_params, const void* obs_t,

@@ -28,11 +28,12 @@ def _same_pad(n, k, s):
 
 class OracleQNet(object):
     def __init__(self, network, tensors, flat_params, nact, hiddens=(256,), dueling=True, convs=(), num_layers=2,
-                 activation='tanh', dtype=torch.float32, lr=5e-4, gamma=1.0, clip=10.0, double_q=True):
+                 activation='tanh', dtype=torch.float32, lr=5e-4, gamma=1.0, clip=10.0, double_q=True, layer_norm=False):
         self.network, self.nact, self.hiddens, self.dueling, self.convs = network, nact, tuple(hiddens), dueling, tuple(convs)
         self.num_layers, self.activation, self.dtype = num_layers, activation, dtype
         self.lr, self.gamma, self.clip, self.double_q = lr, gamma, clip, double_q
         self.tensors = tensors
+        self.layer_norm = layer_norm
         self.names = [t['name'] for t in tensors]
         flat = np.asarray(flat_params)
         self.p = {t['name']: torch.tensor(flat[t['offset']:t['offset'] + t['size']].reshape(t['shape']), dtype=dtype,
@@ -75,6 +76,13 @@ class OracleQNet(object):
                 nm = s + '/' + scope + ('/fully_connected_%d' % i if i else '/fully_connected')
                 o = o @ p[nm + '/weights'] + p[nm + '/biases']
                 if i < len(self.hiddens):
+                    if self.layer_norm:
+                        # deepq/models.py:27-29: layers.layer_norm(out, center=True, scale=True) -- moments over the features
+                        # (biased variance), variance_epsilon 1e-12 (tf.contrib.layers.layer_norm -> tf.nn.batch_normalization)
+                        ln = s + '/' + scope + ('/LayerNorm_%d' % i if i else '/LayerNorm')
+                        mu = o.mean(dim=1, keepdim=True)
+                        var = ((o - mu) ** 2).mean(dim=1, keepdim=True)
+                        o = (o - mu) * torch.rsqrt(var + 1e-12) * p[ln + '/gamma'] + p[ln + '/beta']
                     o = F.relu(o)
             return o
         a = head('action_value', self.nact)

@@ -127,6 +127,33 @@ def test_layout_mlp_layer_norm_variable_names(lib):
     lib.mrl_model_destroy(h)
 
 
+def test_layout_qnet_layer_norm_heads_variable_names(lib):
+    """build_q_func(layer_norm=True), deepq/models.py:24-41: LayerNorm variables between the hidden head layers, none
+    after the output layer; gamma initialised to ones (init_kind 3), beta to zeros"""
+    d = _lib.QNetDesc()
+    d.network, d.ob_ndim, d.ob_dtype, d.num_layers, d.num_hidden, d.activation = _lib.NET_MLP, 1, _lib.OB_F32, 1, 16, _lib.ACT_TANH
+    d.ob_shape[0] = 6
+    d.nhidden, d.dueling, d.nact, d.layer_norm = 2, 1, 3, 1
+    d.hiddens[0], d.hiddens[1] = 8, 4
+    h = ctypes.c_void_p()
+    assert lib.mrl_qnet_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    name = ctypes.create_string_buffer(160)
+    names, kinds = [], {}
+    for i in range(lib.mrl_qnet_num_tensors(h)):
+        nd, shp, off, kind, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_int(), ctypes.c_double()
+        assert lib.mrl_qnet_tensor_info(h, i, name, 160, ctypes.byref(nd), ctypes.byref(shp), ctypes.byref(off), ctypes.byref(kind),
+                                        ctypes.byref(sc)) == 0
+        names.append(name.value.decode())
+        kinds[names[-1]] = kind.value
+    av = 'deepq/q_func/action_value/'
+    assert names[2:12] == [av + 'fully_connected/weights', av + 'fully_connected/biases', av + 'LayerNorm/beta', av + 'LayerNorm/gamma',
+                           av + 'fully_connected_1/weights', av + 'fully_connected_1/biases', av + 'LayerNorm_1/beta',
+                           av + 'LayerNorm_1/gamma', av + 'fully_connected_2/weights', av + 'fully_connected_2/biases']
+    assert names[12].startswith('deepq/q_func/state_value/') and names[-1] == 'deepq/q_func/state_value/fully_connected_2/biases'
+    assert kinds[av + 'LayerNorm/gamma'] == 3 and kinds[av + 'LayerNorm/beta'] == 0
+    lib.mrl_qnet_destroy(h)
+
+
 def test_layout_rejects_unsupported(lib):
     rc, h = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 3), ob_dtype=_lib.OB_U8,
                     pd_kind=_lib.PD_CATEGORICAL, nact=6)
