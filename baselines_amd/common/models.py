@@ -56,20 +56,23 @@ def cnn(**conv_kwargs):
 
 @register('lstm')
 def lstm(nlstm=128, layer_norm=False):
-    """common/models.py:132-176: flatten -> LSTM cell over the steps of a rollout, state managed outside the policy"""
-    if layer_norm:
-        raise NotImplementedError('layer-normalised LSTM (lnlstm) is outside the supported hot path')
-    return NetworkDesc('lstm', nlstm=int(nlstm))
+    """common/models.py:132-176: flatten -> LSTM cell over the steps of a rollout, state managed outside the policy;
+    layer_norm=True: the layer-normalised cell (a2c/utils.py:110-140 lnlstm, variables under scope 'lnlstm')"""
+    return NetworkDesc('lstm', nlstm=int(nlstm), layer_norm=bool(layer_norm))
 
 
 @register('cnn_lstm')
 def cnn_lstm(nlstm=128, layer_norm=False, **conv_kwargs):
-    """common/models.py:179-206: NatureCNN features -> LSTM cell"""
-    if layer_norm:
-        raise NotImplementedError('layer-normalised LSTM (lnlstm) is outside the supported hot path')
+    """common/models.py:179-206: NatureCNN features -> LSTM cell (layer_norm=True: lnlstm)"""
     if conv_kwargs:
         raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(conv_kwargs)))
-    return NetworkDesc('cnn_lstm', nlstm=int(nlstm))
+    return NetworkDesc('cnn_lstm', nlstm=int(nlstm), layer_norm=bool(layer_norm))
+
+
+@register('cnn_lnlstm')
+def cnn_lnlstm(nlstm=128, **conv_kwargs):
+    """common/models.py:216-218"""
+    return cnn_lstm(nlstm, layer_norm=True, **conv_kwargs)
 
 
 def get_network_builder(name):

@@ -353,6 +353,288 @@ __global__ __launch_bounds__(1024) void lstm_bwd_generic_kernel(LstmBwdArgs a, i
     }
 }
 
+// ---- layer-normalised cell --- a2c/utils.py:104-140 `lnlstm` (lstm(layer_norm=True), cnn_lnlstm) ------------------------------
+//
+//     z = LN(x@wx; gx, bx) + LN(h@wh; gh, bh) + b;   c = f*c + i*u;   h = o * tanh(LN(c; gc, bc))
+//     LN(v; g, b) = (v - mean(v)) / sqrt(var(v) + 1e-5) * g + b   over the features of one row (biased variance)
+//
+// LN(x@wx) is row-parallel and is applied to the GEMM output outside (model.hip); inside the scan a step has two more row
+// statistics -- over the 4nh values of h@wh and over the nh values of the new c -- each taken by one wave per environment
+// from LDS (two-pass: mean, then mean of squared differences, like tf.nn.moments).  The scan stores the normalised values
+// and 1/sqrt(var + e) of both; the backward scan adds the two LN Jacobians to the chain and writes, next to the gate
+// gradients dz (which feed dgx/dbx, dgh/dbh, db and the x path outside), the gradient w.r.t. the raw h@wh (for dwh and
+// dh_prev) and w.r.t. LN(c) (for dgc/dbc).  Streamed-weight form for every width (the LN variants are not the headline).
+constexpr float LNLSTM_EPS = 1e-5f;
+struct LnLstmFwdArgs {
+    LstmFwdArgs base;       // base.zx already holds LN(x@wx)*gx + bx; base.bias = b
+    const float *gh, *bh;   // [4nh]
+    const float *gc, *bc;   // [nh]
+    float *xhh, *ish;       // [B][4nh] normalised h@wh, [B] 1/sqrt(var+e)      (nullptr on the act side)
+    float *xhc, *isc;       // [B][nh]  normalised c,    [B]
+};
+struct LnLstmBwdArgs {
+    LstmBwdArgs base;       // base.tc = tanh(LN(c)), base.dzg = dL/dz out
+    const float *gh, *gc;
+    const float *xhh, *ish, *xhc, *isc;
+    float* dzh;             // [B][4nh] gradient w.r.t. the raw h@wh
+    float* dcn;             // [B][nh]  gradient w.r.t. LN(c)*gc + bc
+};
+
+// one wave: sum of f(c) over c = lane, lane+64, ... < n, broadcast to every lane
+template <class F>
+__device__ __forceinline__ float lstm_wave_sum(unsigned n, F f) {
+    float s = 0.f;
+    for (unsigned c = threadIdx.x & 63u; c < n; c += 64u) s += f(c);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void lnlstm_fwd_kernel(LnLstmFwdArgs p, int nh) {
+    const LstmFwdArgs& a = p.base;
+    extern __shared__ __attribute__((aligned(16))) float lg_s[];
+    float* h_s = lg_s;                       // [E][nh]
+    float* c_s = h_s + E * nh;               // [E][nh]
+    float* g_s = c_s + E * nh;               // [E][4nh]: raw h@wh, then the gates
+    float* st_s = g_s + E * 4 * nh;          // [E][2]: mean, 1/sqrt(var + e)
+    const unsigned tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6;
+    const unsigned NH = (unsigned)nh, N4 = 4u * NH;
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    for (unsigned g0 = blockIdx.x * E; g0 < nenv; g0 += gridDim.x * E) {
+        for (unsigned q = tid; q < E * NH; q += nt) {
+            const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+            const bool ok = env < nenv && a.s0;
+            c_s[q] = ok ? a.s0[env * 2u * NH + k] : 0.f;
+            h_s[q] = ok ? a.s0[env * 2u * NH + NH + k] : 0.f;
+        }
+        __syncthreads();
+        for (unsigned t = 0; t < T; ++t) {
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                    const float cv = c_s[q] * keep, hv = h_s[q] * keep;
+                    c_s[q] = cv;
+                    h_s[q] = hv;
+                    if (a.cm) { a.cm[b * NH + k] = cv; a.hm[b * NH + k] = hv; }
+                }
+            }
+            __syncthreads();
+            for (unsigned j = tid; j < N4; j += nt) {
+                float acc[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = 0.f;
+                for (unsigned k = 0; k < NH; ++k) {
+                    const float w = a.wh[k * N4 + j];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] = fmaf(h_s[e * NH + k], w, acc[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) g_s[e * N4 + j] = acc[e];
+            }
+            __syncthreads();
+            if (wave < E) {
+                const float* row = g_s + wave * N4;
+                const float mean = lstm_wave_sum(N4, [&](unsigned c) { return row[c]; }) / (float)N4;
+                const float var = lstm_wave_sum(N4, [&](unsigned c) { const float d = row[c] - mean; return d * d; }) / (float)N4;
+                if ((tid & 63u) == 0) { st_s[2 * wave] = mean; st_s[2 * wave + 1] = 1.f / sqrtf(var + LNLSTM_EPS); }
+            }
+            __syncthreads();
+            for (unsigned j = tid; j < N4; j += nt) {
+                const float ghj = p.gh[j], bhj = p.bh[j], bj = a.bias[j];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool live = g0 + e < nenv;
+                    const unsigned b = min(g0 + (unsigned)e, nenv - 1u) * T + t;
+                    const float xh = (g_s[e * N4 + j] - st_s[2 * e]) * st_s[2 * e + 1];
+                    const float z = (a.zx[b * N4 + j] + (xh * ghj + bhj)) + bj;
+                    const float gv = j < 3 * NH ? lstm_sigmoid(z) : tanhf(z);
+                    g_s[e * N4 + j] = gv;
+                    if (live && a.gates) { a.gates[b * N4 + j] = gv; p.xhh[b * N4 + j] = xh; }
+                    if (live && p.ish && j == 0) p.ish[b] = st_s[2 * e + 1];
+                }
+            }
+            __syncthreads();
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH;
+                const float* g = g_s + e * N4;
+                c_s[q] = g[NH + k] * c_s[q] + g[k] * g[3 * NH + k];
+            }
+            __syncthreads();
+            if (wave < E) {
+                const float* row = c_s + wave * NH;
+                const float mean = lstm_wave_sum(NH, [&](unsigned c) { return row[c]; }) / (float)NH;
+                const float var = lstm_wave_sum(NH, [&](unsigned c) { const float d = row[c] - mean; return d * d; }) / (float)NH;
+                if ((tid & 63u) == 0) { st_s[2 * wave] = mean; st_s[2 * wave + 1] = 1.f / sqrtf(var + LNLSTM_EPS); }
+            }
+            __syncthreads();
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                const float xc = (c_s[q] - st_s[2 * e]) * st_s[2 * e + 1];
+                const float tcv = tanhf(xc * p.gc[k] + p.bc[k]);
+                const float h = g_s[e * N4 + 2 * NH + k] * tcv;
+                h_s[q] = h;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    if (a.tc) { a.tc[b * NH + k] = tcv; p.xhc[b * NH + k] = xc; if (k == 0) p.isc[b] = st_s[2 * e + 1]; }
+                    a.hout[b * NH + k] = h;
+                }
+            }
+            __syncthreads();
+        }
+        if (a.s_out)
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                if (env < nenv) {
+                    a.s_out[env * 2u * NH + k] = c_s[q];
+                    a.s_out[env * 2u * NH + NH + k] = h_s[q];
+                }
+            }
+        __syncthreads();
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void lnlstm_bwd_kernel(LnLstmBwdArgs p, int nh) {
+    const LstmBwdArgs& a = p.base;
+    extern __shared__ __attribute__((aligned(16))) float lg_s[];
+    float* dh_s = lg_s;                      // [E][nh]
+    float* dc_s = dh_s + E * nh;             // [E][nh]
+    float* dz_s = dc_s + E * nh;             // [E][4nh]: dL/dz, then dL/d(raw h@wh)
+    float* r_s = dz_s + E * 4 * nh;          // [E][nh]: dL/d(normalised c)
+    float* st_s = r_s + E * nh;              // [E][2]: the two row means of an LN Jacobian
+    const unsigned tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6;
+    const unsigned NH = (unsigned)nh, N4 = 4u * NH;
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    for (unsigned g0 = blockIdx.x * E; g0 < nenv; g0 += gridDim.x * E) {
+        for (unsigned q = tid; q < E * NH; q += nt) { dh_s[q] = 0.f; dc_s[q] = 0.f; }
+        __syncthreads();
+        for (int ti = (int)T - 1; ti >= 0; --ti) {
+            const unsigned t = (unsigned)ti;
+            // h = o * tanh(cn), cn = xhat_c * gc + bc:  dL/dcn, dL/dxhat_c
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, kk = q - e * NH, env = g0 + e;
+                float dx = 0.f;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    const float ov = a.gates[b * N4 + 2 * NH + kk], tcv = a.tc[b * NH + kk];
+                    const float dh = dh_s[q] + a.dhout[b * NH + kk];
+                    const float dcn = dh * ov * (1.f - tcv * tcv);
+                    p.dcn[b * NH + kk] = dcn;
+                    dx = dcn * p.gc[kk];
+                    dh_s[q] = dh;                                            // total dL/dh_t, used again below
+                }
+                r_s[q] = dx;
+            }
+            __syncthreads();
+            if (wave < E) {
+                const unsigned env = g0 + wave;
+                float m1 = 0.f, m2 = 0.f;
+                if (env < nenv) {
+                    const float* row = r_s + wave * NH;
+                    const float* xh = p.xhc + (env * T + t) * NH;
+                    m1 = lstm_wave_sum(NH, [&](unsigned c) { return row[c]; }) / (float)NH;
+                    m2 = lstm_wave_sum(NH, [&](unsigned c) { return row[c] * xh[c]; }) / (float)NH;
+                }
+                if ((tid & 63u) == 0) { st_s[2 * wave] = m1; st_s[2 * wave + 1] = m2; }
+            }
+            __syncthreads();
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, kk = q - e * NH, env = g0 + e;
+                float dzi = 0.f, dzf = 0.f, dzo = 0.f, dzu = 0.f, dcm = 0.f;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    const float* gr = a.gates + b * N4;
+                    const float iv = gr[kk], fv = gr[NH + kk], ov = gr[2 * NH + kk], uv = gr[3 * NH + kk];
+                    const float tcv = a.tc[b * NH + kk], cmv = a.cm[b * NH + kk];
+                    const float dh = dh_s[q];
+                    const float dov = dh * tcv;
+                    const float dc = dc_s[q] + p.isc[b] * ((r_s[q] - st_s[2 * e]) - p.xhc[b * NH + kk] * st_s[2 * e + 1]);
+                    dzi = (dc * uv) * iv * (1.f - iv);
+                    dzf = (dc * cmv) * fv * (1.f - fv);
+                    dzo = dov * ov * (1.f - ov);
+                    dzu = (dc * iv) * (1.f - uv * uv);
+                    const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                    dcm = (dc * fv) * keep;
+                    float* dst = a.dzg + b * N4;
+                    dst[kk] = dzi; dst[NH + kk] = dzf; dst[2 * NH + kk] = dzo; dst[3 * NH + kk] = dzu;
+                }
+                float* dz = dz_s + e * N4;
+                dz[kk] = dzi; dz[NH + kk] = dzf; dz[2 * NH + kk] = dzo; dz[3 * NH + kk] = dzu;
+                dc_s[q] = dcm;
+            }
+            __syncthreads();
+            // the h path: z contains LN(h@wh)*gh + bh -> Jacobian of that LN over the 4nh features
+            if (wave < E) {
+                const unsigned env = g0 + wave;
+                float m1 = 0.f, m2 = 0.f;
+                if (env < nenv) {
+                    const float* row = dz_s + wave * N4;
+                    const float* xh = p.xhh + (env * T + t) * N4;
+                    m1 = lstm_wave_sum(N4, [&](unsigned c) { return row[c] * p.gh[c]; }) / (float)N4;
+                    m2 = lstm_wave_sum(N4, [&](unsigned c) { return row[c] * p.gh[c] * xh[c]; }) / (float)N4;
+                }
+                if ((tid & 63u) == 0) { st_s[2 * wave] = m1; st_s[2 * wave + 1] = m2; }
+            }
+            __syncthreads();
+            for (unsigned j = tid; j < N4; j += nt) {
+                const float ghj = p.gh[j];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    float v = 0.f;
+                    if (g0 + e < nenv) {
+                        const unsigned b = (g0 + e) * T + t;
+                        v = p.ish[b] * ((dz_s[e * N4 + j] * ghj - st_s[2 * e]) - p.xhh[b * N4 + j] * st_s[2 * e + 1]);
+                        p.dzh[b * N4 + j] = v;
+                    }
+                    dz_s[e * N4 + j] = v;
+                }
+            }
+            __syncthreads();
+            for (unsigned q = tid; q < E * NH; q += nt) {
+                const unsigned e = q / NH, k = q - e * NH, env = g0 + e;
+                float pq[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float* wrow = a.wh + k * N4 + q4 * NH;
+                    const float* dz = dz_s + e * N4 + q4 * NH;
+                    float acc = 0.f;
+                    for (unsigned jj = 0; jj < NH; ++jj) acc = fmaf(dz[jj], wrow[jj], acc);
+                    pq[q4] = acc;
+                }
+                float keep = 0.f;
+                if (env < nenv) {
+                    const unsigned b = env * T + t;
+                    keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                }
+                dh_s[q] = ((pq[0] + pq[1]) + (pq[2] + pq[3])) * keep;
+            }
+            __syncthreads();
+        }
+    }
+}
+inline bool lnlstm_nh_ok(int nh) { return nh >= 1 && nh <= 512; }
+inline hipError_t launch_lnlstm_fwd(const LnLstmFwdArgs& p, int nh, int num_cus, hipStream_t st) {
+    constexpr int E = 4;
+    if (!lnlstm_nh_ok(nh)) return hipErrorInvalidValue;
+    const int groups = (p.base.nenv + E - 1) / E;
+    const int blocks = std::max(1, std::min(groups, 2 * num_cus));
+    const int threads = std::max(64 * E, std::min(1024, (4 * nh + 63) / 64 * 64));       // at least one wave per environment
+    hipLaunchKernelGGL((lnlstm_fwd_kernel<E>), dim3(blocks), dim3(threads), ((size_t)E * nh * 6 + 2 * E) * sizeof(float), st, p, nh);
+    return hipGetLastError();
+}
+inline hipError_t launch_lnlstm_bwd(const LnLstmBwdArgs& p, int nh, int num_cus, hipStream_t st) {
+    constexpr int E = 4;
+    if (!lnlstm_nh_ok(nh)) return hipErrorInvalidValue;
+    const int groups = (p.base.nenv + E - 1) / E;
+    const int blocks = std::max(1, std::min(groups, 2 * num_cus));
+    const int threads = std::max(64 * E, std::min(1024, (4 * nh + 63) / 64 * 64));
+    hipLaunchKernelGGL((lnlstm_bwd_kernel<E>), dim3(blocks), dim3(threads), ((size_t)E * nh * 7 + 2 * E) * sizeof(float), st, p, nh);
+    return hipGetLastError();
+}
+
 // widths the register-resident kernels are compiled for; any other positive width takes the streamed form
 inline bool lstm_nh_fast(int nh) { return nh == 32 || nh == 64 || nh == 96 || nh == 128; }
 inline bool lstm_nh_ok(int nh) { return nh >= 1 && nh <= 1024; }

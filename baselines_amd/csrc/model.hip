@@ -68,6 +68,8 @@ struct Net {
     bool lstm = false;                     // recurrent cell on top of the features (a2c/utils.py:81-102)
     int lstm_nin = 0, nh = 0;
     long wx_off = -1, wh_off = -1, lb_off = -1;
+    bool lnl = false;                      // layer-normalised cell (a2c/utils.py:110-140 lnlstm): gains / biases of the three LNs
+    long gx_off = -1, gh_off = -1, gc_off = -1;       // each gain is followed by its bias (gx|bx, gh|bh, gc|bc)
 };
 
 struct TensorInfo {
@@ -129,6 +131,24 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
             nin = (int)m->ob_elems;
         }
         net.lstm = true; net.lstm_nin = nin; net.nh = d.nlstm;
+        if (d.layer_norm) {
+            // models.py:173-174 / 200-201: utils.lnlstm(scope='lnlstm'); variables in creation order (a2c/utils.py:113-124):
+            // wx, gx (ones), bx, wh, gh (ones), bh, b, gc (ones), bc
+            if (!lnlstm_nh_ok(d.nlstm)) return MRL_EUNSUP;
+            const std::string sc = prefix + "/lnlstm";
+            net.lnl = true;
+            net.wx_off = add_tensor(m, sc + "/wx", {nin, 4 * d.nlstm}, 1.0);
+            net.gx_off = add_tensor(m, sc + "/gx", {4 * d.nlstm}, -2.0);
+            add_tensor(m, sc + "/bx", {4 * d.nlstm}, -1.0);
+            net.wh_off = add_tensor(m, sc + "/wh", {d.nlstm, 4 * d.nlstm}, 1.0);
+            net.gh_off = add_tensor(m, sc + "/gh", {4 * d.nlstm}, -2.0);
+            add_tensor(m, sc + "/bh", {4 * d.nlstm}, -1.0);
+            net.lb_off = add_tensor(m, sc + "/b", {4 * d.nlstm}, -1.0);
+            net.gc_off = add_tensor(m, sc + "/gc", {d.nlstm}, -2.0);
+            add_tensor(m, sc + "/bc", {d.nlstm}, -1.0);
+            net.nlat = d.nlstm; net.lat_act = ACT_NONE;
+            return 0;
+        }
         net.wx_off = add_tensor(m, prefix + "/lstm/wx", {nin, 4 * d.nlstm}, 1.0);
         net.wh_off = add_tensor(m, prefix + "/lstm/wh", {d.nlstm, 4 * d.nlstm}, 1.0);
         net.lb_off = add_tensor(m, prefix + "/lstm/b", {4 * d.nlstm}, -1.0);
@@ -255,6 +275,10 @@ struct NetWs {
     // recurrent cell (lstm.hip.h): x@wx, stored gates / masked state / tanh(c), cell output = policy latent, gradients
     float *zx = nullptr, *gates = nullptr, *cm = nullptr, *hm = nullptr, *tc = nullptr, *hout = nullptr, *dhout = nullptr,
           *dzg = nullptr;
+    // layer-normalised cell: normalised values and 1/sqrt(var + e) of LN(x@wx), LN(h@wh), LN(c); gradients w.r.t. the raw
+    // h@wh and w.r.t. LN(c)
+    float *xhx = nullptr, *isx = nullptr, *xhh = nullptr, *ish = nullptr, *xhc = nullptr, *isc = nullptr, *dzh = nullptr,
+          *dcn = nullptr;
     // ReLU bit masks of the conv outputs (1 bit per element, written by the forward epilogues that can, consumed by the
     // position-major data-gradient engine instead of the fp32 activations): mbits[l] may be nullptr; mvalid[l] is set
     // by the forward pass of THIS call when the engine that ran layer l wrote them
@@ -457,6 +481,12 @@ static void carve(const mrl_model* m, int chunk, char* base, Ws& ws) {
         nw.dhout = (float*)take(g1);
         part_floats = std::max(part_floats, (size_t)max_split_floats(n.lstm_nin, 4 * n.nh, chunk));
         part_floats = std::max(part_floats, (size_t)max_split_floats(n.nh, 4 * n.nh, chunk));
+        if (n.lnl) {
+            nw.xhx = (float*)take(g4); nw.xhh = (float*)take(g4); nw.dzh = (float*)take(g4);
+            nw.xhc = (float*)take(g1); nw.dcn = (float*)take(g1);
+            nw.isx = (float*)take((size_t)chunk * 4); nw.ish = (float*)take((size_t)chunk * 4); nw.isc = (float*)take((size_t)chunk * 4);
+            part_floats = std::max(part_floats, (size_t)LN_MAXBLK * 8 * n.nh);
+        }
     }
     {   // scratch for the split weight planes of the largest hidden layer (first layers read observations: own engines)
         size_t pb = 0;
@@ -1115,7 +1145,8 @@ __global__ __launch_bounds__(256) void heads_act_kernel(HeadArgs a) {
 constexpr float LN_EPS = 1e-12f;
 __global__ __launch_bounds__(256) void ln_fwd_kernel(float* __restrict__ h /* in: z, out: act(y) */, float* __restrict__ xhat,
                                                      float* __restrict__ istd, const float* __restrict__ beta,
-                                                     const float* __restrict__ gamma, int rows, int N, int act) {
+                                                     const float* __restrict__ gamma, int rows, int N, int act,
+                                                     float eps = LN_EPS) {
     const int lane = threadIdx.x & 63;
     for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4L) {
         float* z = h + r * N;
@@ -1128,7 +1159,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(float* __restrict__ h /* in
         for (int c = lane; c < N; c += 64) { const float d = z[c] - mean; q += d * d; }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-        const float inv = 1.f / sqrtf(q / (float)N + LN_EPS);
+        const float inv = 1.f / sqrtf(q / (float)N + eps);
         if (lane == 0 && istd) istd[r] = inv;
         for (int c = lane; c < N; c += 64) {
             const float xh = (z[c] - mean) * inv;
@@ -1139,30 +1170,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(float* __restrict__ h /* in
 }
 // dy (gradient w.r.t. the normalised, scaled and shifted value) -> dz (w.r.t. the affine map's output), in place, and this
 // block's partial sums of dbeta[c] = sum_r dy[r][c], dgamma[c] = sum_r dy[r][c] * xhat[r][c] (rows in fixed order)
+// MODE 0: as described (shift | gain order of tf.contrib's beta, gamma); MODE 1: the partial slab is (dgain | dshift) -- the
+// variable order of lnlstm's gx|bx (a2c/utils.py:114-115); MODE 2: (dgain | dshift) sums only, dz is left alone
+template <int MODE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dz, const float* __restrict__ xhat,
                                                      const float* __restrict__ istd, const float* __restrict__ gamma, int rows,
                                                      int N, float* __restrict__ part /* [gridDim.x][2N] */) {
     extern __shared__ float ln_s[];                       // [4 waves][2N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* mine = ln_s + (long)wave * 2 * N;
+    const int o_shift = MODE == 0 ? 0 : N, o_gain = MODE == 0 ? N : 0;
     for (int c = lane; c < 2 * N; c += 64) mine[c] = 0.f;
     for (long r = blockIdx.x * 4L + wave; r < rows; r += (long)gridDim.x * 4L) {
         float* g = dz + r * N;
         const float* xh = xhat + r * N;
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = lane; c < N; c += 64) {
-            const float gy = g[c] * gamma[c];
-            s1 += gy;
-            s2 += gy * xh[c];
-        }
+        float m1 = 0.f, m2 = 0.f, inv = 0.f;
+        if (MODE != 2) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = lane; c < N; c += 64) {
+                const float gy = g[c] * gamma[c];
+                s1 += gy;
+                s2 += gy * xh[c];
+            }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-        const float m1 = s1 / (float)N, m2 = s2 / (float)N, inv = istd[r];
+            for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+            m1 = s1 / (float)N; m2 = s2 / (float)N; inv = istd[r];
+        }
         for (int c = lane; c < N; c += 64) {
             const float dy = g[c], x = xh[c];
-            mine[c] += dy;
-            mine[N + c] += dy * x;
-            g[c] = inv * ((dy * gamma[c] - m1) - x * m2);
+            mine[o_shift + c] += dy;
+            mine[o_gain + c] += dy * x;
+            if (MODE != 2) g[c] = inv * ((dy * gamma[c] - m1) - x * m2);
         }
     }
     __syncthreads();
@@ -1548,7 +1586,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             if (blocks < 1 || (size_t)i >= nw.xhat.size() || !nw.xhat[i]) return MRL_ENOSPC;
             {
                 ProfScope ps("layer_norm.bwd", 0.0, 16.0 * B * l.N, st);
-                hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)8 * l.N * sizeof(float), st, nw.dz[i], nw.xhat[i],
+                hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(blocks), dim3(256), (size_t)8 * l.N * sizeof(float), st, nw.dz[i], nw.xhat[i],
                                    nw.istd[i], params + l.gamma_off, B, l.N, ws.part);
                 MRL_LAUNCH_CHECK();
             }
@@ -1868,6 +1906,22 @@ static int lstm_forward(const Net& net, const In& in, const float* params, NetWs
     a.nenv = nseq; a.T = T;
     a.gates = train ? nw.gates : nullptr; a.cm = train ? nw.cm : nullptr; a.hm = train ? nw.hm : nullptr;
     a.tc = train ? nw.tc : nullptr; a.hout = nw.hout; a.s_out = s_out;
+    if (net.lnl) {
+        {   // zx <- LN(x@wx) * gx + bx, row-parallel (a2c/utils.py:130, first term)
+            ProfScope ps("lnlstm.ln_x", 0.0, 12.0 * B * N4, st);
+            const int blocks = (int)std::min<long>(((long)B + 3) / 4, 2048);
+            hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, nw.zx, train ? nw.xhx : nullptr, train ? nw.isx : nullptr,
+                               params + net.gx_off + N4, params + net.gx_off, B, N4, ACT_NONE, LNLSTM_EPS);
+            MRL_LAUNCH_CHECK();
+        }
+        LnLstmFwdArgs p;
+        p.base = a;
+        p.gh = params + net.gh_off; p.bh = p.gh + N4; p.gc = params + net.gc_off; p.bc = p.gc + nh;
+        p.xhh = train ? nw.xhh : nullptr; p.ish = train ? nw.ish : nullptr;
+        p.xhc = train ? nw.xhc : nullptr; p.isc = train ? nw.isc : nullptr;
+        ProfScope ps("lnlstm.scan_fwd", 2.0 * B * (double)nh * N4, 0.0, st);
+        return (int)launch_lnlstm_fwd(p, nh, num_cus(), st);
+    }
     ProfScope ps("lstm.scan_fwd", 2.0 * B * (double)nh * N4, 0.0, st);
     return (int)launch_lstm_fwd(a, nh, num_cus(), st);
 }
@@ -1880,9 +1934,43 @@ static int lstm_backward(const Net& net, const In& in, const float* params, NetW
         LstmBwdArgs a;
         a.dhout = nw.dhout; a.wh = params + net.wh_off; a.gates = nw.gates; a.cm = nw.cm; a.tc = nw.tc; a.mask = mask;
         a.srow = msrow; a.nenv = nseq; a.T = T; a.dzg = nw.dzg;
-        ProfScope ps("lstm.scan_bwd", 2.0 * B * (double)nh * N4, 0.0, st);
-        hipError_t e = launch_lstm_bwd(a, nh, num_cus(), st);
-        if (e != hipSuccess) return (int)e;
+        if (net.lnl) {
+            LnLstmBwdArgs p;
+            p.base = a;
+            p.gh = params + net.gh_off; p.gc = params + net.gc_off;
+            p.xhh = nw.xhh; p.ish = nw.ish; p.xhc = nw.xhc; p.isc = nw.isc; p.dzh = nw.dzh; p.dcn = nw.dcn;
+            {
+                ProfScope ps("lnlstm.scan_bwd", 2.0 * B * (double)nh * N4, 0.0, st);
+                hipError_t e = launch_lnlstm_bwd(p, nh, num_cus(), st);
+                if (e != hipSuccess) return (int)e;
+            }
+            // gains and shifts of the three LNs + b, as column sums over all B rows (fixed row order per block, slabs reduced
+            // in fixed order); the x path's LN Jacobian turns dzg into the gradient w.r.t. the raw x@wx in place
+            auto cols = [&](int mode, float* dy, const float* xhat, const float* istd, const float* gain, int N, long out_off,
+                            long also_shift_to) -> int {
+                const int blocks = (int)std::min<long>(std::min<long>(((long)B + 3) / 4, LN_MAXBLK), (long)(ws.part_floats / (2 * N)));
+                if (blocks < 1) return MRL_ENOSPC;
+                ProfScope ps("lnlstm.ln_bwd", 0.0, 16.0 * B * N, st);
+                if (mode == 1)
+                    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(blocks), dim3(256), (size_t)8 * N * sizeof(float), st, dy, xhat, istd, gain,
+                                       B, N, ws.part);
+                else
+                    hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), dim3(256), (size_t)8 * N * sizeof(float), st, dy, xhat, istd, gain,
+                                       B, N, ws.part);
+                MRL_LAUNCH_CHECK();
+                int rc = reduce_slabs(ws.part, 2L * N, blocks, grads + out_off, 2L * N, 0, st, &ctx);
+                if (!rc && also_shift_to >= 0) rc = reduce_slabs(ws.part + N, 2L * N, blocks, grads + also_shift_to, N, 0, st, &ctx);
+                return rc;
+            };
+            int rc;
+            if ((rc = cols(2, nw.dcn, nw.xhc, nullptr, nullptr, nh, net.gc_off, -1))) return rc;
+            if ((rc = cols(2, nw.dzg, nw.xhh, nullptr, nullptr, N4, net.gh_off, net.lb_off))) return rc;       // db = dbh = sum dz
+            if ((rc = cols(1, nw.dzg, nw.xhx, nw.isx, params + net.gx_off, N4, net.gx_off, -1))) return rc;
+        } else {
+            ProfScope ps("lstm.scan_bwd", 2.0 * B * (double)nh * N4, 0.0, st);
+            hipError_t e = launch_lstm_bwd(a, nh, num_cus(), st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     RowMC bfm{nw.dzg, N4, N4, B, is_vec(nw.dzg, N4), nullptr};
     // dwx[k][n] = sum_b x[b][k] dz[b][n],  db[n] = sum_b dz[b][n] (column sums ride on the B operand)
@@ -1904,7 +1992,8 @@ static int lstm_backward(const Net& net, const In& in, const float* params, NetW
         }
         if (rc) return rc;
         if ((rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + net.wx_off, (long)K * N4, 0, st, &ctx))) return rc;
-        if ((rc = reduce_slabs(ws.part + (long)K * N4, slab, sp.nsplit, grads + net.lb_off, N4, 0, st, &ctx))) return rc;
+        // (layer-normalised cell: nw.dzg is the x path's raw gradient here, and b already has its own column sums)
+        if (!net.lnl && (rc = reduce_slabs(ws.part + (long)K * N4, slab, sp.nsplit, grads + net.lb_off, N4, 0, st, &ctx))) return rc;
     }
     // dwh[k][n] = sum_b hm[b][k] dz[b][n]   (hm: the masked previous h the cell actually multiplied)
     {
@@ -1915,7 +2004,9 @@ static int lstm_backward(const Net& net, const In& in, const float* params, NetW
         if ((size_t)sp.nsplit * slab > ws.part_floats) return MRL_ENOSPC;
         EpiPartial ep{ws.part, slab, N4, (long)nh * N4};
         RowMC af{nw.hm, nh, nh, B, is_vec(nw.hm, nh), nullptr};
-        int rc = gemm_dispatch("lstm_h", "wgrad", var, af, bfm, ep, nh, N4, B, sp.nsplit, sp.ksplit, st);
+        const float* dzh = net.lnl ? nw.dzh : nw.dzg;                    // gradient w.r.t. the raw h@wh
+        RowMC bfh{dzh, N4, N4, B, is_vec(dzh, N4), nullptr};
+        int rc = gemm_dispatch("lstm_h", "wgrad", var, af, bfh, ep, nh, N4, B, sp.nsplit, sp.ksplit, st);
         if (rc) return rc;
         if ((rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + net.wh_off, (long)nh * N4, 0, st, &ctx))) return rc;
     }

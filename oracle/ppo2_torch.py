@@ -66,6 +66,13 @@ def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
                 nin = 512
             else:
                 nin = int(np.prod(ob_shape))
+            if layer_norm:
+                # a2c/utils.py:110-124 lnlstm(scope='lnlstm'): wx, gx (ones), bx, wh, gh (ones), bh, b, gc (ones), bc
+                sc = prefix + '/lnlstm'
+                specs.extend([(sc + '/wx', (nin, 4 * nlstm), 1.0), (sc + '/gx', (4 * nlstm,), 'ones'), (sc + '/bx', (4 * nlstm,), None),
+                              (sc + '/wh', (nlstm, 4 * nlstm), 1.0), (sc + '/gh', (4 * nlstm,), 'ones'), (sc + '/bh', (4 * nlstm,), None),
+                              (sc + '/b', (4 * nlstm,), None), (sc + '/gc', (nlstm,), 'ones'), (sc + '/bc', (nlstm,), None)])
+                return nlstm
             specs.append((prefix + '/lstm/wx', (nin, 4 * nlstm), 1.0))
             specs.append((prefix + '/lstm/wh', (nlstm, 4 * nlstm), 1.0))
             specs.append((prefix + '/lstm/b', (4 * nlstm,), None))
@@ -165,17 +172,29 @@ class OracleModel(object):
         ms = torch.as_tensor(np.asarray(M, dtype=np.float64)).to(self.dtype).reshape(nenv, nsteps)
         S = torch.as_tensor(np.asarray(S)).to(self.dtype)
         c, h = S[:, :nh], S[:, nh:]
-        wx, wh, b = p[prefix + '/lstm/wx'], p[prefix + '/lstm/wh'], p[prefix + '/lstm/b']
+        ln = self.layer_norm
+        sc = prefix + ('/lnlstm' if ln else '/lstm')
+        wx, wh, b = p[sc + '/wx'], p[sc + '/wh'], p[sc + '/b']
+
+        def _ln(v, g, bb, e=1e-5):
+            # a2c/utils.py:104-108: moments over axis 1 (biased variance), (v - u) / sqrt(s + e) * g + b
+            u = v.mean(dim=1, keepdim=True)
+            sv = ((v - u) ** 2).mean(dim=1, keepdim=True)
+            return (v - u) / torch.sqrt(sv + e) * g + bb
+
         out = []
         for t in range(nsteps):
             m = ms[:, t:t + 1]
             c = c * (1 - m)
             h = h * (1 - m)
-            z = xs[:, t] @ wx + h @ wh + b
+            if ln:                                                      # a2c/utils.py:130
+                z = _ln(xs[:, t] @ wx, p[sc + '/gx'], p[sc + '/bx']) + _ln(h @ wh, p[sc + '/gh'], p[sc + '/bh']) + b
+            else:
+                z = xs[:, t] @ wx + h @ wh + b
             i, f, o, u = torch.sigmoid(z[:, :nh]), torch.sigmoid(z[:, nh:2 * nh]), torch.sigmoid(z[:, 2 * nh:3 * nh]), \
                 torch.tanh(z[:, 3 * nh:])
             c = f * c + i * u
-            h = o * torch.tanh(c)
+            h = o * torch.tanh(_ln(c, p[sc + '/gc'], p[sc + '/bc']) if ln else c)      # a2c/utils.py:137
             out.append(h)
         return torch.stack(out, dim=1).reshape(nenv * nsteps, nh), torch.cat([c, h], dim=1)
 

@@ -127,6 +127,23 @@ def test_layout_mlp_layer_norm_variable_names(lib):
     lib.mrl_model_destroy(h)
 
 
+def test_layout_lnlstm_variable_names_match_the_oracle_inventory(lib):
+    """lstm(layer_norm=True) / cnn_lnlstm (common/models.py:173-174, 216-218): a2c/utils.py:113-124 variables under 'lnlstm'"""
+    from oracle.ppo2_torch import build_param_specs
+    d = _lib.ModelDesc()
+    d.network, d.ob_ndim, d.ob_dtype, d.nlstm, d.layer_norm = _lib.NET_LSTM, 1, _lib.OB_F32, 48, 1
+    d.ob_shape[0] = 12
+    d.pd_kind, d.nact = _lib.PD_CATEGORICAL, 4
+    h = ctypes.c_void_p()
+    assert lib.mrl_model_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    got = [(x[0], tuple(x[1])) for x in _tensors(lib, h)]
+    specs, _ = build_param_specs('lstm', (12,), 'categorical', 4, nlstm=48, layer_norm=True)
+    assert got == [(n, tuple(s)) for n, s, _ in specs]
+    assert [n.rsplit('/', 1)[1] for n, _ in got[:9]] == ['wx', 'gx', 'bx', 'wh', 'gh', 'bh', 'b', 'gc', 'bc']
+    assert lib.mrl_model_state_size(h) == 96
+    lib.mrl_model_destroy(h)
+
+
 def test_layout_qnet_layer_norm_heads_variable_names(lib):
     """build_q_func(layer_norm=True), deepq/models.py:24-41: LayerNorm variables between the hidden head layers, none
     after the output layer; gamma initialised to ones (init_kind 3), beta to zeros"""

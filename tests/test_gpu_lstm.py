@@ -26,6 +26,11 @@ CASES = {
     'lstm_nh48_streamed': dict(network='lstm', ob_shape=(12,), ob_dtype=np.float32, nlstm=48, nseq=6, T=5),
     'lstm_nh256_streamed': dict(network='lstm', ob_shape=(24,), ob_dtype=np.float32, nlstm=256, nseq=5, T=6),
     'cnn_lstm': dict(network='cnn_lstm', ob_shape=(84, 84, 4), ob_dtype=np.uint8, nlstm=128, nseq=3, T=4),
+    # layer-normalised cell (a2c/utils.py:104-140 lnlstm; lstm(layer_norm=True) / cnn_lnlstm)
+    'lnlstm_nh32': dict(network='lstm', ob_shape=(12,), ob_dtype=np.float32, nlstm=32, nseq=6, T=5, layer_norm=True),
+    'lnlstm_nh128': dict(network='lstm', ob_shape=(40,), ob_dtype=np.float32, nlstm=128, nseq=9, T=12, layer_norm=True),
+    'lnlstm_nh48': dict(network='lstm', ob_shape=(20,), ob_dtype=np.float32, nlstm=48, nseq=5, T=7, layer_norm=True),
+    'cnn_lnlstm': dict(network='cnn_lstm', ob_shape=(84, 84, 4), ob_dtype=np.uint8, nlstm=64, nseq=3, T=4, layer_norm=True),
 }
 
 
@@ -44,7 +49,7 @@ def test_recurrent_act_and_bptt_gradient_vs_oracle(name):
             om.p[k] += torch.tensor(0.05 * rng.randn(*om.p[k].shape), dtype=torch.float32)
     om64 = OracleModel(dtype=torch.float64, params=om.params_numpy(), **kw)
     dm = ops.DeviceModel(network=c['network'], ob_shape=c['ob_shape'], ob_dtype=c['ob_dtype'], pd_kind='categorical', nact=4,
-                         nlstm=nh, chunk=B)
+                         nlstm=nh, layer_norm=c.get('layer_norm', False), chunk=B)
     assert [t['name'] for t in dm.tensors] == om.names and dm.state_size == 2 * nh
     params = dev(om.flat_params().astype(np.float32))
     if c['ob_dtype'] == np.uint8:
@@ -112,7 +117,8 @@ def test_recurrent_act_and_bptt_gradient_vs_oracle(name):
     np.testing.assert_array_equal(grads2.cpu().numpy(), grads.cpu().numpy())
 
 
-@pytest.mark.parametrize('kind,net,N,T,nmb,nep', [('cartpole', 'lstm', 8, 32, 4, 2), ('atari', 'cnn_lstm', 4, 6, 2, 2)])
+@pytest.mark.parametrize('kind,net,N,T,nmb,nep', [('cartpole', 'lstm', 8, 32, 4, 2), ('atari', 'cnn_lstm', 4, 6, 2, 2),
+                                                  ('cartpole', 'lnlstm', 8, 16, 2, 2), ('atari', 'cnn_lnlstm', 4, 6, 2, 1)])
 def test_learn_recurrent_two_updates_match_oracle(kind, net, N, T, nmb, nep):
     """ppo2.learn with a recurrent policy on the device env: env-wise minibatches from the global NumPy stream,
     states = LSTM state when the rollout started, masks = done flags; every recorded minibatch step is replayed by the
@@ -123,6 +129,12 @@ def test_learn_recurrent_two_updates_match_oracle(kind, net, N, T, nmb, nep):
     from baselines_amd.ppo2 import Model
     from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
     rec = {}
+    net_kw, onet = {}, net
+    if net == 'lnlstm':                       # common/models.py:132: lstm(nlstm, layer_norm=True)
+        net, onet, net_kw = 'lstm', 'lstm', dict(layer_norm=True)
+    elif net == 'cnn_lnlstm':                 # the registered name (models.py:216-218)
+        onet = 'cnn_lstm'
+    ln = net_kw.get('layer_norm', False) or net == 'cnn_lnlstm'
 
     class RecModel(Model):          # the reference's model_fn plug point (ppo2.py:103-109)
         def train_indexed(self, lr, cliprange, rollout, idx_dev, stats_out=None, states=None):
@@ -140,14 +152,14 @@ def test_learn_recurrent_two_updates_match_oracle(kind, net, N, T, nmb, nep):
     updates = []
     model = ppo2.learn(network=net, env=env, total_timesteps=2 * N * T, seed=0, nsteps=T, nminibatches=nmb, noptepochs=nep,
                        ent_coef=0.01, lr=lambda f: 3e-4 * f, cliprange=0.2, log_interval=1, model_fn=RecModel,
-                       update_fn=updates.append, nlstm=32 if net == 'lstm' else 128)
+                       update_fn=updates.append, nlstm=32 if net == 'lstm' else 128, **net_kw)
     assert updates == [1, 2] and model.recurrent and model.initial_state.shape == (N, 2 * model.dm.state_size // 2)
     calls = rec['calls']
     assert len(calls) == 2 * nmb * nep
     np.random.seed(0)
-    om = OracleModel(network=net, ob_shape=env.observation_space.shape, ob_dtype=env.observation_space.dtype,
+    om = OracleModel(network=onet, ob_shape=env.observation_space.shape, ob_dtype=env.observation_space.dtype,
                      pd_kind=model.pd_kind, nact=model.nact, value_network=None, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5,
-                     nlstm=32 if net == 'lstm' else 128)
+                     nlstm=32 if net == 'lstm' else 128, layer_norm=ln)
     np.testing.assert_array_equal(calls[0]['params_before'], om.flat_params())       # same seeded init stream
     envsper = N // nmb
     fields = None
