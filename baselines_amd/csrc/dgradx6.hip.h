@@ -14,7 +14,7 @@
 //      position, so the validity of a tap is uniform over the tile and out-of-map taps are skipped instead of being
 //      multiplied by zeros: only useful MACs are executed (the LDS-resident fp32 engine spends 19 % (conv2) / 40 %
 //      (conv3) of its matrix time on border zeros).
-// Arithmetic, staging and tile shape are those of gemmx6.hip.h: both operands split exactly into 3 bf16 planes, 8 (or 6)
+// Arithmetic, staging and tile shape are those of gemmx6.hip.h: both operands split exactly into 3 bf16 planes, 6 (or 8)
 // partial products per multiply accumulated in fp32 by v_mfma_f32_32x32x16_bf16, A split while it is staged into LDS,
 // 4 waves x (64 x 64) per workgroup, two workgroups per CU.  Tiles of one image group (all positions) take consecutive
 // slots of ONE XCD so that the TAPS^2-fold re-reads of dz pixels by neighbouring positions hit that XCD's L2.
@@ -53,14 +53,12 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
         const int a = tap / G::TAPS, b2 = tap - a * G::TAPS;
         const int ky = py + S * a, kx = px + S * b2;
         const float v = (ky < RF && kx < RF) ? w[((long)(ky * RF + kx) * C + c) * NF + n] : 0.f;
-        const uint32_t u = __float_as_uint(v);
-        const float r1 = v - __uint_as_float(u & 0xffff0000u);
-        const uint32_t u1 = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        uint16_t q0, q1, q2;
+        split1_bf16x3(v, q0, q1, q2);
         const int eo = kperm ? col * G::K + tap * NF + (int)kperm32(n) : e;      // k in the order of a plane tensor (planes.hip.h)
-        out[0 * total + eo] = (uint16_t)(u >> 16);
-        out[1 * total + eo] = (uint16_t)(u1 >> 16);
-        out[2 * total + eo] = (uint16_t)(__float_as_uint(r2) >> 16);
+        out[0 * total + eo] = q0;
+        out[1 * total + eo] = q1;
+        out[2 * total + eo] = q2;
     }
 }
 
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {       // small terms first
-                    if (X8) {
+                    if (X8 && kCross21) {
                         acc[a][b] = mma(fa[a][2], fb[b][1], acc[a][b]);
                         acc[a][b] = mma(fa[a][1], fb[b][2], acc[a][b]);
                     }
@@ -390,8 +388,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
     if constexpr (EXP) {
         if (pa) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, false>);
     }
-    if (x8) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);
-    return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, false>);
+    return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true>);
 }
 
 }  // namespace mrl

@@ -2,13 +2,13 @@
 // Used for the fully connected layer of NatureCNN (common/models.py:24-26 `fc(h, 'fc1', nh=512)` via a2c/utils.py:58-63),
 // forward and data-gradient:   C[M][N] = A[M][K] * B[N][K]^T   with A fp32 row-major (K contiguous).
 //
-// Both operands are split EXACTLY into three bf16 planes, x = x0 + x1 + x2 (8 + 8 + 8 significant bits, truncation
-// split, every residual exact), and the six products down to 2^-16 relative are accumulated in fp32:
-//   x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0);   dropped: x1w2, x2w1, x2w2 < 2^-21 of the product worst case,
-// 4e-8 on average (twice the rounding of one fp32 multiply; tests/test_split_arithmetic.py).  6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace
-// 8 v_mfma_f32_32x32x2_f32 (64 cycles): 2.7x less matrix time.  Not the bitwise fmaf chain of the fp32 MFMA engines
-// (gemm.hip.h stays the reference path, MRL_F32_BF16X6=0 selects it; =2 keeps x1w2 and x2w1 too: 8 products, error
-// < 2^-29 per product, +15 % time); parity tests hold unchanged.
+// Both operands are split EXACTLY into three bf16 planes, x = x0 + x1 + x2 (round-to-nearest at each level, every
+// residual exact: split2_bf16x3, wres.hip.h), and the six products down to 2^-17 relative are accumulated in fp32:
+//   x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0);   dropped: x1w2 + x2w1 + x2w2 <= 2^-24 of the product -- the rounding of
+// one IEEE fp32 multiply -- and 3.5e-9 of it on average, a sixth of that rounding's mean (tests/test_split_arithmetic.py).
+// 6 v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace 8 v_mfma_f32_32x32x2_f32 (64 cycles): 2.7x less matrix time.  Not the
+// bitwise fmaf chain of the fp32 MFMA engines (gemm.hip.h stays the reference path, MRL_F32_BF16X6=0 selects it; builds
+// with -DMRL_PRODUCTS8 keep x1w2 and x2w1 too: < 2^-33 per product, 8/6 of the matrix time); parity tests hold unchanged.
 //
 //   * B (the weight matrix, 1.6 M elements) is split and laid out [plane][n][k] ONCE per call by split_planes_kernel
 //     -- its staging is then a plain 16-byte copy;
@@ -41,14 +41,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const long r = e / Cn, c = e - r * Cn;
         const long n = transpose ? c : r, k0 = transpose ? r : c;
         const long k = kperm ? kperm32(k0) : k0;
-        const float v = src[e];
-        const uint32_t u = __float_as_uint(v);
-        const float r1 = v - __uint_as_float(u & 0xffff0000u);
-        const uint32_t u1 = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-        out[(0 * Nn + n) * Kd + k] = (uint16_t)(u >> 16);
-        out[(1 * Nn + n) * Kd + k] = (uint16_t)(u1 >> 16);
-        out[(2 * Nn + n) * Kd + k] = (uint16_t)(__float_as_uint(r2) >> 16);
+        uint16_t b0, b1, b2;
+        split1_bf16x3(src[e], b0, b1, b2);
+        out[(0 * Nn + n) * Kd + k] = b0;
+        out[(1 * Nn + n) * Kd + k] = b1;
+        out[(2 * Nn + n) * Kd + k] = b2;
     }
 }
 
@@ -233,7 +230,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {       // small terms first
-                    if (X8) {                       // the two 2^-22 terms: 8 products, dropped part < 2^-29 of a product
+                    if (X8 && kCross21) {           // -DMRL_PRODUCTS8 builds: x2 w1 and x1 w2 as well (wres.hip.h)
                         acc[a][b] = mma(fa[a][2], fb[b][1], acc[a][b]);
                         acc[a][b] = mma(fa[a][1], fb[b][2], acc[a][b]);
                     }
@@ -447,12 +444,9 @@ inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef,
                                  long long* dbg = nullptr, bool x8 = false) {
     if (M <= 0 || N <= 0) return hipSuccess;
     // 256 x 64 tiles for the 64-filter conv layers, 128 x 128 otherwise
-    if (x8) {          // MRL_F32_BF16X6=2: eight products per multiply (x1w2 and x2w1 kept too)
-        if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true>(af, Bp, ef, M, N, K, dbg, stream);
-        return launch_gemm_x6_cfg<AF, EF, 2, 2, true>(af, Bp, ef, M, N, K, dbg, stream);
-    }
-    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, false>(af, Bp, ef, M, N, K, dbg, stream);
-    return launch_gemm_x6_cfg<AF, EF, 2, 2, false>(af, Bp, ef, M, N, K, dbg, stream);
+    (void)x8;          // one arithmetic per build: kSplitProducts products per multiply (wres.hip.h)
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true>(af, Bp, ef, M, N, K, dbg, stream);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2, true>(af, Bp, ef, M, N, K, dbg, stream);
 }
 
 }  // namespace mrl

@@ -341,7 +341,9 @@ static int get_option(const char* name, const char* env, int dflt) {
 // fp32 x fp32 GEMM sites that run on the bf16 pipe: 0 = fp32 MFMA (bitwise fmaf chain), 1 = six bf16 products per
 // multiply (dropped part < 2^-21 of a product), 2 = eight products (dropped part < 2^-29: below one fp32 rounding).
 // Default 2: every product of the update is then at least as accurate as an IEEE fp32 multiply.
-static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 2); }
+// 0: fp32 MFMA engines; anything else: the split engines (kSplitProducts exact bf16 products per multiply, wres.hip.h).
+// (Callers compare with 2, the value the option has carried since the eight-product form became the only tuned one.)
+static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 2) ? 2 : 0; }
 // transposed-accumulator epilogues and pre-split activation planes (planes.hip.h), eight-product mode only.  Bits:
 //   4 / 8 / 64 (default 76): transposed epilogues (16-byte stores, in-lane ReLU mask words) of the conv forward layers / the
 //                            data gradients / the hidden fc layer's forward -- c2.fwd 6.3 -> 5.5 ms, c2.dgrad 6.2 -> 5.75 ms;
@@ -377,6 +379,7 @@ static const OptionDef kOptions[] = {
 };
 extern "C" int mrl_get_option(const char* name, int* value_out) {
     if (!name || !value_out) return MRL_EINVAL;
+    if (!strcmp(name, "f32_products")) { *value_out = kSplitProducts; return 0; }      // read-only: fixed by the build
     for (const OptionDef& o : kOptions)
         if (!strcmp(o.name, name)) { *value_out = get_option(name, o.env, o.dflt); return 0; }
     return MRL_EINVAL;

@@ -5,11 +5,11 @@
 //
 // (tf.gradients of a2c/utils.py:37-56 `conv`, taken by ppo2/model.py:100-109) for NatureCNN's conv2 / conv3
 // (common/models.py:21-22).  Replaces the fp32-MFMA engine of imgres.hip.h for these two layers (24 % of the benched step
-// at 0.72 of the fp32 pipe, which is only 0.36 of what the 8-product arithmetic reaches on the bf16 pipe).
+// at 0.72 of the fp32 pipe, which is only 0.36 of what the split arithmetic reaches on the bf16 pipe).
 //
-// Arithmetic: the 8-product mode of gemmx6.hip.h -- both operands split EXACTLY into three bf16 planes (truncation split,
-// all residuals exact), 8 of the 9 partial products accumulated in fp32, small terms first; only x2*w2 (< 2^-29 of a
-// product, below one fp32 rounding) is dropped.
+// Arithmetic: that of gemmx6.hip.h -- both operands split EXACTLY into three bf16 planes (split2_bf16x3, wres.hip.h:
+// round-to-nearest at each level, all residuals exact), the six plane products x_i w_j with i + j <= 2 accumulated in fp32,
+// small terms first; what is dropped is at most 2^-24 of a product, one fp32 rounding (8 products in -DMRL_PRODUCTS8 builds).
 //
 // The contraction index of this GEMM is the output PIXEL, the slow index of both operands in memory, while
 // v_mfma_f32_32x32x16_bf16 wants 8 consecutive contraction elements per lane.  The tiled engine (wgradx8.hip.h) transposes
@@ -201,8 +201,10 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int c = 0; c < TN; ++c) {      // 8 of the 9 partial products, small terms first (gemmx6.hip.h)
+                    if (kCross21) {
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[c][1], acc[a][c], 0, 0, 0);
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[c][2], acc[a][c], 0, 0, 0);
+                    }
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[c][0], acc[a][c], 0, 0, 0);
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[c][1], acc[a][c], 0, 0, 0);
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[c][2], acc[a][c], 0, 0, 0);
@@ -402,8 +404,10 @@ __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __rest
                 if (j + 1 < MT) read_a(j + 1, fa[(j + 1) & 1]);
                 const bf16x8(&f)[3] = fa[j & 1];
                 // 8 of the 9 partial products, small terms first (gemmx6.hip.h)
+                if (kCross21) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], fb[1], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], fb[2], acc[j], 0, 0, 0);
+                }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], fb[0], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], fb[1], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], fb[2], acc[j], 0, 0, 0);

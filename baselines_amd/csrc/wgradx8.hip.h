@@ -2,8 +2,9 @@
 // db[n] = sum_m dZ[m][n]  (the gradient of `conv` / `fc`, a2c/utils.py:37-63, taken by tf.gradients in
 // ppo2/model.py:100-109), for the conv2 / conv3 / fc1 layers of NatureCNN (common/models.py:19-26).
 //
-// Same arithmetic as gemmx6.hip.h in its 8-product mode: both operands are split EXACTLY into three bf16 planes while
-// they are staged, 8 of the 9 partial products are accumulated in fp32 (dropped: x2*w2 < 2^-29 of a product).
+// Same arithmetic as gemmx6.hip.h: both operands are split EXACTLY into three bf16 planes while they are staged, six of the
+// nine partial products are accumulated in fp32 (dropped: at most 2^-24 of a product; eight in -DMRL_PRODUCTS8 builds, for
+// which this engine was first written -- hence the name).
 // What differs is the contraction index: it is the GEMM ROW m (sample, output pixel), which is the slow index of both
 // operands in memory, while v_mfma_f32_32x32x16_bf16 wants 8 consecutive contraction elements per lane.  The transpose
 // is free in the staging pass: a thread loads 16-byte pieces of 8 (or 4, or 2) consecutive rows, and the bf16 pairs it
@@ -162,9 +163,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_x8_kernel(AF af, const float* __r
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {       // small terms first (order of gemm_x6_kernel, 8 products)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][2], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) {       // small terms first (order of gemm_x6_kernel)
+                    if (kCross21) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][2], acc[a][b], 0, 0, 0);
+                    }
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);

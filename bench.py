@@ -126,8 +126,9 @@ def cpu_baseline(kind):
 def arithmetic_mode(_lib):
     """which arithmetic the GEMM sites of the NatureCNN update run in (engine options in effect, include/mrl.h)"""
     x3, x6, dg = _lib.get_option('u8_bf16x3'), _lib.get_option('f32_bf16x6'), _lib.get_option('dgrad_x6')
+    x6 = 2 if x6 else 0
     wx = _lib.get_option('wgrad_x8') if x6 == 2 else 0
-    nprod = {0: 0, 1: 6, 2: 8}[x6]
+    nprod = _lib.get_option('f32_products') if x6 else 0        # 6 (product builds) | 8 (-DMRL_PRODUCTS8 builds)
     sites = {}
     for s in ('c1.fwd', 'c1.wgrad'):
         sites[s] = 3 if x3 else 0
@@ -137,17 +138,18 @@ def arithmetic_mode(_lib):
         sites[s] = nprod if dg else 0
     wtr = _lib.get_option('wgrad_tr') if x6 == 2 else 0      # image-resident transpose-read kernel (wgradtr.hip.h)
     for s in ('c2.wgrad', 'c3.wgrad'):
-        sites[s] = 8 if (wx >= 2 or wtr) else 0
-    sites['fc1.wgrad'] = 8 if wx >= 1 else 0
+        sites[s] = nprod if (wx >= 2 or wtr) else 0
+    sites['fc1.wgrad'] = nprod if wx >= 1 else 0
     text = ('fp32 storage, fp32 accumulation, every product at least as accurate as an IEEE fp32 multiply. '
             'fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise fmaf chain): %s. '
             'bf16 MFMA on EXACT operand splits -- uint8 pixels x 3 exact bf16 planes of the other operand (3 products, '
-            'exact): %s; fp32 x fp32 with both operands split into 3 exact bf16 planes, %d of the 9 partial products '
-            'kept (dropped part < 2^-%d of a product; one fp32 rounding is 2^-24): %s.'
+            'exact): %s; fp32 x fp32 with both operands split into 3 exact bf16 planes (round-to-nearest at each level), '
+            '%d of the 9 partial products kept (dropped part <= 2^-%d of a product, %s on average; one fp32 multiply rounds '
+            'by up to 2^-24, 2.1e-8 on average): %s.'
             % (', '.join(k for k, v in sites.items() if v == 0) or '-',
-               ', '.join(k for k, v in sites.items() if v == 3) or '-', nprod, 29 if nprod == 8 else 21,
-               ', '.join(k for k, v in sites.items() if v >= 6) or '-'))
-    short = {0: 'f32-mfma', 1: 'bf16x6-split', 2: 'bf16x8-split'}[x6]
+               ', '.join(k for k, v in sites.items() if v == 3) or '-', nprod, 33 if nprod == 8 else 24,
+               '1e-11' if nprod == 8 else '3.5e-9', ', '.join(k for k, v in sites.items() if v >= 6) or '-'))
+    short = 'bf16x%d-rne-split' % nprod if x6 else 'f32-mfma'
     return sites, text, short
 
 

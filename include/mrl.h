@@ -367,21 +367,24 @@ int mrl_tune_set(const char* label, int variant);
 /* Engine options (process-wide; defaults also settable through the environment variable in brackets).  Every option
  * selects between engines that compute the SAME products (tests/test_gpu_kernels.py::test_engine_options_agree), except
  * "f32_bf16x6", which selects the arithmetic of the fp32 x fp32 GEMM sites:
- *   "f32_bf16x6"  [MRL_F32_BF16X6, 2]  fp32 x fp32 GEMM sites on the bf16 pipe with both operands split exactly into 3 bf16
- *                  planes: 2 = eight products per multiply (what is dropped is < 2^-29 of a product, below one fp32
- *                  rounding: the default), 1 = six products (< 2^-21), 0 = fp32 MFMA (bitwise fmaf chain)
+ *   "f32_bf16x6"  [MRL_F32_BF16X6, 2]  fp32 x fp32 GEMM sites on the bf16 pipe with both operands split EXACTLY into 3 bf16
+ *                  planes (round-to-nearest at each level) and the six plane products x_i w_j, i + j <= 2, accumulated in
+ *                  fp32: what is dropped is at most 2^-24 of a product -- the rounding of one IEEE fp32 multiply -- and
+ *                  3.5e-9 of it on average (csrc/wres.hip.h, tests/test_split_arithmetic.py); 0 = fp32 MFMA (bitwise fmaf
+ *                  chain).  Builds with -DMRL_PRODUCTS8 keep two more products (< 2^-33) at 8/6 of the matrix time;
+ *                  the read-only option "f32_products" reports which build is loaded (6 | 8)
  *   "u8_bf16x3"   [MRL_U8_BF16X3, 1]  first conv layer (uint8 pixels) on the bf16 pipe with an exact 3-way bf16 split of the
  *                  other operand; 0 = fp32 MFMA
- *   "tr_epilogue" [MRL_TR_EPILOGUE, 1]  eight-product split engines (hidden conv / fc forward, data gradients) accumulate
+ *   "tr_epilogue" [MRL_TR_EPILOGUE, 1]  split engines (hidden conv / fc forward, data gradients) accumulate
  *                  transposed (D^T = B A^T): a lane owns one output row, 16-byte stores, in-lane ReLU mask words;
  *                  0 = row-major accumulators, ballot mask words
  *   "relu_bits"   [MRL_RELU_BITS, 1]  conv forward epilogues also write a 1-bit-per-element ReLU mask that the data gradients
  *                  read instead of the fp32 activations; 0 = fp32 activations
  *   "dgrad_x6"    [MRL_DGRAD_X6, 1]  conv data gradients on the position-major tiled split engine; 0 = LDS-resident fp32-MFMA
  *                  engine ("dgrad_async" [MRL_DGRAD_ASYNC, 1]: its LDS-DMA staging form for conv2)
- *   "wgrad_tr"    [MRL_WGRAD_TR, 1]  weight gradients of conv2 / conv3 / fc1 on the eight-product transpose-read kernels
+ *   "wgrad_tr"    [MRL_WGRAD_TR, 1]  weight gradients of conv2 / conv3 / fc1 on the split-arithmetic transpose-read kernels
  *                  (wgradtr.hip.h: operands staged in their natural layout, split once, fragments fetched with LDS transpose
- *                  reads; needs f32_bf16x6 = 2); 0 = "wgrad_x8" / fp32-MFMA engines
+ *                  reads; needs f32_bf16x6 != 0); 0 = "wgrad_x8" / fp32-MFMA engines
  *   "wgrad_x8"    [MRL_WGRAD_X8, 1]  (wgrad_tr = 0) weight gradients on the transposed-staging tiles of wgradx8.hip.h: 1 = layers
  *                  with >= 128 outputs (fc1), 2 = conv2 / conv3 too, 0 = image-resident / tiled fp32-MFMA engines
  *   "c1_wgrad2"   [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
@@ -392,6 +395,7 @@ int mrl_tune_set(const char* label, int variant);
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
  *   "fused_norm"  [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "mlp_fused"   [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
+ *   "mlp_waves"   [MRL_MLP_WAVES, 8]  waves per workgroup of that kernel (8 | 4)
  *   "heads_wave"  [MRL_HEADS_WAVE, 1]  wave-per-sample loss / head-gradient kernel for the NatureCNN head shape; 0 = generic
  * Builds with -DMRL_X6_EXPERIMENTS (MRL_BUILD_DEFINES, csrc/build.py) add the measured-and-dropped variants that
  * profiles/README.md and scripts/ab_options.py refer to ("act_planes", "x6_il", "x6_spec", "*_dbg", ...); they are not part of

@@ -272,14 +272,15 @@ def test_engine_options_agree():
     """The fast engines against their plain counterparts on the same minibatch:
        * first conv layer on the bf16 pipe (exact u8 x 3-way bf16 split) vs the fp32 MFMA path,
        * conv2/conv3/fc1 forward and the conv2/conv3/fc1 data gradients on the bf16 pipe (both operands split into 3 exact
-         bf16 planes, 8 or 6 products per multiply) vs the fp32 MFMA paths (batch >= 1024 so that the tiled split engine
+         bf16 planes, six products per multiply -- eight in -DMRL_PRODUCTS8 builds) vs the fp32 MFMA paths (batch >= 1024 so that the tiled split engine
          takes the fc layer),
        * conv data gradients on the position-major tiled engine vs the LDS-resident fp32-MFMA engine,
        * fused whole-step MLP kernel vs layer-wise launches.
     Gradients agree to fp32 round-off on EVERY entry (the split products are exact; only the summation order and the
-    folded 1/255 scale differ).  The large-batch case runs on a minibatch screened by the fp64 oracle for ReLU margins
-    (tests/test_gpu_large_batch.py): with a thousand samples a few pre-activations otherwise land within round-off of
-    the kink and switch on in one engine and off in the other, which is a property of ReLU, not of an engine."""
+    folded 1/255 scale differ).  The NatureCNN cases run on minibatches screened by the fp64 oracle for ReLU margins
+    (tests/test_gpu_large_batch.py): a pre-activation within round-off of the kink switches on in one engine and off in
+    the other -- the forward value hardly moves, but a whole element of the gradient flowing back does -- which is a
+    property of ReLU, not of an engine."""
     from baselines_amd import _lib as L
     from baselines_amd import ops
     from tests.test_gpu_large_batch import _problem
@@ -323,13 +324,14 @@ def test_engine_options_agree():
         experiments = False
     defaults = {o: L.get_option(o) for o in names}
     assert defaults['tr_epilogue'] == 1, 'transposed-accumulator epilogues are the default'
-    assert defaults['f32_bf16x6'] == 2, 'the default arithmetic of the split engines is the 8-product mode'
+    assert defaults['f32_bf16x6'] == 2 and L.get_option('f32_products') in (6, 8), 'split engines are the default'
     assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 / fc1 weight gradients: transpose-read kernels by default'
     if experiments:
         assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
     try:
         cnn = ('cnn', (84, 84, 4), np.uint8, 'categorical', 6, False)
-        # ---- small batches: plain random data
+        # ---- small batches (screened samples for the NatureCNN cases, plain random data for the MLPs)
+        om_s, _, mb_s = _problem(168, 23)
         small = [(cnn, 160, 'u8_bf16x3', 1), (cnn, 161, 'c1_lds', 1), (cnn, 163, 'c1_wgrad2', 1), (cnn, 165, 'tr_epilogue', 1),
                  (cnn, 168, 'x6_pg', 8),
                  (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused', 1),
@@ -337,8 +339,9 @@ def test_engine_options_agree():
         if experiments:
             small += [(cnn, 32, 'act_planes', 79), (cnn, 166, 'act_planes', 28), (cnn, 167, 'x6_il', 1)]
         for cfg, B, opt, on in small:
-            g1, s1 = grads(*cfg, B, dict(defaults, **{opt: on}))
-            g0, s0 = grads(*cfg, B, dict(defaults, **{opt: 0 if opt != 'x6_pg' else 1}))
+            scr_s = (om_s, None, {k: v[:B] for k, v in mb_s.items()}) if cfg is cnn else None
+            g1, s1 = grads(*cfg, B, dict(defaults, **{opt: on}), scr_s)
+            g0, s0 = grads(*cfg, B, dict(defaults, **{opt: 0 if opt != 'x6_pg' else 1}), scr_s)
             scale = np.abs(g0).max()
             assert np.abs(g1 - g0).max() <= 2e-6 * scale + 1e-9, (opt, np.abs(g1 - g0).max(), scale)
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
@@ -351,21 +354,20 @@ def test_engine_options_agree():
             ref_opts.update(act_planes=0, x6_il=0)
         g0, s0 = grads(*cnn, B, ref_opts, scr)
         scale = np.abs(g0).max()
-        cases = [('8 products (default)', dict(defaults), 3e-6),
-                 ('6 products', dict(defaults, f32_bf16x6=1), 6e-6),
-                 ('8 products, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
-                 ('8 products, act\' from the fp32 activations instead of the ReLU bit masks', dict(defaults, relu_bits=0), 3e-6),
-                 ('8 products, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
-                 ('8 products, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
-                 ('8 products, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
-                 ('8 products, first conv layer forward: the other image-resident kernel',
+        cases = [('split engines (default)', dict(defaults), 3e-6),
+                 ('split engines, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
+                 ('split engines, act\' from the fp32 activations instead of the ReLU bit masks', dict(defaults, relu_bits=0), 3e-6),
+                 ('split engines, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
+                 ('split engines, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
+                 ('split engines, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
+                 ('split engines, first conv layer forward: the other image-resident kernel',
                   dict(defaults, c1_lds=3 - defaults['c1_lds']), 3e-6),
-                 ('8 products, conv1 weight gradient: whole-image workgroups', dict(defaults, c1_wgrad2=1), 3e-6),
-                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
+                 ('split engines, conv1 weight gradient: whole-image workgroups', dict(defaults, c1_wgrad2=1), 3e-6),
+                 ('split engines, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
                   dict(defaults, wgrad_x8=0, wgrad_tr=0), 3e-6),
-                 ('8 products, conv2 / conv3 weight gradients on the fp32-MFMA image-resident engine, fc1 on the transposed-staging tiles',
+                 ('split engines, conv2 / conv3 weight gradients on the fp32-MFMA image-resident engine, fc1 on the transposed-staging tiles',
                   dict(defaults, wgrad_tr=0), 3e-6),
-                 ('8 products, weight gradients of conv2 / conv3 / fc1 on the transposed-staging tiles',
+                 ('split engines, weight gradients of conv2 / conv3 / fc1 on the transposed-staging tiles',
                   dict(defaults, wgrad_x8=2, wgrad_tr=0), 3e-6)]
         if experiments:
             cases += [('loads in a phase of their own instead of between the MFMAs', dict(defaults, x6_il=0), 3e-6),
