@@ -447,18 +447,27 @@ inline hipError_t launch_wres_u8x3(const WresFwdA<true>& al, const float* w, con
 
 // ------------------------------------------------------------------------------------------
 // Exact 3-way bf16 split of fp32 values (the split engines: gemmx6 / dgradx6 / wgradtr / wgradx8): x = x0 + x1 + x2, every
-// plane a bf16 value, the sum EXACT.  Round-to-nearest-even at each level (v_cvt_pk_bf16_f32): the residual after a plane is
-// at most half a unit of that plane's last place, so |x1| <= 2^-8 |x| and |x2| <= 2^-17 |x|, and the last residual has at
-// most 8 significant bits -- it IS a bf16 value.  (Finite inputs below 2^127 (1 - 2^-9): nearer to the largest fp32 the
-// first rounding would overflow; activations and gradients never get there.)
+// plane a bf16 value, the sum EXACT.  Each level rounds to NEAREST (ties away from zero: half a unit of the bf16 last place
+// added to the magnitude bits, then truncated), so the residual after a plane is at most half a unit of that plane's last
+// place: |x1| <= 2^-8 |x|, |x2| <= 2^-17 |x|, and the last residual has at most 8 significant bits -- it IS a bf16 value.
+// (Finite inputs below 2^127 (1 - 2^-9): nearer to the largest fp32 the first rounding would carry into the exponent of
+// infinity; activations and gradients never get there.)
 //
 // A product of two fp32 values is the sum of the 9 plane products, each exact in the fp32 accumulator (8 x 8 significant
 // bits).  The engines keep the SIX products x_i w_j with i + j <= 2; what they drop is x1 w2 + x2 w1 + x2 w2
 // <= (2^-25 + 2^-25 + 2^-34) |x w| -- at most 2^-24 of the product, the rounding of ONE IEEE fp32 multiply, and 3.5e-9 of
-// it on average (an fp32 multiply: 2.1e-8; tests/test_split_arithmetic.py).  A build with -DMRL_PRODUCTS8 keeps x1 w2 and
-// x2 w1 as well (dropped part < 2^-33 of a product) at 8/6 of the matrix-pipe time.
-// (Two floats -> three packed bf16 pairs, 9 VALU instructions.  A weights-resident forward built on per-lane global ->
-// VGPR fragments was measured TA/L1-bound and is not kept: profiles/README.md.)
+// it on average, without bias (an fp32 multiply: 2.1e-8; tests/test_split_arithmetic.py).  A build with -DMRL_PRODUCTS8
+// keeps x1 w2 and x2 w1 as well (dropped part < 2^-33 of a product) at 8/6 of the matrix-pipe time.
+//
+// Cost: 15 full-rate VALU instructions per two values (a truncating split is 11, but its one-sided residuals are twice as
+// large: six products would then be off by up to 2^-21 and biased, eight were needed -- 158 ms per benched epoch against 138
+// with this split).  Measured and dropped: the hardware conversion v_cvt_pk_bf16_f32 (9 instructions per pair, but the
+// A-staging engines ran 35 % SLOWER: the conversion is not a full-rate instruction) and Veltkamp's splitting in packed fp32
+// arithmetic (11 v_pk_mul/add_f32 per pair: 147 ms, the packed fp32 operations issue at half rate), and residuals taken
+// straight from the packed plane with v_dot2c_f32_bf16 (11 per pair: 147 ms as well, and not exact -- it fails the
+// engine-agreement test).
+// (A weights-resident forward built on per-lane global -> VGPR fragments was measured TA/L1-bound and is not kept:
+// profiles/README.md.)
 // ------------------------------------------------------------------------------------------
 #ifdef MRL_PRODUCTS8
 constexpr bool kCross21 = true;
@@ -466,17 +475,15 @@ constexpr bool kCross21 = true;
 constexpr bool kCross21 = false;
 #endif
 constexpr int kSplitProducts = kCross21 ? 8 : 6;
-typedef __bf16 wres_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float wres_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack2_bf16_rne(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(wres_f32x2{lo, hi}, wres_bf16x2));
-}
+// two floats -> three packed bf16 pairs (plane 0 / 1 / 2; x0 in the low half)
 __device__ __forceinline__ void split2_bf16x3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = pack2_bf16_rne(x0, x1);
-    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
-    p1 = pack2_bf16_rne(r0, r1);
-    const float l0 = r0 - __uint_as_float(p1 << 16), l1 = r1 - __uint_as_float(p1 & 0xffff0000u);
-    p2 = pack2_bf16_rne(l0, l1);                     // exact: the second residual has <= 8 significant bits
+    const uint32_t t0 = __float_as_uint(x0) + 0x8000u, t1 = __float_as_uint(x1) + 0x8000u;
+    p0 = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(t0 & 0xffff0000u), r1 = x1 - __uint_as_float(t1 & 0xffff0000u);
+    const uint32_t v0 = __float_as_uint(r0) + 0x8000u, v1 = __float_as_uint(r1) + 0x8000u;
+    p1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float l0 = r0 - __uint_as_float(v0 & 0xffff0000u), l1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);      // exact: <= 8 significant bits left
 }
 // one value -> the bf16 bit patterns of its three planes (the weight-plane kernels)
 __device__ __forceinline__ void split1_bf16x3(float v, uint16_t& b0, uint16_t& b1, uint16_t& b2) {

@@ -149,7 +149,7 @@ def arithmetic_mode(_lib):
             % (', '.join(k for k, v in sites.items() if v == 0) or '-',
                ', '.join(k for k, v in sites.items() if v == 3) or '-', nprod, 33 if nprod == 8 else 24,
                '1e-11' if nprod == 8 else '3.5e-9', ', '.join(k for k, v in sites.items() if v >= 6) or '-'))
-    short = 'bf16x%d-rne-split' % nprod if x6 else 'f32-mfma'
+    short = 'bf16x%d-rn-split' % nprod if x6 else 'f32-mfma'
     return sites, text, short
 
 

@@ -1,23 +1,24 @@
 """CPU: the arithmetic claim behind the split engines, checked with a NumPy emulation of `split2_bf16x3`
-(csrc/wres.hip.h; round-to-nearest-even at each level, the hardware's v_cvt_pk_bf16_f32): the three planes are bf16 values,
+(csrc/wres.hip.h; round-to-nearest at each level, ties away from zero): the three planes are bf16 values,
 their sum is the fp32 value EXACTLY (every mantissa checked), every kept plane product is exact in fp32, and the six-term
 product differs from the exact product by at most 2^-24 relative -- the rounding of one IEEE fp32 multiply -- and by 3.5e-9
 on average (an fp32 multiply: 2.1e-8).  (-DMRL_PRODUCTS8 builds keep two more terms: < 2^-33.)"""
 import numpy as np
 
 
-def rne_bf16(x):
+def round_bf16(x):
+    """half a unit of the bf16 last place added to the magnitude bits, then truncated (split2_bf16x3)"""
     u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
-    return ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32).view(np.float32)
+    return ((u + 0x8000) & 0xffff0000).astype(np.uint32).view(np.float32)
 
 
 def split3(x):
     x = np.asarray(x, np.float32)
-    p0 = rne_bf16(x)
+    p0 = round_bf16(x)
     r1 = x - p0
-    p1 = rne_bf16(r1)
+    p1 = round_bf16(r1)
     r2 = r1 - p1
-    return p0, p1, rne_bf16(r2), r2
+    return p0, p1, round_bf16(r2), r2
 
 
 def _is_bf16(p):
@@ -45,11 +46,12 @@ def test_three_way_split_is_exact_and_bf16():
 def test_three_way_split_is_exact_for_every_mantissa():
     """all 2^23 mantissas of one binade (the split is scale-invariant away from the ends of the exponent range)"""
     x = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3f800000)).view(np.float32)
-    p0, p1, p2, r2 = split3(x)
-    assert _is_bf16(p0) and _is_bf16(p1) and _is_bf16(p2)
-    np.testing.assert_array_equal(p2, r2)
-    np.testing.assert_array_equal(p0.astype(np.float64) + p1.astype(np.float64) + p2.astype(np.float64), x.astype(np.float64))
-    assert (np.abs(p1) / x).max() <= 2.0 ** -8 and (np.abs(p2) / x).max() <= 2.0 ** -17
+    for sign in (1.0, -1.0):
+        p0, p1, p2, r2 = split3(np.float32(sign) * x)
+        assert _is_bf16(p0) and _is_bf16(p1) and _is_bf16(p2)
+        np.testing.assert_array_equal(p2, r2)
+        np.testing.assert_array_equal(p0.astype(np.float64) + p1.astype(np.float64) + p2.astype(np.float64), sign * x.astype(np.float64))
+        assert (np.abs(p1) / x).max() <= 2.0 ** -8 and (np.abs(p2) / x).max() <= 2.0 ** -17
 
 
 def test_u8_times_three_planes_is_exact():
@@ -79,6 +81,7 @@ def test_six_term_product_is_within_one_fp32_rounding():
     fp32_mul = np.abs(exact.astype(np.float32).astype(np.float64) - exact) / np.abs(exact)           # one IEEE fp32 multiply
     assert fp32_mul.max() <= 2.0 ** -24 and rel.max() <= fp32_mul.max()
     assert rel.mean() < 4e-9 and rel.mean() < fp32_mul.mean() / 5                          # 3.5e-9 vs 2.1e-8
+    assert abs(((six - exact) / np.abs(exact)).mean()) < 1e-10                             # and no bias
     eight = six + (a1 * b2 + a2 * b1)                                                      # -DMRL_PRODUCTS8
     assert (np.abs(eight - exact) / np.abs(exact)).max() < 2.0 ** -33
 
