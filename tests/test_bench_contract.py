@@ -1,5 +1,5 @@
 """CPU: the one-line JSON contract of bench.py, checked on the committed result of the last GPU run
-(profiles/r03k_bench_atari4096.json) and on bench.py's own argument defaults."""
+(profiles/r03p_bench_atari4096.json) and on bench.py's own argument defaults."""
 import ast
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r03k_bench_atari4096.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r03p_bench_atari4096.json')))
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert d['metric'] == base['metric']
     for key in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
@@ -22,10 +22,11 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r['traffic'] is None or r['traffic'] > 0
     assert (r['traffic'] is None or r['traffic_source'].startswith('profiles/r03')) and d['dtype'] == 'f32'
     assert r['bound'] == 'mfma' and abs(r['frac'] - r['mfma_frac']) < 1e-12 and 0 < r['hbm_frac'] < r['frac']
-    assert d['config']['arithmetic_mode'] == 'bf16x8-split'          # the headline runs the 8-product (fp32-or-better) mode
+    # the headline runs the split engines: six exact bf16 products per fp32 multiply, nearest-rounded planes
+    assert d['config']['arithmetic_mode'] == 'bf16x6-rn-split'
     kr = d['kernel_rooflines']
-    # every fp32 x fp32 site on the 8-product pipe; the uint8 first layer (3 products) is HBM-bound: priced on HBM
-    assert abs(kr['c2.wgrad']['peak'] - 2516.6 / 8) < 1e-3 and abs(kr['c2.fwd']['peak'] - 2516.6 / 8) < 1e-3
+    # every fp32 x fp32 site on the 6-product pipe; the uint8 first layer (3 products) is HBM-bound: priced on HBM
+    assert abs(kr['c2.wgrad']['peak'] - 2516.6 / 6) < 1e-3 and abs(kr['c2.fwd']['peak'] - 2516.6 / 6) < 1e-3
     assert kr['c1.fwd']['bound'] == 'hbm' and kr['c1.fwd']['peak'] == 8000.0 and abs(kr['c1.fwd']['mfma_peak_tflops'] - 2516.6 / 3) < 1e-3
     assert d['self_check']['stats_max_abs_diff'] <= 1e-5 and d['self_check']['grad_max_abs_diff_over_scale'] <= 1e-5
     assert {o['workload'].split()[0] for o in d['other_configs']} == {'ppo2', 'deepq'} and len(d['other_configs']) == 4
