@@ -36,9 +36,15 @@ struct MlpStepArgs {
     // same fixed order everywhere -- identical results in all workgroups, two launches fewer per step.
     // tile_idx != nullptr (with advstat == nullptr): env-major indices of THIS call's samples, translated here.
     const float* stat_ret; const float* stat_val; const int64_t* stat_idx; const int64_t* tile_idx; int Bstat, T, N;
+    // slice != 0 (two separate nets only): the grid has TWO workgroups per tile -- workgroup 2 t carries the policy net, its
+    // head and the policy part of the loss through the step, workgroup 2 t + 1 the value net; each writes its own part of
+    // slab t and its own entries of the 5 statistics (they are disjoint), and only the policy workgroup needs the advantage
+    // statistics.  A tile's serial chain is cut in half and a 4096-sample minibatch fills 256 CUs instead of 128.
+    int slice;
     float* part;           // [ntiles][P]
     double* spart;         // [ntiles][5]
-    long long* dbg;        // optional [8] phase timestamps of workgroup 0 (s_memtime), nullptr normally
+    long long* dbg;        // optional [8] phase timestamps (shader clock) of workgroup dbg_block, nullptr normally
+    int dbg_block;
 };
 
 constexpr int MLP_NH = 64;             // hidden width
@@ -76,27 +82,34 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int K0 = a.K0, KB0 = (K0 + 7) / 8, KP = KB0 * 8 + 4;
-    const int nets = a.nets, nact = a.nact;
-    const bool shared = nets == 1;
-    const int s0 = blockIdx.x * 32;
+    const int nact = a.nact;
+    const bool shared = a.nets == 1;                        // one latent feeds both heads
+    const bool sl = a.slice != 0;                           // this workgroup carries ONE of the two nets
+    const int tile = sl ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int nb = sl ? (int)(blockIdx.x & 1) : 0;          // first net of this workgroup (0: policy, 1: value)
+    const int nets = sl ? 1 : a.nets;                       // nets this workgroup carries (local index 0 .. nets-1)
+    const bool do_pi = !sl || nb == 0, do_vf = !sl || nb == 1;
+    const int s0 = tile * 32;
     const float* P = a.params;
-    float* slab = a.part + (long)blockIdx.x * a.P;
+    float* slab = a.part + (long)tile * a.P;
     // NOTE: never index a.w0[] etc. with a runtime value -- a dynamically indexed kernel-argument array is
     // spilled to memory and re-loaded (global_load + s_waitcnt vmcnt(0)) in front of every use.
-    auto W0 = [&](int n) { return n ? a.w0[1] : a.w0[0]; };
-    auto B0 = [&](int n) { return n ? a.b0[1] : a.b0[0]; };
-    auto W1 = [&](int n) { return n ? a.w1[1] : a.w1[0]; };
-    auto B1 = [&](int n) { return n ? a.b1[1] : a.b1[0]; };
-    auto stamp = [&](int k) { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[k] = (long long)__builtin_readcyclecounter(); };
+    // (n = LOCAL net index; nb shifts it to the net whose parameters are meant)
+    auto W0 = [&](int n) { return (n + nb) ? a.w0[1] : a.w0[0]; };
+    auto B0 = [&](int n) { return (n + nb) ? a.b0[1] : a.b0[0]; };
+    auto W1 = [&](int n) { return (n + nb) ? a.w1[1] : a.w1[0]; };
+    auto B1 = [&](int n) { return (n + nb) ? a.b1[1] : a.b1[0]; };
+    auto stamp = [&](int k) { if (a.dbg && (int)blockIdx.x == a.dbg_block && tid == 0) a.dbg[k] = (long long)__builtin_readcyclecounter(); };
+    const int anets = nets;                                 // LDS is carved for the nets THIS workgroup carries
     stamp(0);
 
     // ---- LDS carve
     float* obs_s = sm;                                   // [32][KP]
     float* h0_s = obs_s + 32 * KP;                       // [nets][32][MLP_LD]
-    float* h1_s = h0_s + nets * 32 * MLP_LD;
-    float* dz1_s = h1_s + nets * 32 * MLP_LD;
-    float* dz0_s = dz1_s + nets * 32 * MLP_LD;
-    float* pi_s = dz0_s + nets * 32 * MLP_LD;            // [32][32] pdparam (mean / logits)
+    float* h1_s = h0_s + anets * 32 * MLP_LD;
+    float* dz1_s = h1_s + anets * 32 * MLP_LD;
+    float* dz0_s = dz1_s + anets * 32 * MLP_LD;
+    float* pi_s = dz0_s + anets * 32 * MLP_LD;           // [32][32] pdparam (mean / logits)
     float* dpi_s = pi_s + 32 * 32;                       // [32][32]
     float* dls_s = dpi_s + 32 * 32;                      // [32][32]
     float* v_s = dls_s + 32 * 32;                        // [32]
@@ -104,116 +117,184 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     float* wpi_s = dv_s + 32;                            // [64][nact] policy head weights
     float* wvf_s = wpi_s + 64 * 32;                      // [64] value head weights
     long* row_s = reinterpret_cast<long*>(wvf_s + 64);   // [32] storage rows (-1: beyond the minibatch)
-    float* kp_s = reinterpret_cast<float*>(row_s + 32);  // [4 waves][16][64] partial accumulators of the second k half
+    float* kp_s = reinterpret_cast<float*>(row_s + 32);  // [<= 6 waves][16][64] partial accumulators of the later k ranges
 
-    // ---- P0: rows + observation tile
-    if (tid < 32) {
-        const int b = s0 + tid;
-        long r = -1;
-        if (b < a.B) r = a.tile_idx ? envmajor_to_row(a.tile_idx[b], a.T, a.N) : (a.srow ? (long)a.srow[b] : (long)b);
-        row_s[tid] = r;
-    }
-    // ---- P0': advantage statistics of the whole minibatch (f64 accumulation, fixed order)
-    float adv_mean, adv_sd;
-    if (!a.advstat) {
-        double* red = reinterpret_cast<double*>(pi_s);       // LDS scratch; pi_s is first written in P3a
-        double s1 = 0.0, s2 = 0.0;
-        // batches of 8 samples per thread: all index loads, then all gathers in flight together (one wave per SIMD here:
-        // every dependent load would otherwise expose its full latency, 2 per sample)
-        for (int b0 = tid; b0 < a.Bstat; b0 += 8 * MLP_NT) {
-            long r[8];
-            float rv[8], vv[8];
+    // ---- weight fragments of the two forward layers: requested FIRST.  The parameters were rewritten by the optimizer since
+    //      the last step, so every XCD fetches them from the fabric again; asked for here, that trip overlaps with P0's
+    //      index / gather chains instead of standing in front of the MFMAs of P1 / P2 (P1: 9.5 -> ... us).
+    const int p1_NTL = 2 * nets, p1_KS = MLP_NW / p1_NTL;
+    const int p1_wq = wave % p1_NTL, p1_kr = wave / p1_NTL;         // output tile, k range of this wave
+    const int p1_net = p1_wq >> 1, p1_n0 = (p1_wq & 1) * 32;
+    const int p1_NGT = (KB0 + 3) / 4;                               // groups of 4 k blocks; range p1_kr of p1_KS
+    const int p1_gb = (p1_NGT * p1_kr + p1_KS - 1) / p1_KS, p1_NG = (p1_NGT * (p1_kr + 1) + p1_KS - 1) / p1_KS;
+    const float* p1_wcol = P + W0(p1_net) + p1_n0 + i;
+    auto loadg = [&](int g, float (&dst)[16]) {                     // unconditional loads with a clamped row, zeroed by select
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = min(b0 + u * MLP_NT, a.Bstat - 1);
-                r[u] = a.stat_idx ? (long)a.stat_idx[b] : (long)b;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 8 * (4 * g + u) + 4 * h + q;
+                const float w = p1_wcol[(long)min(k, K0 - 1) * MLP_NH];
+                dst[4 * u + q] = k < K0 ? w : 0.f;
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (a.stat_idx) r[u] = envmajor_to_row(r[u], a.T, a.N);
-                rv[u] = a.stat_ret[r[u]];
-                vv[u] = a.stat_val[r[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (b0 + u * MLP_NT < a.Bstat) {
-                    const float x = __fsub_rn(rv[u], vv[u]);
-                    s1 += (double)x;
-                    s2 += (double)x * (double)x;
-                }
-        }
-        const double t1 = mlp_block_sum<MLP_NW>(s1, red);
-        const double t2 = mlp_block_sum<MLP_NW>(s2, red + MLP_NW);
-        if (tid == 0) {
-            const double mean = t1 / a.Bstat;
-            double var = t2 / a.Bstat - mean * mean;
-            if (var < 0) var = 0;
-            red[2 * MLP_NW] = (double)(float)mean;
-            red[2 * MLP_NW + 1] = (double)(float)sqrt(var);
-        }
-        __syncthreads();
-        adv_mean = (float)red[2 * MLP_NW];
-        adv_sd = (float)red[2 * MLP_NW + 1] + 1e-8f;
-    } else {
-        adv_mean = a.advstat[0];
-        adv_sd = a.advstat[1] + 1e-8f;
+    };
+    const bool p1_pre = p1_NG - p1_gb <= 3;                         // short k range (3 groups at K0 = 376 with 8 waves on one net)
+    float fb0[16], fb1[16], fb2[16];
+    if (p1_pre) {
+        if (p1_gb < p1_NG) loadg(p1_gb, fb0);
+        if (p1_gb + 1 < p1_NG) loadg(p1_gb + 1, fb1);
+        if (p1_gb + 2 < p1_NG) loadg(p1_gb + 2, fb2);
     }
-    __syncthreads();
-    // one wave per SIMD: every memory latency is exposed, so loads are issued in batches of 8 before use
+    const int p2_net = wave >> 1, p2_n0 = (wave & 1) * 32;
+    const bool p2_on = wave < 4 && p2_net < nets;
+    float w1f[32];                                                   // fc1 weight fragments of this wave's output tile
+    if (p2_on) {
+        const float* W = P + W1(p2_net);
+#pragma unroll
+        for (int kb = 0; kb < MLP_NH / 8; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w1f[4 * kb + q] = W[(8 * kb + 4 * h + q) * MLP_NH + p2_n0 + i];
+    }
+
+    // ---- P0: rows, advantage statistics of the whole minibatch (model.py:136-139; f64 accumulation, fixed order), observation
+    //      tile, small weights.  One wave per SIMD: every memory latency is exposed, so the two dependent chains (index ->
+    //      returns / values of the Bstat samples; index -> observation row) are walked TOGETHER: all index loads, then all
+    //      gathers, then the reductions and LDS writes (round 3; one chain after the other cost 16 of the step's 53 us).
+    auto tile_row = [&](int sidx) -> long {                 // storage row of sample sidx of this tile (-1: beyond the minibatch)
+        const int b = s0 + sidx;
+        if (b >= a.B) return -1;
+        return a.tile_idx ? envmajor_to_row(a.tile_idx[b], a.T, a.N) : (a.srow ? (long)a.srow[b] : (long)b);
+    };
+    if (tid < 32) row_s[tid] = tile_row(tid);
+    float adv_mean = 0.f, adv_sd = 1.f;
+    const bool own_stats = do_pi && !a.advstat;             // (a value workgroup of a sliced launch never needs the advantage)
     {
         const int nv = 32 * (KP / 4);
-        for (int e0 = tid; e0 < nv; e0 += 8 * MLP_NT) {
+        const int nob = (nv + 8 * MLP_NT - 1) / (8 * MLP_NT);          // batches of 8 float4 per thread (1 at K0 = 376)
+        const int nsb = own_stats ? (a.Bstat + 8 * MLP_NT - 1) / (8 * MLP_NT) : 0;
+        double s1 = 0.0, s2 = 0.0;
+        for (int it = 0; it < max(nob, nsb); ++it) {
+            const int b0 = tid + it * 8 * MLP_NT, e0 = tid + it * 8 * MLP_NT;
+            long sr[8], orow[8];
+            float rv[8], vv[8];
             float4 v[8];
+            // round 1: indices
+            if (it < nsb) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * MLP_NT;
-                v[u] = f4zero();
-                if (e < nv) {
-                    const int s = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
-                    const long r = row_s[s];
-                    if (r >= 0 && c4 + 3 < K0) v[u] = *reinterpret_cast<const float4*>(a.obs + r * K0 + c4);
-                    else if (r >= 0 && c4 < K0) v[u] = load_partial(a.obs + r * K0 + c4, K0 - c4);
+                for (int u = 0; u < 8; ++u) {
+                    const int b = min(b0 + u * MLP_NT, a.Bstat - 1);
+                    sr[u] = a.stat_idx ? (long)a.stat_idx[b] : (long)b;
                 }
             }
+            if (it < nob) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * MLP_NT;
-                if (e < nv) {
-                    const int s = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
-                    *reinterpret_cast<float4*>(obs_s + s * KP + c4) = v[u];
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * MLP_NT;
+                    orow[u] = e < nv ? tile_row(e / (KP / 4)) : -1;
+                }
+            }
+            // round 2: gathers
+            if (it < nsb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (a.stat_idx) sr[u] = envmajor_to_row(sr[u], a.T, a.N);
+                    rv[u] = a.stat_ret[sr[u]];
+                    vv[u] = a.stat_val[sr[u]];
+                }
+            }
+            if (it < nob) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * MLP_NT;
+                    v[u] = f4zero();
+                    if (e < nv) {
+                        const int c4 = (e % (KP / 4)) * 4;
+                        const long r = orow[u];
+                        if (r >= 0 && c4 + 3 < K0) v[u] = *reinterpret_cast<const float4*>(a.obs + r * K0 + c4);
+                        else if (r >= 0 && c4 < K0) v[u] = load_partial(a.obs + r * K0 + c4, K0 - c4);
+                    }
+                }
+            }
+            if (it == 0) {      // small weights -> LDS (coalesced): pi head, value head
+                if (do_pi)
+                    for (int e = tid; e < 64 * nact; e += MLP_NT) wpi_s[e] = P[a.wpi + e];
+                if (do_vf)
+                    for (int e = tid; e < 64; e += MLP_NT) wvf_s[e] = P[a.wvf + e];
+            }
+            if (it < nsb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + u * MLP_NT < a.Bstat) {
+                        const float x = __fsub_rn(rv[u], vv[u]);
+                        s1 += (double)x;
+                        s2 += (double)x * (double)x;
+                    }
+            }
+            if (it < nob) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * MLP_NT;
+                    if (e < nv) {
+                        const int sidx = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
+                        *reinterpret_cast<float4*>(obs_s + sidx * KP + c4) = v[u];
+                    }
                 }
             }
         }
-        // small weights -> LDS (coalesced): pi head, value head, biases, logstd
-        for (int e = tid; e < 64 * nact; e += MLP_NT) wpi_s[e] = P[a.wpi + e];
-        for (int e = tid; e < 64; e += MLP_NT) wvf_s[e] = P[a.wvf + e];
+        if (own_stats) {
+            double* red = reinterpret_cast<double*>(pi_s);       // LDS scratch; pi_s is first written in P3a
+            const double t1 = mlp_block_sum<MLP_NW>(s1, red);
+            const double t2 = mlp_block_sum<MLP_NW>(s2, red + MLP_NW);
+            if (tid == 0) {
+                const double mean = t1 / a.Bstat;
+                double var = t2 / a.Bstat - mean * mean;
+                if (var < 0) var = 0;
+                red[2 * MLP_NW] = (double)(float)mean;
+                red[2 * MLP_NW + 1] = (double)(float)sqrt(var);
+            }
+            __syncthreads();
+            adv_mean = (float)red[2 * MLP_NW];
+            adv_sd = (float)red[2 * MLP_NW + 1] + 1e-8f;
+        } else if (do_pi) {
+            adv_mean = a.advstat[0];
+            adv_sd = a.advstat[1] + 1e-8f;
+        }
     }
     __syncthreads();
 
+    // per-sample scalars of the loss (P3b) are fetched NOW: their latency hides behind the two forward layers
+    constexpr int LPS = MLP_NT / 32;                         // lanes per sample in P3b: 16 | 8
+    const int ls_s = tid / LPS, ls_q = tid % LPS;
+    const long ls_r = row_s[ls_s];
+    float pf_R = 0.f, pf_oldv = 0.f, pf_oldnlp = 0.f, pf_x[2] = {0.f, 0.f}, pf_ls[2] = {0.f, 0.f};
+    int pf_act = 0;
+    if (ls_r >= 0) {
+        pf_R = a.returns[ls_r]; pf_oldv = a.values[ls_r]; pf_oldnlp = a.neglogp[ls_r];
+        if (do_pi) {
+            if (a.pd_kind == MRL_PD_CATEGORICAL) {
+                pf_act = static_cast<const int32_t*>(a.actions)[ls_r];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = ls_q + u * LPS;
+                    if (k < nact) {
+                        pf_x[u] = static_cast<const float*>(a.actions)[ls_r * nact + k];
+                        pf_ls[u] = P[a.logstd + k];
+                    }
+                }
+            }
+        }
+    }
     stamp(1);
-    // ---- P1: fc0 forward.  wave -> (k half, net, 32-column tile); nets == 1: waves 2, 3, 6, 7 idle
+    // ---- P1: fc0 forward.  wave -> (k range, net, 32-column tile): the 2 * nets output tiles are shared out over the waves,
+    //      KS = waves / (2 nets) of them splitting the k range of one tile (8 waves: 2 ranges for two nets, 4 for one)
     {
-        const int wq = wave & 3, khalf = wave >> 2;
-        const int net = wq >> 1, n0 = (wq & 1) * 32;
-        if (net < nets) {
-            const float* W = P + W0(net);
+        const int NTL = p1_NTL, KS = p1_KS, wq = p1_wq, khalf = p1_kr, net = p1_net, n0 = p1_n0, gb = p1_gb, NG = p1_NG;
+        {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* arow = obs_s + i * KP + 4 * h;
-            const float* wcol = W + n0 + i;
-            // B fragments come straight from L2: issue the 16 loads of the NEXT group of 4 k-blocks before the
-            // 16 MFMAs of the current one (unconditional loads with a clamped row, zeroed by select)
-            auto loadg = [&](int g, float (&dst)[16]) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int k = 8 * (4 * g + u) + 4 * h + q;
-                        const float w = wcol[(long)min(k, K0 - 1) * MLP_NH];
-                        dst[4 * u + q] = k < K0 ? w : 0.f;
-                    }
-            };
             auto mmag = [&](int g, const float (&fbv)[16]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -227,35 +308,37 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
                     }
                 }
             };
-            // groups of 4 k blocks: [0, NGH) for the first wave group, [NGH, NGT) for the second
-            const int NGT = (KB0 + 3) / 4, NGH = MLP_NW > 4 ? (NGT + 1) / 2 : NGT;
-            const int gb = khalf ? NGH : 0, NG = khalf ? NGT : NGH;
-            float fb0[16], fb1[16];
-            if (gb < NG) loadg(gb, fb0);
-            for (int g = gb; g < NG; g += 2) {
-                if (g + 1 < NG) loadg(g + 1, fb1);
-                mmag(g, fb0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g + 2 < NG) loadg(g + 2, fb0);
-                if (g + 1 < NG) mmag(g + 1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
+            if (p1_pre) {
+                if (gb < NG) mmag(gb, fb0);
+                if (gb + 1 < NG) mmag(gb + 1, fb1);
+                if (gb + 2 < NG) mmag(gb + 2, fb2);
+            } else {
+                // long k range: the 16 loads of the NEXT group of 4 k-blocks are issued before the 16 MFMAs of the current one
+                if (gb < NG) loadg(gb, fb0);
+                for (int g = gb; g < NG; g += 2) {
+                    if (g + 1 < NG) loadg(g + 1, fb1);
+                    mmag(g, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 2 < NG) loadg(g + 2, fb0);
+                    if (g + 1 < NG) mmag(g + 1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (khalf) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) kp_s[(wq * 16 + r) * 64 + lane] = acc[r];
+                for (int r = 0; r < 16; ++r) kp_s[(((khalf - 1) * NTL + wq) * 16 + r) * 64 + lane] = acc[r];
             }
-            __syncthreads();                                     // (waves of the same net: both halves arrive here)
+            __syncthreads();                                     // (every wave arrives here)
             if (!khalf) {
                 const float bias = P[B0(net) + n0 + i];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float part = MLP_NW > 4 ? kp_s[(wq * 16 + r) * 64 + lane] : 0.f;
-                    h0_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(MLP_NW > 4 ? (acc[r] + part) + bias : acc[r] + bias);
+                    float v = acc[r];
+                    for (int q = 1; q < KS; ++q) v += kp_s[(((q - 1) * NTL + wq) * 16 + r) * 64 + lane];     // fixed order
+                    h0_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(v + bias);
                 }
             }
-        } else {
-            __syncthreads();
         }
     }
     __syncthreads();
@@ -263,9 +346,8 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     stamp(2);
     // ---- P2: fc1 forward (K = 64: 32 MFMAs per tile, the first four waves)
     {
-        const int net = wave >> 1, n0 = (wave & 1) * 32;
-        if (wave < 4 && net < nets) {
-            const float* W = P + W1(net);
+        const int net = p2_net, n0 = p2_n0;
+        if (p2_on) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -273,14 +355,10 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
 #pragma unroll
             for (int kb = 0; kb < MLP_NH / 8; ++kb) {
                 const float4 fa = *reinterpret_cast<const float4*>(arow + 8 * kb);
-                const int k = 8 * kb + 4 * h;
-                float fb[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) fb[q] = W[(k + q) * MLP_NH + n0 + i];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, w1f[4 * kb + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, w1f[4 * kb + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, w1f[4 * kb + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, w1f[4 * kb + 3], acc, 0, 0, 0);
             }
             const float bias = P[B1(net) + n0 + i];
 #pragma unroll
@@ -295,9 +373,10 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     stamp(3);
     // ---- P3a: pdparam (mean / logits) and value, same fmaf order as heads_train_kernel
     const float* lat = h1_s;                                 // policy latent
-    const float* vlat = shared ? h1_s : h1_s + 32 * MLP_LD;  // value latent
+    const float* vlat = (shared || sl) ? h1_s : h1_s + 32 * MLP_LD;  // value latent (sliced: this workgroup's only net)
     for (int q = tid; q < 32 * (nact + 1); q += MLP_NT) {
         const int s = q / (nact + 1), j = q - s * (nact + 1);
+        if (j < nact ? !do_pi : !do_vf) continue;
         if (j < nact) {
             float acc = 0.f;
             const float* x = lat + s * MLP_LD;
@@ -312,70 +391,89 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     }
     __syncthreads();
 
-    // ---- P3b: per-sample loss and closed-form gradients (ppo2/model.py:57-91)
-    if (tid < 32) {
-        const int s = tid;
-        const long r = row_s[s];
+    // ---- P3b: per-sample loss and closed-form gradients (ppo2/model.py:57-91).  MLP_NT / 32 consecutive
+    //      lanes share a sample and split its action dimensions (round 3; one lane per sample walked 2 x nact exp / divide
+    //      chains: 8 of the step's 53 us); sums over the action dimensions are butterfly sums inside the lane group.
+    {
+        const int s = ls_s, q = ls_q;
+        const long r = ls_r;
         double st[5] = {0, 0, 0, 0, 0};
         float* pi = pi_s + s * 32;
         float* dpi = dpi_s + s * 32;
         float* dls = dls_s + s * 32;
+        auto gsum = [&](float v) {
+#pragma unroll
+            for (int off = LPS / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPS);
+            return v;
+        };
+        auto gmax = [&](float v) {
+#pragma unroll
+            for (int off = LPS / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, LPS));
+            return v;
+        };
         if (r >= 0) {
             const float mean = adv_mean, sd = adv_sd;
             const float eps = a.cliprange, ce = a.ent_coef * a.invB;
-            const float R = a.returns[r], oldv = a.values[r], oldnlp = a.neglogp[r];
+            const float R = pf_R, oldv = pf_oldv, oldnlp = pf_oldnlp;
             const float adv = ((R - oldv) - mean) / sd;
-            float nlp, H;
-            if (a.pd_kind == MRL_PD_CATEGORICAL) {
-                const int act = static_cast<const int32_t*>(a.actions)[r];
-                float mx = pi[0];
-                for (int j = 1; j < nact; ++j) mx = fmaxf(mx, pi[j]);
+            float H = 0.f;
+            if (!do_pi) {
+                // value workgroup of a sliced launch
+            } else if (a.pd_kind == MRL_PD_CATEGORICAL) {
+                const int act = pf_act;
+                float mx = -INFINITY;
+                for (int j = q; j < nact; j += LPS) mx = fmaxf(mx, pi[j]);
+                mx = gmax(mx);
                 float z0 = 0.f;
-                for (int j = 0; j < nact; ++j) z0 += expf(pi[j] - mx);
+                for (int j = q; j < nact; j += LPS) z0 += expf(pi[j] - mx);
+                z0 = gsum(z0);
                 const float logz = logf(z0);
-                nlp = logz - (pi[act] - mx);
-                H = 0.f;
-                for (int j = 0; j < nact; ++j) {
-                    float a0 = pi[j] - mx;
+                const float nlp = logz - (pi[act] - mx);
+                for (int j = q; j < nact; j += LPS) {
+                    const float a0 = pi[j] - mx;
                     H += (expf(a0) / z0) * (logz - a0);
                 }
+                H = gsum(H);
                 const float ratio = expf(oldnlp - nlp);
                 const float pg1 = -adv * ratio;
                 const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
                 const float pg2 = -adv * rc;
-                float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+                const float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
                 const float dnlp = dr * (-ratio) * a.invB;
-                for (int j = 0; j < nact; ++j) {
-                    float a0 = pi[j] - mx;
-                    float p = expf(a0) / z0;
-                    float logp = a0 - logz;
+                for (int j = q; j < nact; j += LPS) {
+                    const float a0 = pi[j] - mx;
+                    const float p = expf(a0) / z0;
+                    const float logp = a0 - logz;
                     dpi[j] = dnlp * (p - (j == act ? 1.f : 0.f)) + ce * p * (logp + H);
                 }
                 st[0] = (double)fmaxf(pg1, pg2);
                 st[3] = 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
                 st[4] = (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
             } else {
+                // nact <= 32 <= 2 LPS when LPS = 16; the 8-lane form walks up to 4 dimensions per lane (the last two re-read)
                 const float* x = static_cast<const float*>(a.actions) + r * nact;
                 const float* logstd = P + a.logstd;
+                auto xk = [&](int k) { const int u = (k - q) / LPS; return u < 2 ? pf_x[u & 1] : x[k]; };
+                auto lsk = [&](int k) { const int u = (k - q) / LPS; return u < 2 ? pf_ls[u & 1] : logstd[k]; };
                 float ssum = 0.f, lsum = 0.f;
-                H = 0.f;
-                for (int k = 0; k < nact; ++k) {
-                    float ls = logstd[k];
-                    float u = (x[k] - pi[k]) / expf(ls);
+                for (int k = q; k < nact; k += LPS) {
+                    const float ls = lsk(k);
+                    const float u = (xk(k) - pi[k]) / expf(ls);
                     ssum += u * u;
                     lsum += ls;
                     H += ls + MRL_MLP_HALF_LOG_2PIE;
                 }
-                nlp = 0.5f * ssum + MRL_MLP_HALF_LOG_2PI * (float)nact + lsum;
+                ssum = gsum(ssum); lsum = gsum(lsum); H = gsum(H);
+                const float nlp = 0.5f * ssum + MRL_MLP_HALF_LOG_2PI * (float)nact + lsum;
                 const float ratio = expf(oldnlp - nlp);
                 const float pg1 = -adv * ratio;
                 const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
                 const float pg2 = -adv * rc;
-                float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+                const float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
                 const float dnlp = dr * (-ratio) * a.invB;
-                for (int k = 0; k < nact; ++k) {
-                    float sdk = expf(logstd[k]);
-                    float u = (x[k] - pi[k]) / sdk;
+                for (int k = q; k < nact; k += LPS) {
+                    const float sdk = expf(lsk(k));
+                    const float u = (xk(k) - pi[k]) / sdk;
                     dpi[k] = dnlp * (-(u / sdk));
                     dls[k] = dnlp * (1.f - u * u) - ce;
                 }
@@ -383,24 +481,35 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
                 st[3] = 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
                 st[4] = (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
             }
-            const float v = v_s[s];
-            const float dvc = fminf(fmaxf(v - oldv, -eps), eps);
-            const float vclip = oldv + dvc;
-            const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
-            float dl = (l1 >= l2) ? (v - R) : ((v - oldv >= -eps && v - oldv <= eps) ? (vclip - R) : 0.f);
-            dv_s[s] = a.vf_coef * a.invB * dl;
-            st[1] = 0.5 * (double)fmaxf(l1, l2);
+            if (do_vf && q == 0) {
+                const float v = v_s[s];
+                const float dvc = fminf(fmaxf(v - oldv, -eps), eps);
+                const float vclip = oldv + dvc;
+                const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+                const float dl = (l1 >= l2) ? (v - R) : ((v - oldv >= -eps && v - oldv <= eps) ? (vclip - R) : 0.f);
+                dv_s[s] = a.vf_coef * a.invB * dl;
+                st[1] = 0.5 * (double)fmaxf(l1, l2);
+            }
             st[2] = (double)H;
         } else {                                    // beyond the minibatch: no contribution
-            for (int j = 0; j < nact; ++j) { dpi[j] = 0.f; dls[j] = 0.f; }
-            dv_s[s] = 0.f;
+            for (int j = q; j < nact; j += LPS) { dpi[j] = 0.f; dls[j] = 0.f; }
+            if (q == 0) dv_s[s] = 0.f;
         }
-        // sum the 32 samples of the tile in lane order (fixed)
+        // the tile's 32 samples are summed in sample order by the first 32 lanes (fixed); a sliced workgroup writes the
+        // statistics of its own part of the loss
+        double* st_s = reinterpret_cast<double*>(kp_s);      // [32][5]; kp_s is free since the end of P1
+        if (q == 0) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            double t = st[j];
-            for (int off = 16; off > 0; off >>= 1) t += __shfl_down(t, off, 32);
-            if (s == 0) a.spart[(long)blockIdx.x * 5 + j] = t;
+            for (int j = 0; j < 5; ++j) st_s[s * 5 + j] = st[j];
+        }
+        __syncthreads();
+        if (tid < 32) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                double t = st_s[tid * 5 + j];
+                for (int off = 16; off > 0; off >>= 1) t += __shfl_down(t, off, 32);
+                if (tid == 0 && (j == 1 ? do_vf : do_pi)) a.spart[(long)tile * 5 + j] = t;
+            }
         }
     }
     __syncthreads();
@@ -408,7 +517,7 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     stamp(4);
     // ---- P4: head parameter gradients (slab) + dz of the last hidden layer (LDS)
     {
-        const int HPn = 64 * nact + nact;            // pi/w, pi/b
+        const int HPn = do_pi ? 64 * nact + nact : 0;            // pi/w, pi/b
         for (int e = tid; e < HPn; e += MLP_NT) {
             float g = 0.f;
             if (e < 64 * nact) {
@@ -421,13 +530,13 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
                 slab[a.bpi + j] = g;
             }
         }
-        if (a.logstd >= 0)
+        if (a.logstd >= 0 && do_pi)
             for (int j = tid; j < nact; j += MLP_NT) {
                 float g = 0.f;
                 for (int s = 0; s < 32; ++s) g += dls_s[s * 32 + j];
                 slab[a.logstd + j] = g;
             }
-        for (int k = tid; k < 65; k += MLP_NT) {
+        for (int k = tid; k < (do_vf ? 65 : 0); k += MLP_NT) {
             float g = 0.f;
             if (k < 64) {
                 for (int s = 0; s < 32; ++s) g = fmaf(vlat[s * MLP_LD + k], dv_s[s], g);
@@ -439,16 +548,18 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
         }
         for (int q = tid; q < 32 * 64; q += MLP_NT) {
             const int s = q >> 6, k = q & 63;
-            float g = 0.f;
-            const float* w = wpi_s + k * nact;
-            const float* d = dpi_s + s * 32;
-            for (int j = 0; j < nact; ++j) g = fmaf(d[j], w[j], g);
-            if (shared) g = fmaf(dv_s[s], wvf_s[k], g);
-            const float hv = lat[s * MLP_LD + k];
-            dz1_s[s * MLP_LD + k] = g * (1.f - hv * hv);
-            if (!shared) {
+            if (do_pi) {
+                float g = 0.f;
+                const float* w = wpi_s + k * nact;
+                const float* d = dpi_s + s * 32;
+                for (int j = 0; j < nact; ++j) g = fmaf(d[j], w[j], g);
+                if (shared) g = fmaf(dv_s[s], wvf_s[k], g);
+                const float hv = lat[s * MLP_LD + k];
+                dz1_s[s * MLP_LD + k] = g * (1.f - hv * hv);
+            }
+            if (!shared && do_vf) {                          // the value net's rows: local net 1, or 0 in a sliced workgroup
                 const float hvv = vlat[s * MLP_LD + k];
-                dz1_s[(32 + s) * MLP_LD + k] = dv_s[s] * wvf_s[k] * (1.f - hvv * hvv);
+                dz1_s[((sl ? 0 : 32) + s) * MLP_LD + k] = dv_s[s] * wvf_s[k] * (1.f - hvv * hvv);
             }
         }
     }
@@ -557,10 +668,11 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     stamp(7);
 }
 
+// nets = nets carried by ONE workgroup (1 in a sliced launch)
 inline size_t mlp_step_lds_bytes(int K0, int nets) {
     const int KP = (K0 + 7) / 8 * 8 + 4;
     size_t floats = (size_t)32 * KP + (size_t)4 * nets * 32 * MLP_LD + 3 * 32 * 32 + 64 + 64 * 32 + 64;
-    return floats * 4 + 32 * sizeof(long) + (size_t)4 * 16 * 64 * sizeof(float) + 64;
+    return floats * 4 + 32 * sizeof(long) + (size_t)(8 - 2 * nets) * 16 * 64 * sizeof(float) + 64;
 }
 
 }  // namespace mrl

@@ -370,6 +370,7 @@ static const OptionDef kOptions[] = {
     {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 2},
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 2}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
+    {"mlp_slice", "MRL_MLP_SLICE", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -2223,9 +2224,13 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         {   // MRL_MLP_DBG=1: phase timestamps of workgroup 0 land in the last 64 bytes of the zero page
             const int dbgon = dbg_option("mlp_dbg", "MRL_MLP_DBG");
             a.dbg = dbgon ? reinterpret_cast<long long*>(ws.zeros) + 64 : nullptr;
+            a.dbg_block = dbgon - 1;                    // MRL_MLP_DBG = 1 + the workgroup to stamp
         }
-        const size_t lds = mlp_step_lds_bytes(K0, nets);
         const int waves8 = get_option("mlp_waves", "MRL_MLP_WAVES", 8) >= 8;      // 8 waves per workgroup (4: the round-2 form)
+        // separate policy / value nets: one workgroup per (tile, net) -- half the serial chain, twice the workgroups
+        a.slice = (nets == 2 && get_option("mlp_slice", "MRL_MLP_SLICE", 1)) ? 1 : 0;
+        const int nwg = ntiles * (a.slice ? 2 : 1);
+        const size_t lds = mlp_step_lds_bytes(K0, a.slice ? 1 : nets);
         static bool raised = false;
         if (!raised) {
             MRL_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_step_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2237,8 +2242,8 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
             double fl = 0.0;
             for (int n = 0; n < nets; ++n) fl += 2.0 * B * ((double)K0 * 64 * 2 + 64.0 * 64 * 3);
             ProfScope ps("mlp_step", fl, 0.0, st);
-            if (waves8) hipLaunchKernelGGL(mlp_step_kernel<512>, dim3(ntiles), dim3(512), lds, st, a);
-            else hipLaunchKernelGGL(mlp_step_kernel<256>, dim3(ntiles), dim3(256), lds, st, a);
+            if (waves8) hipLaunchKernelGGL(mlp_step_kernel<512>, dim3(nwg), dim3(512), lds, st, a);
+            else hipLaunchKernelGGL(mlp_step_kernel<256>, dim3(nwg), dim3(256), lds, st, a);
         }
         MRL_LAUNCH_CHECK();
         int rc = reduce_slabs(ws.part, m->P, ntiles, grads_out, m->P, 0, st, &ctx, spart, ntiles, invB, stats_out);

@@ -92,6 +92,7 @@ class Model(object):
         self._train_calls = 0
         self._fast = None
         self._epoch_graph = None
+        self._rings = {}                                  # pinned staging rings of the asynchronous uploads (_upload)
         # ---- multi-rank: total weight (mpi_adam_optimizer.py:25-27), sync_from_root (model.py:129-131) ----
         self.total_weight = 1.0
         if self.comm is not None and self.comm.Get_size() > 1:
@@ -275,6 +276,35 @@ class Model(object):
         self._train_calls += 1
         return stats
 
+    # ------------------------------------------------------------------ asynchronous host -> device uploads
+    def _upload(self, host_array, key, slots=4):
+        """Copy a host array to the device WITHOUT blocking the host: through a ring of pinned staging buffers, each guarded
+        by an event (a slot is reused only after the copy that read it has run), into a ring of device buffers.
+        A pageable `tensor.to(device)` makes the host wait for everything queued before it -- with one launch graph per epoch
+        that left the GPU idle between epochs while the next permutation was drawn and shipped (0.5 ms of every 2.7 ms in the
+        MuJoCo-shaped configuration).  The returned tensor is valid until `slots` further uploads with the same key."""
+        a = np.ascontiguousarray(host_array)
+        ring = self._rings.get(key)
+        if ring is None or ring['shape'] != a.shape or ring['dtype'] != a.dtype:
+            tdt = torch.from_numpy(a[:0].copy()).dtype
+            ring = self._rings[key] = dict(
+                shape=a.shape, dtype=a.dtype, n=0,
+                host=[torch.empty(a.shape, dtype=tdt).pin_memory() for _ in range(slots)],
+                dev=[torch.empty(a.shape, dtype=tdt, device=self.device) for _ in range(slots)],
+                ev=[torch.cuda.Event() for _ in range(slots)])
+        k = ring['n'] % len(ring['host'])
+        ring['n'] += 1
+        if ring['n'] > len(ring['host']):
+            ring['ev'][k].synchronize()
+        ring['host'][k].numpy()[...] = a
+        ring['dev'][k].copy_(ring['host'][k], non_blocking=True)
+        ring['ev'][k].record()
+        return ring['dev'][k]
+
+    def indices_to_device(self, inds):
+        """an epoch's permutation (or a minibatch's index list) as a device tensor, uploaded asynchronously"""
+        return self._upload(np.asarray(inds, dtype=np.int64), 'inds')
+
     # ------------------------------------------------------------------ one epoch as a replayable launch graph
     def _next_alpha(self, lr):
         """TF-1 Adam step size for the next step + the beta-power update (host f32 arithmetic, model.py:98-100)"""
@@ -315,7 +345,7 @@ class Model(object):
                 torch.cuda.synchronize()
                 return self.train_epoch(lr, cliprange, rollout, inds_dev)
         g['idx'].copy_(inds_dev.view(M, B))
-        g['alpha'].copy_(torch.from_numpy(np.array([self._next_alpha(lr) for _ in range(M)], dtype=np.float32)))
+        g['alpha'].copy_(self._upload(np.array([self._next_alpha(lr) for _ in range(M)], dtype=np.float32), 'alpha'))
         g['graph'].replay()
         return g['stats'].clone()
 

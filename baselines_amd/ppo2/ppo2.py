@@ -158,7 +158,10 @@ def learn(*, network, env, total_timesteps, eval_env=None, seed=None, nsteps=204
         for _ in range(noptepochs if states is None else 0):
             np.random.shuffle(inds)
             if fast:
-                inds_dev = torch.from_numpy(inds).to(model.device)
+                # (asynchronous upload where the model offers one: the host goes on to draw the next permutation while the
+                # device is still working through this epoch)
+                inds_dev = (model.indices_to_device(inds) if hasattr(model, 'indices_to_device')
+                            else torch.from_numpy(inds).to(model.device))
                 if hasattr(model, 'train_epoch'):           # one replayable launch graph per epoch where that pays
                     step_stats.extend(model.train_epoch(lrnow, cliprangenow, runner.rollout, inds_dev).unbind(0))
                 else:

@@ -332,7 +332,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
             return torch.stack(stats).mean(dim=0)
         for _ in range(hp['noptepochs']):
             np.random.shuffle(inds)
-            inds_dev = torch.from_numpy(inds).to(model.device)
+            inds_dev = model.indices_to_device(inds)          # asynchronous upload, as in ppo2.learn
             stats.extend(model.train_epoch(hp['lr'], hp['cliprange'], ro, inds_dev).unbind(0))
         return torch.stack(stats).mean(dim=0)
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
-"""Phase timestamps (s_memtime) of workgroup 0 of the fused MLP step kernel.  MRL_MLP_DBG=1 python scripts/mlp_phases.py"""
+"""Phase timestamps (shader clock) of one workgroup of the fused MLP step kernel (experiment builds, -DMRL_X6_EXPERIMENTS).
+MRL_MLP_DBG=<1 + workgroup> python scripts/mlp_phases.py      (sliced launches: even workgroups carry the policy net)"""
 import os
 import sys
-os.environ['MRL_MLP_DBG'] = '1'
+os.environ.setdefault('MRL_MLP_DBG', '1')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa
@@ -32,7 +33,8 @@ ws = model.dm.workspace
 stamps = ws[-2048 + 512:-2048 + 512 + 64].view(torch.int64).cpu().numpy()
 d = np.diff(stamps)
 names = ['P0 gather', 'P1 fc0 fwd', 'P2 fc1 fwd', 'P3 heads+loss', 'P4 head grads/dz1', 'P5 fc1 bwd', 'P6 fc0 wgrad']
-# s_memtime ticks at 100 MHz on gfx9 (constant-rate counter); report ticks and microseconds
+# the stamps are shader-clock cycles (s_memtime via __builtin_readcyclecounter): ~2.4 GHz when nothing else loads the chip
 for n, x in zip(names, d):
-    print('%-20s %8d ticks  %7.2f us' % (n, x, x / 100.0))
-print('total %d ticks = %.2f us' % (stamps[-1] - stamps[0], (stamps[-1] - stamps[0]) / 100.0))
+    print('%-20s %8d cycles  %6.2f us at 2.4 GHz' % (n, x, x / 2400.0))
+print('workgroup %d: total %d cycles = %.2f us at 2.4 GHz' % (int(os.environ['MRL_MLP_DBG']) - 1, stamps[-1] - stamps[0],
+                                                          (stamps[-1] - stamps[0]) / 2400.0))

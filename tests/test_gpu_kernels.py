@@ -314,7 +314,7 @@ def test_engine_options_agree():
         return g.cpu().numpy(), st.cpu().numpy()
 
     names = ['u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'tr_epilogue',
-             'wgrad_tr', 'x6_pg']
+             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves']
     # builds with -DMRL_X6_EXPERIMENTS also carry the measured-and-dropped variants (plane tensors, separate load phase)
     experiments = True
     try:
@@ -335,6 +335,8 @@ def test_engine_options_agree():
         small = [(cnn, 160, 'u8_bf16x3', 1), (cnn, 161, 'c1_lds', 1), (cnn, 163, 'c1_wgrad2', 1), (cnn, 165, 'tr_epilogue', 1),
                  (cnn, 168, 'x6_pg', 8),
                  (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused', 1),
+                 (('mlp', (376,), np.float32, 'gaussian', 17, True), 203, 'mlp_slice', 1),       # (tile, net) workgroups vs one per tile
+                 (('mlp', (12,), np.float32, 'categorical', 5, True), 97, 'mlp_slice', 1),
                  (('mlp', (4,), np.float32, 'categorical', 2, False), 96, 'mlp_fused', 1)]
         if experiments:
             small += [(cnn, 32, 'act_planes', 79), (cnn, 166, 'act_planes', 28), (cnn, 167, 'x6_il', 1)]
