@@ -80,6 +80,8 @@ SIGNATURES = {
     'mrl_qnet_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_qnet_td_grad': (c_int, [c_void_p] * 9 + [c_float, c_int, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    'mrl_advstat_minibatches': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'mrl_model_set_advstat': (c_int, [c_void_p, c_void_p]),
     'mrl_qnet_policy_kl': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'mrl_qnet_adam_step': (c_int, [c_void_p] * 5 + [c_float, c_void_p] + [c_float] * 4 + [c_void_p, c_size_t, c_int, c_void_p]),
     'mrl_synth_env_obs': (c_int, [ctypes.c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

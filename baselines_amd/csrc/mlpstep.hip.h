@@ -145,8 +145,10 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
         if (p1_gb + 1 < p1_NG) loadg(p1_gb + 1, fb1);
         if (p1_gb + 2 < p1_NG) loadg(p1_gb + 2, fb2);
     }
+    const float p1_bias = p1_kr == 0 ? P[B0(p1_net) + p1_n0 + i] : 0.f;
     const int p2_net = wave >> 1, p2_n0 = (wave & 1) * 32;
     const bool p2_on = wave < 4 && p2_net < nets;
+    const float p2_bias = p2_on ? P[B1(p2_net) + p2_n0 + i] : 0.f;
     float w1f[32];                                                   // fc1 weight fragments of this wave's output tile
     if (p2_on) {
         const float* W = P + W1(p2_net);
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
             }
             __syncthreads();                                     // (every wave arrives here)
             if (!khalf) {
-                const float bias = P[B0(net) + n0 + i];
+                const float bias = p1_bias;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, w1f[4 * kb + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, w1f[4 * kb + 3], acc, 0, 0, 0);
             }
-            const float bias = P[B1(net) + n0 + i];
+            const float bias = p2_bias;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -377,16 +379,17 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     for (int q = tid; q < 32 * (nact + 1); q += MLP_NT) {
         const int s = q / (nact + 1), j = q - s * (nact + 1);
         if (j < nact ? !do_pi : !do_vf) continue;
+        const float hb = P[j < nact ? a.bpi + j : a.bvf];       // head bias: requested before the dot product, used after it
         if (j < nact) {
             float acc = 0.f;
             const float* x = lat + s * MLP_LD;
             for (int k = 0; k < MLP_NH; ++k) acc = fmaf(x[k], wpi_s[k * nact + j], acc);
-            pi_s[s * 32 + j] = acc + P[a.bpi + j];
+            pi_s[s * 32 + j] = acc + hb;
         } else {
             float acc = 0.f;
             const float* x = vlat + s * MLP_LD;
             for (int k = 0; k < MLP_NH; ++k) acc = fmaf(x[k], wvf_s[k], acc);
-            v_s[s] = acc + P[a.bvf];
+            v_s[s] = acc + hb;
         }
     }
     __syncthreads();
@@ -669,6 +672,52 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
 }
 
 // nets = nets carried by ONE workgroup (1 in a sliced launch)
+// The advantage statistics of `gridDim.x` minibatches (idx [gridDim.x][B] env-major indices) in ONE launch: out[mb] = (mean,
+// std) of returns - values over the minibatch -- exactly the sums, in exactly the order, every policy workgroup of
+// mlp_step_kernel<NT> otherwise takes for itself (thread-strided batches of 8, f64 accumulation, mlp_block_sum), so a step fed
+// from here is bit-identical to one that computes them on its own.  One launch per epoch instead of 128 redundant gathers
+// of 4096 samples in front of every step (13 of the step kernel's 48 us).
+template <int NT>
+__global__ __launch_bounds__(NT) void mlp_advstat_kernel(const float* __restrict__ ret, const float* __restrict__ val,
+                                                         const int64_t* __restrict__ idx, int B, int T, int N,
+                                                         float* __restrict__ out) {
+    constexpr int NW = NT / 64;
+    __shared__ double red[2 * NW + 2];
+    const int tid = threadIdx.x;
+    const int64_t* my = idx + (long)blockIdx.x * B;
+    double s1 = 0.0, s2 = 0.0;
+    const int nsb = (B + 8 * NT - 1) / (8 * NT);
+    for (int it = 0; it < nsb; ++it) {
+        const int b0 = tid + it * 8 * NT;
+        long sr[8];
+        float rv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sr[u] = (long)my[min(b0 + u * NT, B - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            sr[u] = envmajor_to_row(sr[u], T, N);
+            rv[u] = ret[sr[u]];
+            vv[u] = val[sr[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (b0 + u * NT < B) {
+                const float x = __fsub_rn(rv[u], vv[u]);
+                s1 += (double)x;
+                s2 += (double)x * (double)x;
+            }
+    }
+    const double t1 = mlp_block_sum<NW>(s1, red);
+    const double t2 = mlp_block_sum<NW>(s2, red + NW);
+    if (tid == 0) {
+        const double mean = t1 / B;
+        double var = t2 / B - mean * mean;
+        if (var < 0) var = 0;
+        out[2 * blockIdx.x] = (float)mean;
+        out[2 * blockIdx.x + 1] = (float)sqrt(var);
+    }
+}
+
 inline size_t mlp_step_lds_bytes(int K0, int nets) {
     const int KP = (K0 + 7) / 8 * 8 + 4;
     size_t floats = (size_t)32 * KP + (size_t)4 * nets * 32 * MLP_LD + 3 * 32 * 32 + 64 + 64 * 32 + 64;

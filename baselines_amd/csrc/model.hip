@@ -93,6 +93,7 @@ struct mrl_model {
     std::vector<TensorInfo> tensors;
     mrl_comm* comm = nullptr;              // data-parallel communicator (mrl_model_attach_comm); not owned
     float rank_weight = 1.f;               // mpi_adam_optimizer.py:21 `flat_grad * mpi_rank_weight`
+    const float* ext_advstat = nullptr;    // precomputed minibatch advantage statistics (mrl_model_set_advstat); not owned
 };
 
 static long add_tensor(mrl_model* m, const std::string& name, std::vector<int> shape, double scale) {
@@ -2216,7 +2217,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         a.wpi = m->pi_w; a.bpi = m->pi_b; a.logstd = m->logstd; a.wvf = m->vf_w; a.bvf = m->vf_b;
         a.K0 = K0; a.nact = d.nact; a.nets = nets; a.pd_kind = d.pd_kind; a.P = m->P;
         a.params = params; a.obs = (const float*)obs; a.actions = actions; a.returns = returns; a.values = values;
-        a.neglogp = neglogpacs; a.advstat = nullptr; a.cliprange = cliprange; a.ent_coef = ent_coef;
+        a.neglogp = neglogpacs; a.advstat = m->ext_advstat; a.cliprange = cliprange; a.ent_coef = ent_coef;
         a.vf_coef = vf_coef; a.invB = invB; a.B = B; a.part = ws.part; a.spart = spart;
         a.stat_ret = stat_ret; a.stat_val = stat_val; a.stat_idx = stat_idx; a.Bstat = Bstat; a.T = T; a.N = N;
         a.tile_idx = idx;                               // already advanced to the slice (nullptr: direct rows)
@@ -2357,6 +2358,24 @@ extern "C" int mrl_model_grad_micro(const mrl_model* m, const float* params, con
 }
 
 // ---- data-parallel attachment --- common/mpi_adam_optimizer.py:18-51 -----------------------------------------------
+extern "C" int mrl_advstat_minibatches(const float* returns, const float* values, const int64_t* idx, int nmb, int B, int T,
+                                       int N, float* out, void* stream) {
+    if (!returns || !values || !idx || !out || nmb <= 0 || B <= 0 || T <= 0 || N <= 0) return MRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // the thread count of the fused step kernel in effect: the partial sums must be the ones its workgroups would form
+    if (get_option("mlp_waves", "MRL_MLP_WAVES", 8) >= 8)
+        hipLaunchKernelGGL(mlp_advstat_kernel<512>, dim3(nmb), dim3(512), 0, st, returns, values, idx, B, T, N, out);
+    else
+        hipLaunchKernelGGL(mlp_advstat_kernel<256>, dim3(nmb), dim3(256), 0, st, returns, values, idx, B, T, N, out);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mrl_model_set_advstat(mrl_model* m, const float* advstat) {
+    if (!m) return MRL_EINVAL;
+    m->ext_advstat = advstat;
+    return 0;
+}
+
 extern "C" int mrl_model_attach_comm(mrl_model* m, mrl_comm* comm, float rank_weight) {
     if (!m || rank_weight <= 0.f) return MRL_EINVAL;
     m->comm = comm;

@@ -354,13 +354,29 @@ class Model(object):
         idx = torch.zeros((M, B), dtype=torch.int64, device=self.device)
         alpha = torch.zeros(M, dtype=torch.float32, device=self.device)
         stats = torch.zeros((M, 5), dtype=st_dtype, device=self.device)
+        adv = torch.zeros((M, 2), dtype=torch.float32, device=self.device)     # (mean, std) of every minibatch of the epoch
         mgn = -1.0 if self.max_grad_norm is None else float(self.max_grad_norm)
         P = self.params.numel()
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        try:
+            return self._capture_epoch_into(graph, key, cliprange, rollout, M, B, idx, alpha, stats, adv, mgn)
+        finally:
+            lib.mrl_model_set_advstat(self.dm.handle, None)
+
+    def _capture_epoch_into(self, graph, key, cliprange, rollout, M, B, idx, alpha, stats, adv, mgn):
+        lib = _lib.load()
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             st = _lib.stream_ptr()                         # the capturing stream
+            # the epoch's permutation is known up front: the advantage statistics (model.py:136-139) of all its minibatches
+            # in ONE launch, instead of every workgroup of every fused step gathering its whole minibatch again
+            fused = self.dm.network == 'mlp' and _lib.get_option('mlp_fused')
+            if fused:
+                _lib.check(lib.mrl_advstat_minibatches(_lib.ptr(rollout.returns), _lib.ptr(rollout.values), _lib.ptr(idx), M, B,
+                                                       int(rollout.T), int(rollout.N), _lib.ptr(adv), st), 'mrl_advstat_minibatches')
             for k in range(M):
+                if fused:
+                    _lib.check(lib.mrl_model_set_advstat(self.dm.handle, _lib.ptr(adv[k])), 'mrl_model_set_advstat')
                 _lib.check(lib.mrl_model_train_step(
                     self.dm.handle, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
                     _lib.ptr(rollout.obs), _lib.ptr(rollout.actions), _lib.ptr(rollout.returns), _lib.ptr(rollout.values),
@@ -368,7 +384,7 @@ class Model(object):
                     self.ent_coef, self.vf_coef, 0.0, _lib.ptr(alpha[k:k + 1]), float(self.beta1), float(self.beta2),
                     float(self.epsilon), mgn, float(self.total_weight), _lib.ptr(stats[k]), _lib.ptr(self._gnorm),
                     _lib.ptr(self.dm.workspace), self.dm.workspace.numel(), self.dm.chunk, st), 'mrl_model_train_step')
-        return dict(key=key, graph=graph, idx=idx, alpha=alpha, stats=stats)
+        return dict(key=key, graph=graph, idx=idx, alpha=alpha, stats=stats, adv=adv)
 
     def _field(self, x, dtype):
         if isinstance(x, torch.Tensor):

@@ -185,6 +185,18 @@ int mrl_model_train_step(const mrl_model* m, float* params, float* grads, float*
                          float beta2, float eps, float max_grad_norm, float total_weight, float* stats_out,
                          float* gnorm_out, void* workspace, size_t workspace_bytes, int chunk, void* stream);
 
+/* ---- minibatch advantage statistics ahead of time --- ppo2/model.py:136-139 for every minibatch of an epoch at once
+ * (ppo2.py:157-166: the epoch's permutation is known before its first step).  idx int64 [nmb][B] env-major indices;
+ * out f32 [nmb][2] = (mean, std) of returns - values over each minibatch, formed exactly like the fused MLP step kernel
+ * forms them in every workgroup (same partial sums, same order: bit-identical).
+ * mrl_model_set_advstat(m, p): while p != NULL the fused MLP step (option "mlp_fused") reads its minibatch statistics
+ * from p[0..1] at launch time instead of gathering the whole minibatch again in each of its workgroups; the other engines
+ * ignore it.  The pointer is read when a gradient / train-step call is issued (or captured into a hipGraph); NULL restores
+ * the default. */
+int mrl_advstat_minibatches(const float* returns, const float* values, const int64_t* idx, int nmb, int B, int T, int N,
+                            float* out, void* stream);
+int mrl_model_set_advstat(mrl_model* m, const float* advstat);
+
 /* ---- C1: data-parallel collectives over RCCL / xGMI --- common/mpi_adam_optimizer.py:18-51
  * (`flat_grad * mpi_rank_weight` -> Allreduce(SUM) -> / total weight), common/mpi_util.py:15-26
  * (sync_from_root).  One communicator per process (= per GPU).  Bootstrap like ncclCommInitRank: rank 0

@@ -385,3 +385,55 @@ def test_engine_options_agree():
     finally:
         for o, v in defaults.items():
             L.set_option(o, v)
+
+
+@pytest.mark.parametrize('waves', [8, 4])
+def test_precomputed_advantage_statistics_feed_the_fused_mlp_step_bit_identically(waves):
+    """mrl_advstat_minibatches + mrl_model_set_advstat (the epoch graphs of Model.train_epoch): the statistics of all
+    minibatches of an epoch in one launch are the (mean, std) of model.py:136-139 and bit-identical to what the fused step's
+    workgroups form for themselves -- the gradient of a step fed from them equals the gradient of a plain step, bit for bit"""
+    from baselines_amd import _lib as L
+    from baselines_amd import ops
+    T, N, M = 8, 96, 4
+    B = T * N // M
+    r = np.random.RandomState(7)
+    old = L.get_option('mlp_waves')
+    L.set_option('mlp_waves', waves)
+    try:
+        dm = ops.DeviceModel(network='mlp', ob_shape=(376,), ob_dtype=np.float32, pd_kind='gaussian', nact=17, value_copy=True,
+                             chunk=B)
+        params = dev((r.randn(dm.P) * 0.05).astype(np.float32))
+        obs, act = dev(r.randn(T * N, 376).astype(np.float32)), dev(r.randn(T * N, 17).astype(np.float32))
+        ret, val_ = r.randn(T * N).astype(np.float32), r.randn(T * N).astype(np.float32)
+        nlp = dev((np.abs(r.randn(T * N)) + 1.0).astype(np.float32))
+        perm = r.permutation(T * N).astype(np.int64).reshape(M, B)                 # env-major indices i = e * T + t
+        idx = dev(perm)
+        adv = torch.zeros((M, 2), dtype=torch.float32, device='cuda')
+        d_ret, d_val = dev(ret), dev(val_)
+        L.check(dm.lib.mrl_advstat_minibatches(L.ptr(d_ret), L.ptr(d_val), L.ptr(idx), M, B, T, N, L.ptr(adv),
+                                               L.stream_ptr()), 'mrl_advstat_minibatches')
+        rows = (perm % T) * N + perm // T                                          # storage rows of the time-major rollout
+        x = (ret[rows] - val_[rows]).astype(np.float64)
+        np.testing.assert_allclose(adv.cpu().numpy()[:, 0], x.mean(axis=1), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(adv.cpu().numpy()[:, 1], x.std(axis=1), rtol=2e-7, atol=0)
+        for k in range(M):
+            g0 = torch.empty(dm.P, dtype=torch.float32, device='cuda')
+            g1 = torch.empty_like(g0)
+            s0, s1 = torch.empty(5, dtype=torch.float32, device='cuda'), torch.empty(5, dtype=torch.float32, device='cuda')
+            dm.grad(params, obs, act, d_ret, d_val, nlp, idx[k], B, T, N, 0.2, 0.01, 0.5, g0, s0)
+            L.check(dm.lib.mrl_model_set_advstat(dm.handle, L.ptr(adv[k])), 'mrl_model_set_advstat')
+            try:
+                dm.grad(params, obs, act, d_ret, d_val, nlp, idx[k], B, T, N, 0.2, 0.01, 0.5, g1, s1)
+            finally:
+                L.check(dm.lib.mrl_model_set_advstat(dm.handle, None), 'mrl_model_set_advstat')
+            assert torch.equal(g0, g1) and torch.equal(s0, s1) and float(g0.abs().max()) > 0
+        # wrong statistics DO change the result (the pointer is what the step reads)
+        bad = torch.tensor([5.0, 0.1], dtype=torch.float32, device='cuda')
+        L.check(dm.lib.mrl_model_set_advstat(dm.handle, L.ptr(bad)), 'mrl_model_set_advstat')
+        try:
+            dm.grad(params, obs, act, d_ret, d_val, nlp, idx[0], B, T, N, 0.2, 0.01, 0.5, g1, s1)
+        finally:
+            L.check(dm.lib.mrl_model_set_advstat(dm.handle, None), 'mrl_model_set_advstat')
+        assert not torch.equal(g0, g1)
+    finally:
+        L.set_option('mlp_waves', old)
