@@ -149,20 +149,23 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
             o1, a, r, o2, d = replay_buffer.sample_dev(batch_size)
             model.train_dev(o1, a, r, o2, d, model.ones(batch_size))
 
+    n_actions = float(env.action_space.n)
+
+    def exploration_arguments(t, reset):
+        """what `act` is told at step t (deepq.py:263-275).  eps-greedy: the schedule's eps.  Parameter noise: eps-greedy off,
+        and the KL threshold that sizes the perturbation is the KL between a greedy policy and its eps-greedy version at the
+        schedule's eps, -log(1 - eps + eps / |A|) (Plappert et al. 2017, appendix C.1); the acting copy is re-drawn at the
+        start of every episode."""
+        eps = exploration.value(t)
+        if not param_noise:
+            return eps, {}
+        return 0.0, dict(reset=reset, update_param_noise_threshold=-np.log(1.0 - eps + eps / n_actions),
+                         update_param_noise_scale=True)
+
     for t in range(total_timesteps):
         if callback is not None and callback(locals(), globals()):
             break
-        kwargs = {}
-        if not param_noise:
-            update_eps = exploration.value(t)
-        else:
-            # deepq.py:263-275: eps-greedy off; the perturbation is sized so that the KL between the perturbed and the
-            # unperturbed policy matches that of eps-greedy exploration at the current eps (Plappert et al. 2017, app. C.1)
-            update_eps = 0.
-            update_param_noise_threshold = -np.log(1. - exploration.value(t) + exploration.value(t) / float(env.action_space.n))
-            kwargs['reset'] = reset
-            kwargs['update_param_noise_threshold'] = update_param_noise_threshold
-            kwargs['update_param_noise_scale'] = True
+        update_eps, kwargs = exploration_arguments(t, reset)
         action = act(np.array(obs)[None], update_eps=update_eps, **kwargs)[0]
         reset = False
         new_obs, rew, done, _ = env.step(action)
