@@ -3,6 +3,7 @@
 The product path has NO CPU fallback: if the library is missing or no HIP device is visible,
 every op raises.  (The oracle under oracle/ is test infrastructure and is never imported here.)
 """
+import contextlib
 import ctypes
 import os
 
@@ -235,6 +236,25 @@ def tune_set(label, variant):
 def set_option(name, value):
     """Engine option (include/mrl.h: "u8_bf16x3", "mlp_fused", ...)."""
     check(load().mrl_set_option(name.encode(), int(value)), 'mrl_set_option')
+
+
+@contextlib.contextmanager
+def capture_graph(graph):
+    """`torch.cuda.graph(graph, capture_error_mode='thread_local')` with the cyclic garbage collector held off.  A collection
+    that happens to run while the stream is capturing destroys whatever unreachable objects it finds -- an old Model's pinned
+    staging buffers, events, device tensors of a finished test -- and the runtime refuses those calls during capture (the
+    process aborts).  Collect first, then keep the collector off until the capture has ended."""
+    import gc
+    import torch
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def get_option(name):

@@ -312,7 +312,7 @@ class QModel(object):
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             try:                                         # (stream capture records the launches, it does not execute them)
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                with _lib.capture_graph(graph):
                     self._step_launches(g['o1'], g['a'], g['r'], g['o2'], g['d'], g['w'], g['td'], B, 0.0, g['alpha'])
                 g['graph'], g['ws'] = graph, self.workspace.data_ptr()
             except Exception as exc:                     # capture unsupported here: stay eager

@@ -366,7 +366,7 @@ class Model(object):
 
     def _capture_epoch_into(self, graph, key, cliprange, rollout, M, B, idx, alpha, stats, adv, mgn):
         lib = _lib.load()
-        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        with _lib.capture_graph(graph):
             st = _lib.stream_ptr()                         # the capturing stream
             # the epoch's permutation is known up front: the advantage statistics (model.py:136-139) of all its minibatches
             # in ONE launch, instead of every workgroup of every fused step gathering its whole minibatch again

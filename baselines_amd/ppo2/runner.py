@@ -176,7 +176,7 @@ class Runner(AbstractEnvRunner):
                     g = torch.cuda.CUDAGraph()
                     g.register_generator_state(self.model._gen)
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    with _lib.capture_graph(g):
                         out = self._rollout_steps(ro)
                     self._graph, self._graph_out = g, out
                 except Exception as exc:                                    # capture unsupported here: stay eager
