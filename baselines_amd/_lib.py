@@ -243,11 +243,11 @@ def capture_graph(graph):
     """`torch.cuda.graph(graph, capture_error_mode='thread_local')` with the cyclic garbage collector held off.  A collection
     that happens to run while the stream is capturing destroys whatever unreachable objects it finds -- an old Model's pinned
     staging buffers, events, device tensors of a finished test -- and the runtime refuses those calls during capture (the
-    process aborts).  Collect first, then keep the collector off until the capture has ended."""
+    process aborts).  `torch.cuda.graph` runs one explicit collection on entry, before the capture starts; the automatic
+    collector stays off until the capture has ended."""
     import gc
     import torch
     was_enabled = gc.isenabled()
-    gc.collect()
     gc.disable()
     try:
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):

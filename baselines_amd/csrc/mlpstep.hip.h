@@ -117,7 +117,9 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     float* wpi_s = dv_s + 32;                            // [64][nact] policy head weights
     float* wvf_s = wpi_s + 64 * 32;                      // [64] value head weights
     long* row_s = reinterpret_cast<long*>(wvf_s + 64);   // [32] storage rows (-1: beyond the minibatch)
-    float* kp_s = reinterpret_cast<float*>(row_s + 32);  // [<= 6 waves][16][64] partial accumulators of the later k ranges
+    // [waves][16][64] accumulator exchange of the two forward layers (k-range partial sums; sharing out the tanh epilogue).
+    // A workgroup that carries two nets borrows the dz1 | dz0 area for it (first written in P4), one net has its own 32 KB.
+    float* kp_s = nets == 1 ? reinterpret_cast<float*>(row_s + 32) : dz1_s;
 
     // ---- weight fragments of the two forward layers: requested FIRST.  The parameters were rewritten by the optimizer since
     //      the last step, so every XCD fetches them from the fabric again; asked for here, that trip overlaps with P0's
@@ -145,7 +147,10 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
         if (p1_gb + 1 < p1_NG) loadg(p1_gb + 1, fb1);
         if (p1_gb + 2 < p1_NG) loadg(p1_gb + 2, fb2);
     }
-    const float p1_bias = p1_kr == 0 ? P[B0(p1_net) + p1_n0 + i] : 0.f;
+    const float p1_bias = P[B0(p1_net) + p1_n0 + i];            // (every wave finishes a share of its tile: tanh is not cheap)
+    const float p2t_bias = P[B1(p1_net) + p1_n0 + i];           // same tile roles in the epilogue of P2
+    const int hq0 = tid;                                        // P3a: head bias of this thread's first output
+    const float hb0 = hq0 < 32 * (nact + 1) ? P[(hq0 % (nact + 1)) < nact ? a.bpi + (hq0 % (nact + 1)) : a.bvf] : 0.f;
     const int p2_net = wave >> 1, p2_n0 = (wave & 1) * 32;
     const bool p2_on = wave < 4 && p2_net < nets;
     const float p2_bias = p2_on ? P[B1(p2_net) + p2_n0 + i] : 0.f;
@@ -326,18 +331,22 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (khalf) {
+            // the KS waves of a tile exchange their partial accumulators through LDS; wave `khalf` then finishes 16 / KS of the
+            // 16 accumulator registers (partials summed in k-range order, bias, tanh): the 16 tanh evaluations per lane that
+            // one wave used to walk through (4 of P1's 8 us) are shared out
+            if (KS > 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) kp_s[(((khalf - 1) * NTL + wq) * 16 + r) * 64 + lane] = acc[r];
+                for (int r = 0; r < 16; ++r) kp_s[((khalf * NTL + wq) * 16 + r) * 64 + lane] = acc[r];
             }
             __syncthreads();                                     // (every wave arrives here)
-            if (!khalf) {
+            {
                 const float bias = p1_bias;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if (r * KS / 16 != khalf) continue;          // wave-uniform
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float v = acc[r];
-                    for (int q = 1; q < KS; ++q) v += kp_s[(((q - 1) * NTL + wq) * 16 + r) * 64 + lane];     // fixed order
+                    float v = KS > 1 ? kp_s[(wq * 16 + r) * 64 + lane] : acc[r];
+                    for (int q = 1; q < KS; ++q) v += kp_s[((q * NTL + wq) * 16 + r) * 64 + lane];           // fixed order
                     h0_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(v + bias);
                 }
             }
@@ -362,11 +371,26 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, w1f[4 * kb + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, w1f[4 * kb + 3], acc, 0, 0, 0);
             }
-            const float bias = p2_bias;
+            if (p1_KS > 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kp_s[(wave * 16 + r) * 64 + lane] = acc[r];       // wave == tile index here
+            } else {
+                const float bias = p2_bias;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    h1_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(acc[r] + bias);
+                }
+            }
+        }
+        if (p1_KS > 1) {
+            // bias + tanh of the tile shared out like in P1: wave (tile p1_wq, part p1_kr) finishes 16 / KS registers
+            __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if (r * p1_KS / 16 != p1_kr) continue;
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                h1_s[(net * 32 + row) * MLP_LD + n0 + i] = tanhf(acc[r] + bias);
+                h1_s[(p1_net * 32 + row) * MLP_LD + p1_n0 + i] = tanhf(kp_s[(p1_wq * 16 + r) * 64 + lane] + p2t_bias);
             }
         }
     }
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(MLP_NT) void mlp_step_kernel(MlpStepArgs a) {
     for (int q = tid; q < 32 * (nact + 1); q += MLP_NT) {
         const int s = q / (nact + 1), j = q - s * (nact + 1);
         if (j < nact ? !do_pi : !do_vf) continue;
-        const float hb = P[j < nact ? a.bpi + j : a.bvf];       // head bias: requested before the dot product, used after it
+        const float hb = q == hq0 ? hb0 : P[j < nact ? a.bpi + j : a.bvf];      // head bias: asked for at kernel start
         if (j < nact) {
             float acc = 0.f;
             const float* x = lat + s * MLP_LD;
@@ -721,7 +745,7 @@ __global__ __launch_bounds__(NT) void mlp_advstat_kernel(const float* __restrict
 inline size_t mlp_step_lds_bytes(int K0, int nets) {
     const int KP = (K0 + 7) / 8 * 8 + 4;
     size_t floats = (size_t)32 * KP + (size_t)4 * nets * 32 * MLP_LD + 3 * 32 * 32 + 64 + 64 * 32 + 64;
-    return floats * 4 + 32 * sizeof(long) + (size_t)(8 - 2 * nets) * 16 * 64 * sizeof(float) + 64;
+    return floats * 4 + 32 * sizeof(long) + (nets == 1 ? (size_t)8 * 16 * 64 * sizeof(float) : 0) + 64;
 }
 
 }  // namespace mrl

@@ -14,9 +14,10 @@ def _dev(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs=False):
+def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs=False, out=None):
     """ppo2/runner.py:52-65 on device.  rewards/values f32 [T,N], dones u8/bool [T,N],
-    last_values f32 [N], last_dones u8/bool [N] -> returns f32 [T,N] (and advs)."""
+    last_values f32 [N], last_dones u8/bool [N] -> returns f32 [T,N] (and advs).  `out`: write the returns into this
+    tensor (a rollout buffer whose address launch graphs have captured) instead of a new one."""
     _lib.require_gpu()
     rewards, values = _dev(rewards), _dev(values)
     T, N = rewards.shape
@@ -25,7 +26,9 @@ def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs=F
     last_values = _dev(last_values)
     assert rewards.dtype == values.dtype == last_values.dtype == torch.float32
     assert dones.dtype == torch.uint8 and dones.shape == (T, N) and values.shape == (T, N)
-    ret = torch.empty_like(rewards)
+    if out is not None:
+        assert out.shape == rewards.shape and out.dtype == torch.float32 and out.is_contiguous() and out.device == rewards.device
+    ret = out if out is not None else torch.empty_like(rewards)
     adv = torch.empty_like(rewards) if want_advs else None
     check(_lib.load().mrl_gae(ptr(rewards), ptr(values), ptr(dones), ptr(last_values), ptr(last_dones),
                               float(gamma), float(lam), ptr(adv), ptr(ret), T, N, stream_ptr()), 'mrl_gae')

@@ -320,9 +320,9 @@ class Model(object):
         indices on the device).  Returns a device tensor [nminibatches, 5] of loss stats.
 
         The launch-bound MLP configurations (320 steps of ~7 small kernels per update) run the epoch as ONE hipGraph:
-        the step sequence is captured once per update (the learning rate and the clip range are fixed inside an update),
-        reads its indices and its Adam step sizes from device buffers that are refreshed before every replay, and
-        is replayed once per epoch -- HIP graphs instead of ~2,000 individual launches per update.  Large-kernel
+        the step sequence is captured once (again only when the clip range or a rollout buffer changes: the rollout fields
+        are written in place, the learning rate enters through the step sizes), reads its indices and its Adam step sizes
+        from device buffers that are refreshed before every replay, and is replayed once per epoch -- HIP graphs instead of ~2,000 individual launches per update.  Large-kernel
         configurations (NatureCNN), multi-rank runs (the all-reduce sits between the two halves of a step) and
         per-kernel profiling use the plain step loop."""
         B = self.nbatch_train
@@ -333,7 +333,9 @@ class Model(object):
                      and os.environ.get('MRL_EPOCH_GRAPH', '1') != '0')
         if not graphable:
             return torch.stack([self.train_indexed(lr, cliprange, rollout, inds_dev[k * B:(k + 1) * B]) for k in range(M)])
-        key = (float(lr), float(cliprange), rollout.obs.data_ptr(), rollout.returns.data_ptr(), rollout.values.data_ptr(), M, B)
+        # (the learning rate is not part of the captured sequence: the Adam step sizes come from the `alpha` buffer)
+        key = (float(cliprange), rollout.obs.data_ptr(), rollout.actions.data_ptr(), rollout.returns.data_ptr(),
+               rollout.values.data_ptr(), rollout.neglogpacs.data_ptr(), M, B)
         g = self._epoch_graph
         if g is None or g['key'] != key:
             try:

@@ -267,7 +267,7 @@ class Runner(AbstractEnvRunner):
         else:
             last_values, epinfos = self._run_host_env(ro)
         # GAE(lambda) + returns: one HIP kernel, bit-exact vs runner.py:52-65
-        ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, self._dones_dev, self.gamma, self.lam)
+        ops.gae(ro.rewards, ro.values, ro.dones, last_values, self._dones_dev, self.gamma, self.lam, out=ro.returns)
         T, N = ro.T, ro.N
         act_dtype = np.int64 if ro.pd_kind == 'categorical' else np.float32
         fields = (RolloutField(ro.obs, T, N, self._ob_np), RolloutField(ro.returns, T, N, np.float32),

@@ -295,7 +295,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     # oracle entry by entry -- must agree to 1e-5 (stats) / 1e-5 of the gradient scale (every entry)
     self_check = None
     if workload == 'atari' and world == 1 and nbatch_train > 8192 and os.environ.get('MRL_BENCH_SELF_CHECK', '1') != '0':
-        ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
+        ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95, out=ro.returns)
         idx = torch.from_numpy(np.random.RandomState(7).permutation(nbatch)[:nbatch_train]).to(model.device)
         dm2 = ops.DeviceModel(chunk=8192, device=model.device, **policy.device_model_kwargs())
         outs = []
@@ -316,7 +316,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
 
     def update():
         """the PPO2 update (ppo2.py:142 GAE part + :154-166)"""
-        ro.returns = ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95)
+        ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95, out=ro.returns)
         inds = np.arange(nbatch)
         stats = []
         if recurrent:
