@@ -346,6 +346,12 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         update()                                   # the first update after the eager warm-up captures; keep that out too
     if want_prof and not graph_mode:
         _lib.prof_enable(True)
+    # host hygiene for the launch-bound configurations: whatever earlier workloads of this process left behind is collected
+    # NOW and the survivors are frozen, so that no full collection of the interpreter (~20 ms in this process) lands inside a
+    # timed region whose updates take 18 ms
+    import gc
+    gc.collect()
+    gc.freeze()
     sampler = DeviceStateSampler().start() if (rank == 0 and os.environ.get('MRL_BENCH_SMI', '1') != '0') else None
     sync()
     t0 = time.perf_counter()

@@ -1,7 +1,7 @@
 # full round-end check on one box: parity suite, smoke, bench, rocprof kernel trace of the bench command, PMC passes
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r02z}
 cd $R; mkdir -p $O
-bash scripts/gpu_check.sh $TAG
+bash scripts/gpu_check.sh $TAG "${@:2}"      # further arguments go to pytest (e.g. -k "not full_size")
 export TMPDIR=/tmp; cd /tmp
 rm -rf $O/prof_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-other-configs > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.err
