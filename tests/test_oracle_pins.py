@@ -277,3 +277,131 @@ def test_oracle_loss_statistics_and_gradient_from_the_formulas_of_model_py():
     # tf.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)
     gn = float(np.linalg.norm(flat.numpy()))
     np.testing.assert_allclose(om.average_and_clip(flat.clone()).numpy(), flat.numpy() * 0.5 / max(gn, 0.5), rtol=1e-12)
+
+
+def test_oracle_lnlstm_equals_the_formulas_of_a2c_utils_in_numpy():
+    """the layer-normalised cell of the oracle (oracle/ppo2_torch.py `_lstm` with layer_norm=True) against a float64 NumPy
+    restatement written straight from a2c/utils.py:104-140 -- `_ln` = (x - mean) / sqrt(var + 1e-5) * g + b with the
+    biased variance over axis 1, z = _ln(x@wx, gx, bx) + _ln(h@wh, gh, bh) + b, c = f c + i u, h = o tanh(_ln(c, gc, bc)),
+    episode masks applied to (c, h) first -- forward values, final state, and the gradient of a random functional as a
+    directional derivative (central differences in float64) against the oracle's autograd gradient"""
+    import torch
+    from oracle.ppo2_torch import OracleModel
+    rng = np.random.RandomState(4)
+    np.random.seed(4)
+    nenv, T, nin, nh = 3, 5, 6, 8
+    om = OracleModel(network='lstm', ob_shape=(nin,), ob_dtype=np.float32, pd_kind='categorical', nact=3, value_network=None,
+                     nlstm=nh, layer_norm=True, dtype=torch.float64)
+    with torch.no_grad():
+        for k in om.names:
+            om.p[k] += torch.tensor(0.3 * rng.randn(*om.p[k].shape), dtype=torch.float64)
+    sc = 'ppo2_model/pi/lnlstm/'
+    assert [n for n in om.names if 'lnlstm' in n] == [sc + s for s in ('wx', 'gx', 'bx', 'wh', 'gh', 'bh', 'b', 'gc', 'bc')]
+    P = {k[len(sc):]: om.p[k].detach().numpy().copy() for k in om.names if k.startswith(sc)}
+    feat = rng.randn(nenv * T, nin)                       # env-major rows like batch_to_seq expects
+    M = (rng.rand(nenv * T) < 0.3).astype(np.float64)
+    S0 = 0.5 * rng.randn(nenv, 2 * nh)
+
+    def ln(x, g, b, e=1e-5):
+        u = x.mean(axis=1, keepdims=True)
+        s = ((x - u) ** 2).mean(axis=1, keepdims=True)
+        return (x - u) / np.sqrt(s + e) * g + b
+
+    def forward(P, feat):
+        xs, ms = feat.reshape(nenv, T, nin), M.reshape(nenv, T)
+        c, h = S0[:, :nh].copy(), S0[:, nh:].copy()
+        out = np.zeros((nenv, T, nh))
+        for t in range(T):
+            m = ms[:, t:t + 1]
+            c, h = c * (1 - m), h * (1 - m)
+            z = ln(xs[:, t] @ P['wx'], P['gx'], P['bx']) + ln(h @ P['wh'], P['gh'], P['bh']) + P['b']
+            i, f, o = (1.0 / (1.0 + np.exp(-z[:, k * nh:(k + 1) * nh])) for k in range(3))
+            u = np.tanh(z[:, 3 * nh:])
+            c = f * c + i * u
+            h = o * np.tanh(ln(c, P['gc'], P['bc']))
+            out[:, t] = h
+        return out.reshape(nenv * T, nh), np.concatenate([c, h], axis=1)
+
+    h_np, s_np = forward(P, feat)
+    ft = torch.tensor(feat, dtype=torch.float64, requires_grad=True)
+    h_t, s_t = om._lstm(ft, S0, M, nenv, 'ppo2_model/pi')
+    np.testing.assert_allclose(h_t.detach().numpy(), h_np, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(s_t.detach().numpy(), s_np, rtol=1e-12, atol=1e-13)
+    # gradient of L = <h, G> + <s, Gs> along a random direction in (parameters, features)
+    G, Gs = rng.randn(*h_np.shape), rng.randn(*s_np.shape)
+    L = (h_t * torch.tensor(G)).sum() + (s_t * torch.tensor(Gs)).sum()
+    keys = list(P)
+    grads = torch.autograd.grad(L, [om.p[sc + k] for k in keys] + [ft])
+    D = {k: rng.randn(*P[k].shape) for k in keys}
+    Df = rng.randn(*feat.shape)
+    analytic = sum(float((g.numpy() * D[k]).sum()) for g, k in zip(grads[:-1], keys)) + float((grads[-1].numpy() * Df).sum())
+
+    def Lnp(eps):
+        Pp = {k: P[k] + eps * D[k] for k in keys}
+        hh, ss = forward(Pp, feat + eps * Df)
+        return float((hh * G).sum() + (ss * Gs).sum())
+
+    eps = 1e-6
+    numeric = (Lnp(eps) - Lnp(-eps)) / (2 * eps)
+    assert abs(numeric - analytic) <= 1e-7 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
+def test_oracle_layer_norm_variants_equal_their_formulas_in_numpy():
+    """tf.contrib.layers.layer_norm(center=True, scale=True) as the oracles restate it -- moments over the features of a row
+    (biased variance), variance_epsilon 1e-12, gamma * xhat + beta -- in its two places: between every fc and its activation
+    in `mlp(layer_norm=True)` (common/models.py:97-98) and between the hidden head layers and their ReLU in
+    `build_q_func(layer_norm=True)` (deepq/models.py:24-41, dueling combination :42-44); float64 NumPy from the formulas"""
+    import torch
+    from oracle.ppo2_torch import OracleModel
+    from oracle.dqn_torch import OracleQNet
+    rng = np.random.RandomState(8)
+    np.random.seed(8)
+
+    def ln(x, g, b):
+        u = x.mean(axis=1, keepdims=True)
+        s = ((x - u) ** 2).mean(axis=1, keepdims=True)
+        return (x - u) / np.sqrt(s + 1e-12) * g + b
+
+    # ---- mlp(layer_norm=True): latent of the policy net
+    om = OracleModel(network='mlp', ob_shape=(7,), ob_dtype=np.float32, pd_kind='categorical', nact=3, value_network=None,
+                     num_layers=2, num_hidden=16, layer_norm=True, dtype=torch.float64)
+    with torch.no_grad():
+        for k in om.names:
+            om.p[k] += torch.tensor(0.2 * rng.randn(*om.p[k].shape), dtype=torch.float64)
+    P = {k: v.detach().numpy() for k, v in om.p.items()}
+    x = rng.randn(9, 7)
+    h = x
+    for i in range(2):
+        z = h @ P['ppo2_model/pi/mlp_fc%d/w' % i] + P['ppo2_model/pi/mlp_fc%d/b' % i]
+        lnm = 'ppo2_model/pi/LayerNorm' + ('_%d' % i if i else '')
+        h = np.tanh(ln(z, P[lnm + '/gamma'], P[lnm + '/beta']))
+    np.testing.assert_allclose(om._net(torch.tensor(x), 'ppo2_model/pi').detach().numpy(), h, rtol=1e-12, atol=1e-13)
+
+    # ---- Q heads with layer norm on mlp features, dueling
+    tensors, off = [], 0
+    def add(name, shape):
+        nonlocal off
+        n = int(np.prod(shape))
+        tensors.append(dict(name=name, shape=tuple(shape), offset=off, size=n))
+        off += n
+    s = 'deepq/q_func'
+    add(s + '/mlp_fc0/w', (5, 12)); add(s + '/mlp_fc0/b', (12,))
+    for scope, nout in (('action_value', 4), ('state_value', 1)):
+        add('%s/%s/fully_connected/weights' % (s, scope), (12, 10)); add('%s/%s/fully_connected/biases' % (s, scope), (10,))
+        add('%s/%s/LayerNorm/beta' % (s, scope), (10,)); add('%s/%s/LayerNorm/gamma' % (s, scope), (10,))
+        add('%s/%s/fully_connected_1/weights' % (s, scope), (10, nout)); add('%s/%s/fully_connected_1/biases' % (s, scope), (nout,))
+    flat = 0.3 * rng.randn(off)
+    oq = OracleQNet('mlp', tensors, flat, nact=4, hiddens=(10,), dueling=True, num_layers=1, activation='tanh',
+                    dtype=torch.float64, layer_norm=True)
+    W = {t['name']: flat[t['offset']:t['offset'] + t['size']].reshape(t['shape']) for t in tensors}
+    obs = rng.randn(6, 5)
+    feat = np.tanh(obs @ W[s + '/mlp_fc0/w'] + W[s + '/mlp_fc0/b'])
+
+    def head(scope):
+        pre = '%s/%s/' % (s, scope)
+        o = feat @ W[pre + 'fully_connected/weights'] + W[pre + 'fully_connected/biases']
+        o = np.maximum(ln(o, W[pre + 'LayerNorm/gamma'], W[pre + 'LayerNorm/beta']), 0.0)
+        return o @ W[pre + 'fully_connected_1/weights'] + W[pre + 'fully_connected_1/biases']
+
+    a, v = head('action_value'), head('state_value')
+    np.testing.assert_allclose(oq.q_values(obs), v + (a - a.mean(axis=1, keepdims=True)), rtol=1e-12, atol=1e-13)
