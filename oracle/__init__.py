@@ -24,5 +24,8 @@ Pinning status (see DESIGN.md "Oracle"):
     in float64 NumPy (no library convolution: layout conventions HWIO, NHWC
     flatten, bias broadcast); the loss statistics from the formulas of
     model.py:57-91; the gradient as a directional derivative of that loss;
-    clip_by_global_norm.
+    clip_by_global_norm; the LSTM cell against a closed-form NumPy backward
+    (tests/test_oracle_golden.py); the layer-normalised LSTM cell (a2c/utils.py:104-140),
+    mlp(layer_norm=True) (common/models.py:97-98) and the layer-normalised dueling
+    Q heads (deepq/models.py:24-44) against float64 NumPy written from those lines.
 """
