@@ -29,7 +29,7 @@ class QNetDesc(ctypes.Structure):
     _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
                 ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('nconv', c_int),
                 ('convs', (c_int * 3) * 4), ('nhidden', c_int), ('hiddens', c_int * 4), ('dueling', c_int), ('nact', c_int),
-                ('layer_norm', c_int)]
+                ('layer_norm', c_int), ('body_layer_norm', c_int)]
 
 PD_CATEGORICAL, PD_DIAG_GAUSSIAN = 0, 1
 OB_F32, OB_U8 = 0, 1

@@ -28,9 +28,11 @@ class Comm(object):
         """Create the mrl_comm of this rank: rank 0 draws the RCCL unique id, torch.distributed ships it.
 
         Collective and fail-safe: every rank takes part in the id broadcast (rank 0 sends None when it could not
-        draw one), and the outcome is agreed on with an all-reduce(MIN) of a success flag -- when ANY rank failed
-        (librccl not loadable, ncclCommInitRank error) every rank drops its handle and the collectives stay in
-        torch.distributed.  Returns True when the in-library communicator is in use on all ranks."""
+        draw one); an all-reduce(MIN) of a success flag decides BEFORE the (collective) ncclCommInitRank whether all
+        ranks enter it, a second one agrees on its outcome, a third on a probe all-reduce through the new communicator
+        -- when ANY rank failed anywhere (library not loadable, no id, ncclCommInitRank error, wrong probe result) every
+        rank drops its handle and the collectives stay in torch.distributed; nobody blocks alone.
+        Returns True when the in-library communicator is in use on all ranks."""
         from .. import _lib
         size, rank = self.Get_size(), self.Get_rank()
         box, ok, why = [None], 1, ''
@@ -44,18 +46,29 @@ class Comm(object):
         except Exception as exc:                     # the broadcast below must still run on every rank
             ok, why = 0, repr(exc)
         dist.broadcast_object_list(box, src=0, group=self.group)
-        h = None
-        if ok and box[0] is not None:
-            try:
-                h = ctypes.c_void_p()
-                _lib.check(lib.mrl_comm_create(box[0], size, rank, ctypes.byref(h)), 'mrl_comm_create')
-            except Exception as exc:
-                ok, why, h = 0, repr(exc), None
-        else:
-            ok = 0
         dev = 'cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu'
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+
+        def agree(ok):
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item())
+
+        # phase 0: ncclCommInitRank is itself collective (it waits for `size` participants), so NO rank may enter it
+        # unless EVERY rank loaded the library and received an id -- a rank that skipped it would leave the others blocked
+        if box[0] is None:
+            ok, why = 0, why or 'rank 0 could not draw an RCCL unique id'
+        if not agree(ok):
+            self.native = None
+            self.native_error = why or 'another rank could not load the library'
+            return False
+        # phase 1: communicator creation, agreed on
+        h = None
+        try:
+            h = ctypes.c_void_p()
+            _lib.check(lib.mrl_comm_create(box[0], size, rank, ctypes.byref(h)), 'mrl_comm_create')
+        except Exception as exc:
+            ok, why, h = 0, repr(exc), None
+        flag = torch.tensor([agree(ok)], dtype=torch.int32)
         if int(flag.item()) == 1 and dev == 'cuda':
             # phase 2: the first collective through the new communicator, checked, and agreed on again
             try:
@@ -67,8 +80,7 @@ class Comm(object):
                     raise RuntimeError('probe all-reduce returned %r, expected %d' % (float(probe[0].item()), size))
             except Exception as exc:
                 ok, why = 0, repr(exc)
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            flag = torch.tensor([agree(ok)], dtype=torch.int32)
         if int(flag.item()) == 1:
             self.native = h
             self.native_error = None

@@ -71,6 +71,7 @@ extern "C" int mrl_qnet_create(const mrl_qnet_desc* d, mrl_qnet** out) {
     for (int i = 0; i < 3; ++i) m.d.ob_shape[i] = d->ob_shape[i];
     m.d.num_layers = d->num_layers; m.d.num_hidden = d->num_hidden; m.d.activation = d->activation;
     m.d.nact = d->nact; m.d.pd_kind = MRL_PD_CATEGORICAL;
+    m.d.layer_norm = (d->network == MRL_NET_MLP && d->body_layer_norm) ? 1 : 0;       // mlp(layer_norm=True) as the Q body
     m.vf_copy = false; m.has_pi_head = false; m.HP = 0;
     const std::string scope = "deepq/q_func";
     int rc = 0;
@@ -99,7 +100,7 @@ extern "C" int mrl_qnet_create(const mrl_qnet_desc* d, mrl_qnet** out) {
     } else if (d->network == MRL_NET_MLP || d->network == MRL_NET_NATURE_CNN) {
         const size_t before = m.tensors.size();
         rc = build_net(&m, m.pi, scope);                                   // ortho_init weights (a2c/utils.py:20-35)
-        for (size_t i = before; i < m.tensors.size(); ++i) q->init_kind.push_back(m.tensors[i].scale < 0 ? 0 : 1);
+        for (size_t i = before; i < m.tensors.size(); ++i) q->init_kind.push_back(m.tensors[i].scale == -2.0 ? 3 : m.tensors[i].scale < 0 ? 0 : 1);   // -2: LayerNorm gamma (ones)
     } else {
         rc = MRL_EUNSUP;
     }

@@ -64,6 +64,8 @@ class QModel(object):
         d.dueling = 1 if q_func.dueling else 0
         d.nact = self.num_actions
         d.layer_norm = 1 if getattr(q_func, 'layer_norm', False) else 0
+        # network = mlp(layer_norm=True): the body's own LayerNorm variables (common/models.py:97-98), independent of the heads'
+        d.body_layer_norm = 1 if (net.kind == 'mlp' and net.kw.get('layer_norm', False)) else 0
         self.ob_shape, self.torch_ob_dtype = ob_shape, (torch.uint8 if d.ob_dtype == _lib.OB_U8 else torch.float32)
         h = c_void_p()
         check(lib.mrl_qnet_create(ctypes.byref(d), ctypes.byref(h)), 'mrl_qnet_create')

@@ -334,8 +334,11 @@ class Model(object):
         if not graphable:
             return torch.stack([self.train_indexed(lr, cliprange, rollout, inds_dev[k * B:(k + 1) * B]) for k in range(M)])
         # (the learning rate is not part of the captured sequence: the Adam step sizes come from the `alpha` buffer)
+        # everything the captured launches bake in: rollout pointers, shapes, the workspace (set_chunk re-allocates it) and the
+        # engine options read at capture time -- a set_option / set_chunk after the first capture re-captures
         key = (float(cliprange), rollout.obs.data_ptr(), rollout.actions.data_ptr(), rollout.returns.data_ptr(),
-               rollout.values.data_ptr(), rollout.neglogpacs.data_ptr(), M, B)
+               rollout.values.data_ptr(), rollout.neglogpacs.data_ptr(), M, B, self.dm.workspace.data_ptr(), self.dm.chunk,
+               tuple(_lib.get_option(o) for o in ('mlp_fused', 'mlp_waves', 'mlp_slice')))
         g = self._epoch_graph
         if g is None or g['key'] != key:
             try:

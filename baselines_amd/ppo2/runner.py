@@ -51,7 +51,8 @@ class Rollout(object):
 
 class RolloutField(object):
     """Env-major view of a time-major device field: `field[mbinds]` == the reference's
-    `sf01(arr)[mbinds]` (runner.py:69-74 + ppo2.py:162), computed by the gather kernel."""
+    `sf01(arr)[mbinds]` (runner.py:69-74 + ppo2.py:162), computed by the gather kernel.
+    It ALIASES the runner's resident rollout buffer: the next Runner.run() overwrites what it shows."""
 
     def __init__(self, tensor, T, N, host_dtype):
         self.tensor, self.T, self.N, self.host_dtype = tensor, T, N, host_dtype
@@ -261,6 +262,10 @@ class Runner(AbstractEnvRunner):
         return last_values, epinfos
 
     def run(self):
+        """runner.py:20-67.  With return_host=True the eight results are fresh host arrays like the reference's.  With
+        return_host=False (the device fast path learn() uses) the fields are `RolloutField` VIEWS of the ONE resident HBM
+        rollout -- obs, returns, dones, actions, values, neglogpacs are overwritten in place by the next run(); a caller that
+        wants to keep a rollout across run() calls must copy it first (`field.to_numpy()` or `field.tensor.clone()`)."""
         ro = self.rollout
         if self.device_env and self.fast_step:
             last_values, epinfos = self._run_device_env(ro)

@@ -352,13 +352,16 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     import gc
     gc.collect()
     gc.freeze()
-    sampler = DeviceStateSampler().start() if (rank == 0 and os.environ.get('MRL_BENCH_SMI', '1') != '0') else None
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        lossvals = update()
-    sync()
-    t1 = time.perf_counter()
+    try:
+        sampler = DeviceStateSampler().start() if (rank == 0 and os.environ.get('MRL_BENCH_SMI', '1') != '0') else None
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lossvals = update()
+        sync()
+        t1 = time.perf_counter()
+    finally:
+        gc.unfreeze()                              # the frozen set is this timing window's only (config.host_gc says so)
     dt = t1 - t0
     device_state = sampler.stop(t0, t1) if sampler else None
     prof = {}

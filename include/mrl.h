@@ -292,6 +292,8 @@ typedef struct mrl_qnet_desc {
     int dueling;                                 /* build_q_func(dueling=True) */
     int nact;
     int layer_norm;                              /* build_q_func(layer_norm=True): LayerNorm before the ReLU of the hidden head layers */
+    int body_layer_norm;                         /* network = mlp(layer_norm=True) (common/models.py:97-98): LayerNorm[_i]/beta, gamma
+                                                    behind every mlp_fc<i> of the BODY, between the affine map and its activation */
 } mrl_qnet_desc;
 typedef struct mrl_qnet mrl_qnet;
 int  mrl_qnet_create(const mrl_qnet_desc* desc, mrl_qnet** out);

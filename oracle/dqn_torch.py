@@ -28,12 +28,14 @@ def _same_pad(n, k, s):
 
 class OracleQNet(object):
     def __init__(self, network, tensors, flat_params, nact, hiddens=(256,), dueling=True, convs=(), num_layers=2,
-                 activation='tanh', dtype=torch.float32, lr=5e-4, gamma=1.0, clip=10.0, double_q=True, layer_norm=False):
+                 activation='tanh', dtype=torch.float32, lr=5e-4, gamma=1.0, clip=10.0, double_q=True, layer_norm=False,
+                 body_layer_norm=False):
         self.network, self.nact, self.hiddens, self.dueling, self.convs = network, nact, tuple(hiddens), dueling, tuple(convs)
         self.num_layers, self.activation, self.dtype = num_layers, activation, dtype
         self.lr, self.gamma, self.clip, self.double_q = lr, gamma, clip, double_q
         self.tensors = tensors
         self.layer_norm = layer_norm
+        self.body_layer_norm = body_layer_norm          # network = mlp(layer_norm=True), common/models.py:97-98
         self.names = [t['name'] for t in tensors]
         flat = np.asarray(flat_params)
         self.p = {t['name']: torch.tensor(flat[t['offset']:t['offset'] + t['size']].reshape(t['shape']), dtype=dtype,
@@ -54,7 +56,14 @@ class OracleQNet(object):
             h = x.to(self.dtype).reshape(x.shape[0], -1)
             act = torch.tanh if self.activation == 'tanh' else F.relu
             for i in range(self.num_layers):
-                h = act(h @ p[s + '/mlp_fc%d/w' % i] + p[s + '/mlp_fc%d/b' % i])
+                h = h @ p[s + '/mlp_fc%d/w' % i] + p[s + '/mlp_fc%d/b' % i]
+                if self.body_layer_norm:
+                    # common/models.py:97-98: tf.contrib.layers.layer_norm(h, center=True, scale=True) in the q_func scope
+                    ln = s + ('/LayerNorm_%d' % i if i else '/LayerNorm')
+                    mu = h.mean(dim=1, keepdim=True)
+                    var = ((h - mu) ** 2).mean(dim=1, keepdim=True)
+                    h = (h - mu) * torch.rsqrt(var + 1e-12) * p[ln + '/gamma'] + p[ln + '/beta']
+                h = act(h)
         elif self.network == 'cnn':
             h = (x.to(self.dtype) / 255.).permute(0, 3, 1, 2)
             for name, stride in (('c1', 4), ('c2', 2), ('c3', 1)):

@@ -171,6 +171,33 @@ def test_layout_qnet_layer_norm_heads_variable_names(lib):
     lib.mrl_qnet_destroy(h)
 
 
+def test_layout_qnet_mlp_body_layer_norm_variable_names(lib):
+    """build_q_func(mlp(layer_norm=True)): the BODY's LayerNorm variables (common/models.py:97-98) exist, in the
+    q_func scope, beta before gamma, gamma initialised to ones -- independent of the heads' layer_norm switch"""
+    d = _lib.QNetDesc()
+    d.network, d.ob_ndim, d.ob_dtype, d.num_layers, d.num_hidden, d.activation = _lib.NET_MLP, 1, _lib.OB_F32, 2, 16, _lib.ACT_TANH
+    d.ob_shape[0] = 8
+    d.nhidden, d.dueling, d.nact, d.layer_norm, d.body_layer_norm = 1, 0, 3, 0, 1
+    d.hiddens[0] = 8
+    h = ctypes.c_void_p()
+    assert lib.mrl_qnet_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    name = ctypes.create_string_buffer(160)
+    names, kinds = [], {}
+    for i in range(lib.mrl_qnet_num_tensors(h)):
+        nd, shp, off, kind, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_int(), ctypes.c_double()
+        assert lib.mrl_qnet_tensor_info(h, i, name, 160, ctypes.byref(nd), ctypes.byref(shp), ctypes.byref(off), ctypes.byref(kind),
+                                        ctypes.byref(sc)) == 0
+        names.append(name.value.decode())
+        kinds[names[-1]] = kind.value
+    s = 'deepq/q_func/'
+    assert names == [s + 'mlp_fc0/w', s + 'mlp_fc0/b', s + 'LayerNorm/beta', s + 'LayerNorm/gamma', s + 'mlp_fc1/w', s + 'mlp_fc1/b',
+                     s + 'LayerNorm_1/beta', s + 'LayerNorm_1/gamma', s + 'action_value/fully_connected/weights',
+                     s + 'action_value/fully_connected/biases', s + 'action_value/fully_connected_1/weights',
+                     s + 'action_value/fully_connected_1/biases']
+    assert kinds[s + 'LayerNorm/gamma'] == 3 and kinds[s + 'LayerNorm_1/beta'] == 0 and kinds[s + 'mlp_fc1/w'] == 1
+    lib.mrl_qnet_destroy(h)
+
+
 def test_layout_rejects_unsupported(lib):
     rc, h = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 3), ob_dtype=_lib.OB_U8,
                     pd_kind=_lib.PD_CATEGORICAL, nact=6)

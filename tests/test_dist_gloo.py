@@ -128,3 +128,47 @@ def test_shard_envs_contiguous_cover():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _bringup_worker(rank, port, failing_rank, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    from baselines_amd import _lib
+    from baselines_amd.common.dist import Comm
+    entered = []
+
+    class FakeLib(object):                # stands in for libmrl.so: an id can be drawn, creation would block forever alone
+        def mrl_comm_unique_id(self, buf):
+            return 0
+
+        def mrl_comm_create(self, *a):
+            entered.append(rank)
+            return 0
+
+        def mrl_comm_destroy(self, h):
+            return 0
+
+    def load():
+        if rank == failing_rank:
+            raise OSError('libmrl.so: cannot open shared object file')
+        return FakeLib()
+    _lib.load = load
+    comm = Comm()
+    ok = comm.enable_native()
+    out[rank] = (ok, list(entered), comm.native is None, comm.native_error)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('failing_rank', [0, 1])
+def test_enable_native_agrees_before_the_collective_communicator_creation(failing_rank):
+    """ncclCommInitRank waits for every rank, so a rank whose library failed to load must keep ALL ranks out of
+    mrl_comm_create (not just itself) -- everybody falls back to the torch.distributed collectives, nobody blocks."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bringup_worker, args=(port, failing_rank, out), nprocs=WORLD, join=True)
+    for rank in range(WORLD):
+        ok, entered, no_handle, err = out[rank]
+        assert ok is False and entered == [] and no_handle and err

@@ -20,6 +20,11 @@ CASES = {
     'mlp_dueling': dict(network='mlp', ob=Box(-1.0, 1.0, (12,), np.float32), nact=5, hiddens=(32, 16), dueling=True),
     'mlp_dueling_layer_norm': dict(network='mlp', ob=Box(-1.0, 1.0, (12,), np.float32), nact=5, hiddens=(48, 24), dueling=True,
                                    layer_norm=True),
+    # network = mlp(layer_norm=True) (common/models.py:97-98): LayerNorm variables in the BODY; heads plain / normalised too
+    'mlp_body_layer_norm': dict(network='mlp', ob=Box(-1.0, 1.0, (12,), np.float32), nact=5, hiddens=(32,), dueling=True,
+                                body_layer_norm=True, num_layers=3, num_hidden=40),
+    'mlp_body_and_heads_layer_norm': dict(network='mlp', ob=Box(-1.0, 1.0, (10,), np.float32), nact=4, hiddens=(24,), dueling=False,
+                                          layer_norm=True, body_layer_norm=True),
     'conv_only_dueling': dict(network='conv_only', ob=Box(0, 255, (84, 84, 4), np.uint8), nact=6, hiddens=(256,), dueling=True),
     'conv_only_small': dict(network='conv_only', ob=Box(0, 255, (21, 17, 4), np.uint8), nact=4, hiddens=(32,), dueling=True,
                             convs=((8, 5, 3), (12, 3, 2))),
@@ -31,10 +36,15 @@ def _pair(name, B, seed, double_q=True):
     from baselines_amd.deepq import QModel, build_q_func
     c = dict(CASES[name])
     ob, nact = c.pop('ob'), c.pop('nact')
-    net_kw = {k: c.pop(k) for k in list(c) if k in ('convs',)}
+    net_kw = {k: c.pop(k) for k in list(c) if k in ('convs', 'num_layers', 'num_hidden')}
+    if c.get('body_layer_norm'):
+        net_kw['layer_norm'] = True          # build_q_func(network, **network_kwargs) -> mlp(layer_norm=True)
+        from baselines_amd.deepq.models import get_network_builder
+        qf_net = get_network_builder(c['network'])(**net_kw)
     np.random.seed(seed)
     torch.manual_seed(seed)
-    qf = build_q_func(c['network'], hiddens=c['hiddens'], dueling=c['dueling'], layer_norm=c.get('layer_norm', False), **net_kw)
+    qf = build_q_func(qf_net if c.get('body_layer_norm') else c['network'], hiddens=c['hiddens'], dueling=c['dueling'],
+                      layer_norm=c.get('layer_norm', False), **({} if c.get('body_layer_norm') else net_kw))
     qm = QModel(qf, ob, nact, lr=1e-3, gamma=0.99, grad_norm_clipping=10, double_q=double_q, max_batch=B)
     rng = np.random.RandomState(seed + 1)
     # biases are zero at init: perturb everything so every gradient path is exercised
@@ -44,7 +54,14 @@ def _pair(name, B, seed, double_q=True):
     qm.target.copy_(torch.from_numpy(tflat))
     kw = dict(network=c['network'], tensors=qm.tensors, nact=nact, hiddens=c['hiddens'], dueling=c['dueling'],
               convs=qf.network.kw.get('convs', ()), lr=1e-3, gamma=0.99, clip=10.0, double_q=double_q,
-              layer_norm=c.get('layer_norm', False))
+              layer_norm=c.get('layer_norm', False), body_layer_norm=c.get('body_layer_norm', False),
+              num_layers=qf.network.kw.get('num_layers', 2))
+    if c.get('body_layer_norm'):             # the body's variables sit in the q_func scope, created beta first (models.py:97-98)
+        nm = [t['name'] for t in qm.tensors]
+        assert nm[:4] == ['deepq/q_func/mlp_fc0/w', 'deepq/q_func/mlp_fc0/b', 'deepq/q_func/LayerNorm/beta', 'deepq/q_func/LayerNorm/gamma']
+        assert 'deepq/q_func/LayerNorm_1/gamma' in nm
+        g = [t for t in qm.tensors if t['name'] == 'deepq/q_func/LayerNorm/gamma'][0]
+        assert g['init_kind'] == 3
     oms = []
     for dt in (torch.float32, torch.float64):
         om = OracleQNet(flat_params=flat, dtype=dt, **kw)
