@@ -67,12 +67,13 @@ def test_config2_epochs_at_the_benched_shape_vs_oracle_step_by_step():
               ent_coef=ent, vf_coef=0.5, max_grad_norm=0.5)
     om = OracleModel(**kw)
     np.testing.assert_array_equal(model.get_flat_params(), om.flat_params())
+    om64 = OracleModel(dtype=torch.float64, params=om.params_numpy(), **kw)       # the yardstick for free-running trajectories
     runner = Runner(env=env, model=model, nsteps=T, gamma=0.99, lam=0.95, return_host=False)
     runner.run()
     runner.run()                                       # second rollout: episodes have ended, dones are mixed in
     ro = runner.rollout
     f = {k: O.sf01(getattr(ro, k).cpu().numpy()) for k in ('obs', 'actions', 'returns', 'values', 'neglogpacs')}
-    worst_stats, worst_par = 0.0, []
+    worst_stats, worst_par, worst_o32 = 0.0, [], []
     inds = np.arange(N * T)
     for epoch in range(3):
         np.random.shuffle(inds)                        # ppo2.py:156-158
@@ -82,16 +83,29 @@ def test_config2_epochs_at_the_benched_shape_vs_oracle_step_by_step():
             idx = inds[k * B:(k + 1) * B]
             so = om.train(lr, clip, f['obs'][idx], f['returns'][idx], None, f['actions'][idx], f['values'][idx],
                           f['neglogpacs'][idx])
+            s64 = om64.train(lr, clip, f['obs'][idx], f['returns'][idx], None, f['actions'][idx], f['values'][idx],
+                             f['neglogpacs'][idx])
             np.testing.assert_allclose(st[k], np.array(so), rtol=1e-5, atol=1e-5, err_msg='epoch %d step %d' % (epoch, k))
-            worst_stats = max(worst_stats, float(np.abs(st[k] - np.array(so)).max()))
+            np.testing.assert_allclose(st[k], np.array(s64), rtol=1e-5, atol=1e-5, err_msg='epoch %d step %d (fp64)' % (epoch, k))
+            worst_stats = max(worst_stats, float(np.abs(st[k] - np.array(s64)).max()))
         # epoch 0 ran as individually launched steps (nothing to replay yet), epochs 1, 2 as the captured graph and its replay
         assert (model._epoch_graph is None) == (epoch == 0)
-        worst_par.append(float(np.abs(model.get_flat_params() - om.flat_params()).max()))
-        np.testing.assert_allclose(model.get_flat_params(), om.flat_params(), rtol=0, atol=5e-6,
-                                   err_msg='parameters after epoch %d' % epoch)
+        # Adam steps are sign-like (|step| ~ lr whatever |g|), so two fp32 implementations drift apart along a free-running
+        # trajectory on the entries whose gradient is a cancellation residue; the yardstick is the fp64 trajectory: the device
+        # has to stay within 5e-6 of it for the first two epochs (one launched step by step, one replayed) and as close
+        # to it as the fp32 CPU restatement does thereafter
+        p64 = om64.flat_params()
+        worst_par.append(float(np.abs(model.get_flat_params() - p64).max()))
+        worst_o32.append(float(np.abs(om.flat_params() - p64).max()))
+    report(test='config2_epochs_benched_shape.trajectory', max_param_abs_diff_vs_fp64_after_each_epoch=worst_par,
+           fp32_oracle_max_param_abs_diff_vs_fp64_after_each_epoch=worst_o32, worst_stat_abs_diff_vs_fp64=worst_stats)
+    for epoch in range(3):
+        assert worst_par[epoch] <= max(5e-6 if epoch < 2 else 0.0, 2.0 * worst_o32[epoch]), (epoch, worst_par, worst_o32)
     assert model._train_calls == 3 * M and isinstance(model._epoch_graph, dict)
-    np.testing.assert_allclose(model.adam_v.cpu().numpy(),
-                               np.concatenate([om.v[k].numpy().reshape(-1) for k in om.names]), rtol=1e-4, atol=1e-12)
+    v64 = np.concatenate([om64.v[k].numpy().reshape(-1) for k in om.names])
+    v32 = np.concatenate([om.v[k].numpy().reshape(-1) for k in om.names]).astype(np.float64)
+    e_d, e_o = np.abs(model.adam_v.cpu().numpy() - v64).max(), np.abs(v32 - v64).max()
+    assert e_d <= max(1e-6 * v64.max(), 4.0 * e_o), (e_d, e_o, v64.max())          # second-moment slots: same yardstick (a trajectory, not a step)
 
     # ---- one 4096-sample gradient, every entry against the fp64 oracle (the policy has moved: ratios != 1, clipping active)
     flat = model.get_flat_params()
@@ -116,7 +130,8 @@ def test_config2_epochs_at_the_benched_shape_vs_oracle_step_by_step():
         tol = 5e-5 * max(np.abs(g64n[sl]).max(), 1e-3 * scale)
         assert np.abs(g_d[sl] - g64n[sl]).max() <= tol, (t['name'], errs[t['name']])
     report(test='config2_epochs_benched_shape', N=N, T=T, minibatch=B, steps_checked=3 * M,
-           worst_stat_abs_diff_vs_fp32_oracle=worst_stats, max_param_abs_diff_after_each_epoch=worst_par,
+           worst_stat_abs_diff_vs_fp64_oracle=worst_stats, max_param_abs_diff_vs_fp64_after_each_epoch=worst_par,
+           fp32_oracle_max_param_abs_diff_vs_fp64_after_each_epoch=worst_o32,
            grad_errors_over_tensor_scale=errs)
 
 

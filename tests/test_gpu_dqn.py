@@ -113,7 +113,7 @@ def test_q_values_td_gradient_and_clipped_adam_vs_oracle(name):
     # the next gradients by a percent, so free-running trajectories of two fp32 implementations are not comparable at
     # tight tolerances; the optimizer arithmetic is, when both sides are fed the same gradient.
     flat_of = lambda dct: np.concatenate([dct[k].detach().numpy().reshape(-1) for k in names]).astype(np.float32)
-    for it, gscale in enumerate((1.0, 300.0, 1.0)):          # step 1: every variable is clipped to norm 10
+    for it, gscale in enumerate((1.0, 1000.0, 1.0)):          # step 1: every variable is clipped to norm 10
         _, _, g = om.td_and_grads(b['obs_t'], b['act'], b['rew'], b['obs_tp1'], b['done'], b['w'])
         g = {k: v * gscale for k, v in g.items()}
         if it == 1:
