@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "wres.hip.h"
 #include "planes.hip.h"
@@ -159,6 +160,9 @@ __global__ __launch_bounds__(WAVES * 64) void c1fwd_lds_kernel(const uint8_t* __
 // v_writelane from the wave ballots.  8 waves, two LDS image buffers (2 x 56448 B bf16) + filter planes (50688 B).
 constexpr int C1_IMG16 = C1_IMG * 2;                     // bytes of a bf16 image
 typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef C1_TR_STORE_STRIDE
+#define C1_TR_STORE_STRIDE 6
+#endif
 
 struct C1TrRelu {            // h = relu(acc) (bias folded into the accumulator), fp32 + bit mask + planes
     float* out; uint32_t* mask; uint16_t* hp; long pstride;
@@ -326,6 +330,331 @@ __global__ __launch_bounds__(512) void c1fwd2_kernel(const uint8_t* __restrict__
         if (more) stage(img + (par ^ 1) * C1_IMG16);
         __syncthreads();                                  // next image staged; this image's patch reads are done
     }
+}
+
+// ---- third generation (round 4): the second-generation kernel walks its phases in lock-step -- all 8 waves multiply, then
+// all of them walk their epilogue (16 dword stores + ballots per tile), then all convert and stage the next image, then the
+// barrier: the matrix pipe idles for ~45 % of an image's time (6.1 k MFMA cycles on the busiest SIMD of ~11 k per image at
+// 3.02 ms per 131072 images).  Here the three phases are ONE software pipeline per wave: while the MFMAs of image b run,
+// the wave issues -- between them, in program order, a few instructions per MFMA -- (a) the stores / mask ballots of ITS
+// tiles of image b-G (kept ReLU'd in 32 registers), (b) the u8 -> bf16 conversion and LDS writes of ITS chunks of image
+// b+G (into the other LDS buffer), (c) the global loads of image b+2G.  Nothing but the barrier is left between two MFMA
+// streams.  Tiles: 13 per image (12.5 real); waves 0-4 own two, waves 5-7 one each, so every SIMD (waves w, w+4) carries
+// 3-4 tiles.  Same products, same order of accumulation per output as c1fwd2_kernel: bit-identical results.
+template <bool MASK, int DBG = 0, bool TR = false>
+__global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out, uint32_t* __restrict__ mask, int B) {
+    constexpr int NT = 512;
+    constexpr int CHUNKS = C1_IMG / 16;                   // 1764 16-byte chunks of an image
+    constexpr int NLD = (CHUNKS + NT - 1) / NT;           // 4
+    constexpr int TILES = (C1_PIX + 31) / 32;             // 13 (the last one: 16 pixels)
+    extern __shared__ __attribute__((aligned(16))) uint16_t c1s[];
+    uint16_t* wp = c1s;                                   // [3][32][KP] bf16 planes of filter / 255
+    uint8_t* img = reinterpret_cast<uint8_t*>(c1s + 3 * 32 * C1_KP);      // [2 buffers][C1_IMG] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    for (int e = tid; e < 3 * 32 * C1_KP; e += NT) wp[e] = 0;
+    __syncthreads();
+    for (int e = tid; e < C1_K * C1_NF; e += NT) {
+        const int k = e / C1_NF, n = e - k * C1_NF;
+        const float v = w[e] / 255.f;
+        const uint32_t h0 = bf16_rn_bits(v);
+        const float r1 = v - __uint_as_float(h0 << 16);
+        const uint32_t h1 = bf16_rn_bits(r1);
+        const float r2 = r1 - __uint_as_float(h1 << 16);
+        const uint32_t h2 = bf16_rn_bits(r2);
+        wp[(0 * 32 + n) * C1_KP + k] = (uint16_t)h0;
+        wp[(1 * 32 + n) * C1_KP + k] = (uint16_t)h1;
+        wp[(2 * 32 + n) * C1_KP + k] = (uint16_t)h2;
+    }
+    const float bv = bias[i];
+    float bvr[16];                                        // TR: the accumulator register indexes the channel (8g + 4h + j = register 4g + j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bvr[r] = TR ? bias[2 * (r & ~3) + 4 * h + (r & 3)] : 0.f;
+    const int G = gridDim.x;
+    c1_u32x4 st[NLD];
+    // chunk q of this thread (clamped: the 28 threads past the image's end re-read its last chunk and drop it when staging)
+    const int cidx[NLD] = {min(tid, CHUNKS - 1), min(NT + tid, CHUNKS - 1), min(2 * NT + tid, CHUNKS - 1), min(3 * NT + tid, CHUNKS - 1)};
+    auto img_ptr = [&](int b) {
+        b = min(b, B - 1);                                // past the end: a valid image, staged and never multiplied
+        const long row = srow ? (long)srow[b] : (long)b;
+        return obs + row * C1_IMG;
+    };
+    auto stage_half = [&](uint8_t* dst, int q, int half) {       // 8 bytes of chunk q -> 8 bf16 (16 bytes of LDS)
+        uint32_t e0, e1, e2, e3;
+        u8x4_to_bf16(st[q][2 * half], e0, e1);
+        u8x4_to_bf16(st[q][2 * half + 1], e2, e3);
+        if (q < NLD - 1 || 3 * NT + tid < CHUNKS)
+            *reinterpret_cast<c1_u32x4*>(dst + (long)cidx[q] * 32 + 16 * half) = c1_u32x4{e0, e1, e2, e3};
+    };
+    int b = blockIdx.x;
+    {
+        const uint8_t* g = img_ptr(b);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) st[q] = *reinterpret_cast<const c1_u32x4*>(g + (long)cidx[q] * 16);
+    }
+    __syncthreads();                                      // planes built
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) { stage_half(img, q, 0); stage_half(img, q, 1); }
+    {
+        const uint8_t* g = img_ptr(b + G);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) st[q] = *reinterpret_cast<const c1_u32x4*>(g + (long)cidx[q] * 16);
+    }
+    __syncthreads();
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wp + (long)i * C1_KP + 8 * h);
+    // tiles of this wave: waves 0-4 -> (2w, 2w+1), waves 5, 6, 7 -> 10, 11, 12
+    const int t0 = wave < 5 ? 2 * wave : 5 + wave;
+    const bool two = wave < 5;
+    int aoff[2];                                          // byte offset of this lane's patch inside an LDS image, per tile
+    int pixl[2];                                          // TR: output pixel of this lane, per tile
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        // the last tile has 16 pixels: its lanes 16 .. 31 compute pixels 384 .. 399 AGAIN (TR: they then store the same values to
+        // the same addresses as lanes 0 .. 15 -- no predicates in the epilogue)
+        int m = (t0 + u) * 32 + i;
+        if (m >= C1_PIX) m = TR ? m - 16 : C1_PIX - 1;
+        m = min(m, C1_PIX - 1);
+        pixl[u] = m;
+        const int oy = m / C1_OW, ox = m - oy * C1_OW;
+        aoff[u] = ((oy * C1_S * C1_W + ox * C1_S) * C1_C + 8 * h) * 2;
+    }
+    const int nr0 = (t0 == TILES - 1) ? 8 : 16;           // valid accumulator registers of the first tile (the last tile: pixels 384 .. 399)
+    f32x16 pend[2];                                       // ReLU'd outputs of this wave's tiles of the previous image
+    long ppix0 = 0;
+
+    // one image: MFMAs with (EPI) the previous image's epilogue, the next image's staging and the loads of the one after that
+    // issued between them.  TWO: this wave owns two tiles.
+    auto phase = [&](auto two_c, auto epi_c, const uint8_t* cur, uint8_t* nxt, int bnext2) {
+        constexpr bool TWO = decltype(two_c)::value, EPI = decltype(epi_c)::value;
+        constexpr int NU = TWO ? 2 : 1;
+        const uint8_t* arow[2] = {cur + aoff[0], cur + aoff[1]};
+        f32x16 acc[2];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = TR ? bvr[r] : bv;  // bias: column (= lane & 31) constant of the C layout (TR: row)
+        c1_u32x4 fa[2][2], fb[2][3];
+        auto lds_a = [&](int q, int u, c1_u32x4 (&a)[2]) {
+            a[u] = *reinterpret_cast<const c1_u32x4*>(arow[u] + ((q >> 1) * (C1_W * C1_C) + 16 * (q & 1)) * 2);
+        };
+        auto lds_b = [&](int q, int pl, c1_u32x4 (&bq)[3]) {
+            bq[pl] = *reinterpret_cast<const c1_u32x4*>(wrow + (q * 16 + pl * 32 * C1_KP) * 2);
+        };
+#pragma unroll
+        for (int u = 0; u < NU; ++u) lds_a(0, u, fa[0]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) lds_b(0, pl, fb[0]);
+        float* ob[2];
+        int mw[2] = {0, 0};
+        if constexpr (EPI) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                ob[u] = TR ? out + ((ppix0 + pixl[u]) * C1_NF + 4 * h) : out + ((ppix0 + (t0 + u) * 32 + 4 * h) * C1_NF + i);
+        }
+        // TR epilogue piece e (0 .. 8 NU - 1) of the previous image: tile e >> 3, channel group g = (e & 7) >> 1 (channels
+        // 8g + 4h .. +3); even pieces: its 16-byte store; odd pieces: its mask bits (bit = channel; v >= 0 after the ReLU)
+        // The four 16-byte stores of a tile complete 32 whole 128-byte lines between them: issued close together (every SS-th
+        // gap) they merge on the way to memory; spread evenly over the phase the same stores cost 0.3 ms more per launch.
+        auto epi_tr_store = [&](int u, int g) {
+            if constexpr (EPI && TR) {
+                if (!(DBG & 1))
+                    *reinterpret_cast<float4*>(ob[u] + 8 * g) = make_float4(pend[u][4 * g], pend[u][4 * g + 1], pend[u][4 * g + 2], pend[u][4 * g + 3]);
+            }
+        };
+        auto epi_tr_mask = [&](int u, int g) {
+            if constexpr (EPI && TR && MASK && !(DBG & 16)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    mw[u] |= (int)(min(__float_as_uint(pend[u][4 * g + j]), 1u) << (8 * g + j));       // (shifted by 4h once, below)
+            }
+        };
+        const uint8_t* gnext = img_ptr(bnext2);
+        // epilogue row e (0 .. 16 NU - 1) of the previous image: tile e >> 4, accumulator register e & 15
+        auto epi_row = [&](int e) {
+            if constexpr (EPI) {
+                const int u = e >> 4, r = e & 15, rr = (r & 3) + 8 * (r >> 2);
+                if (u == 0 && r >= nr0) return;           // (wave-uniform) rows past the image's last pixel
+                const float v = pend[u][r];
+                if (!(DBG & 1)) ob[u][rr * C1_NF] = v;
+                if constexpr (MASK && !(DBG & 16)) {
+                    const unsigned long long bal = __ballot(v > 0.f);
+                    const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
+                    // (the s_nop covers the VALU-writes-SGPR -> v_writelane wait states, which the compiler does not insert
+                    // around inline assembly)
+                    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                                 : "+v"(mw[u]) : "s"(blo), "s"(bhi), "n"(rr), "n"(rr + 4));
+                }
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 2 * C1_RF; ++q) {
+            const int cq = q & 1;
+            int slot = 0;                                  // MFMA gap inside this k block
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    if (!(DBG & 2)) {
+                        if constexpr (TR) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cq][pl]), __builtin_bit_cast(bf16x8, fa[cq][u]), acc[u], 0, 0, 0);
+                        else acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cq][u]), __builtin_bit_cast(bf16x8, fb[cq][pl]), acc[u], 0, 0, 0);
+                    }
+                    else acc[u][0] += __uint_as_float(fa[cq][u][0] ^ fb[cq][pl][0]);       // timing experiment: fragments consumed, no matrix work
+                    // ---- the gap behind this MFMA
+                    const int gap = q * 3 * NU + slot;     // 0 .. 48 NU - 1
+                    if (q + 1 < 2 * C1_RF) {
+                        // fragment reads of the next k block, in the order its MFMAs need them (plane 2 first): the fragment
+                        // read last is needed ~2 gaps into the next block, every other one has 4-6 gaps of cover
+                        if constexpr (TWO) {
+                            if (slot == 0) lds_b(q + 1, 2, fb[cq ^ 1]);
+                            if (slot == 1) lds_a(q + 1, 0, fa[cq ^ 1]);
+                            if (slot == 2) lds_a(q + 1, 1, fa[cq ^ 1]);
+                            if (slot == 3) lds_b(q + 1, 1, fb[cq ^ 1]);
+                            if (slot == 4) lds_b(q + 1, 0, fb[cq ^ 1]);
+                        } else {
+                            if (slot == 0) { lds_b(q + 1, 2, fb[cq ^ 1]); lds_a(q + 1, 0, fa[cq ^ 1]); }
+                            if (slot == 1) lds_b(q + 1, 1, fb[cq ^ 1]);
+                            if (slot == 2) lds_b(q + 1, 0, fb[cq ^ 1]);
+                        }
+                    }
+                    if constexpr (TR) {
+                        constexpr int SS = C1_TR_STORE_STRIDE;
+                        const int gu = gap % 48, u = gap / 48;                        // 48 gaps per tile
+                        if (gu % SS == 0 && gu / SS < 4) epi_tr_store(u, gu / SS);
+                        if (gu >= 24 && gu % 6 == 0) epi_tr_mask(u, (gu - 24) / 6);
+                    }
+                    else if (gap % 3 == 0) epi_row(gap / 3);                          // 32 (16) rows over 96 (48) gaps
+                    if (gap % 3 == 1 && gap / 3 < 2 * NLD && !(DBG & 8)) stage_half(nxt, gap / 6, (gap / 3) & 1);   // gaps 1, 4, .. 22: 8 half chunks
+                    if (gap % 3 == 1 && gap / 3 >= 2 * NLD && gap / 3 < 3 * NLD && !(DBG & 4))
+                        st[gap / 3 - 2 * NLD] = *reinterpret_cast<const c1_u32x4*>(gnext + (long)cidx[gap / 3 - 2 * NLD] * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++slot;
+                }
+        }
+        if constexpr (EPI && MASK && TR) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int mine = mw[u] << (4 * h);
+                const int other = __shfl_xor(mine, 32);    // the other 16 channels of this lane's pixel
+                if (h == 0 && !(DBG & 1)) mask[ppix0 + pixl[u]] = (uint32_t)(mine | other);
+            }
+        } else if constexpr (EPI && MASK) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int t = t0 + u;
+                if (lane < (t == TILES - 1 ? 16 : 32)) mask[ppix0 + t * 32 + lane] = (uint32_t)mw[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pend[u][r] = fmaxf(acc[u][r], 0.f);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // Control flow: the first image (no epilogue yet) and the second one are peeled, the loop runs from the third.  The image
+    // loads of phase k are consumed in phase k+1 behind ~10 younger stores; the compiler's s_waitcnt insertion merges the
+    // states of all paths into a loop header, so a loop entered straight from the prologue (loads just issued, nothing
+    // behind them) gets vmcnt(0..3) at the top of EVERY phase -- which also waits for the previous phase's last stores
+    // (0.6 ms of 2.8 per 131072 images).  Entered from a peeled copy of its own body, the counts are exact (vmcnt(10)).
+    int par = 0;
+    bool first = true;
+#define MRL_C1_STEP(TWOC, EPIC)                                                                                   \
+    {                                                                                                            \
+        phase(TWOC, EPIC, img + par * C1_IMG16, img + (par ^ 1) * C1_IMG16, b + 2 * G);                           \
+        ppix0 = (long)b * C1_PIX;                                                                                \
+        first = false;                                                                                           \
+        b += G;                                                                                                  \
+        par ^= 1;                                                                                                \
+        __syncthreads(); /* next image staged; this image's patch reads are done */                              \
+    }
+    if (two) {
+        if (b < B) MRL_C1_STEP(T_{}, F_{})
+        if (b < B) {
+            MRL_C1_STEP(T_{}, T_{})
+            while (b < B) MRL_C1_STEP(T_{}, T_{})
+        }
+    } else {
+        if (b < B) MRL_C1_STEP(F_{}, F_{})
+        if (b < B) {
+            MRL_C1_STEP(F_{}, T_{})
+            while (b < B) MRL_C1_STEP(F_{}, T_{})
+        }
+    }
+#undef MRL_C1_STEP
+    // the last image's epilogue
+    if (!first && TR) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            float* ob = out + ((ppix0 + pixl[u]) * C1_NF + 4 * h);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(ob + 8 * g) = make_float4(pend[u][4 * g], pend[u][4 * g + 1], pend[u][4 * g + 2], pend[u][4 * g + 3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bits |= min(__float_as_uint(pend[u][4 * g + j]), 1u) << (8 * g + 4 * h + j);
+            }
+            if constexpr (MASK) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)bits, 32);
+                if (h == 0) mask[ppix0 + pixl[u]] = bits | other;
+            }
+        }
+    } else if (!first) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int t = t0 + u;
+            const int nr = (t == TILES - 1) ? 8 : 16;
+            float* ob = out + ((ppix0 + t * 32 + 4 * h) * C1_NF + i);
+            int mw = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r < nr) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    const float v = pend[u][r];
+                    ob[rr * C1_NF] = v;
+                    if constexpr (MASK) {
+                        const unsigned long long bal = __ballot(v > 0.f);
+                        const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
+                        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                                     : "+v"(mw) : "s"(blo), "s"(bhi), "n"(rr), "n"(rr + 4));
+                    }
+                }
+            }
+            if (MASK && lane < (nr == 16 ? 32 : 16)) mask[ppix0 + t * 32 + lane] = (uint32_t)mw;
+        }
+    }
+}
+
+inline hipError_t launch_c1fwd3(const void* obs, const int32_t* srow, const float* w, const float* bias, float* out, uint32_t* mask,
+                                int B, int num_cus, hipStream_t stream, int dbg = 0, bool tr = false) {
+    auto kern = mask ? c1fwd3_kernel<true> : c1fwd3_kernel<false>;
+    if (tr) kern = mask ? c1fwd3_kernel<true, 0, true> : c1fwd3_kernel<false, 0, true>;
+#ifdef MRL_C1_EXPERIMENTS
+    if (tr) switch (dbg) {
+        case 1: kern = c1fwd3_kernel<true, 1, true>; break;   case 2: kern = c1fwd3_kernel<true, 2, true>; break;
+        case 4: kern = c1fwd3_kernel<true, 4, true>; break;   case 8: kern = c1fwd3_kernel<true, 8, true>; break;
+        case 16: kern = c1fwd3_kernel<true, 16, true>; break; case 3: kern = c1fwd3_kernel<true, 3, true>; break;
+        case 31: kern = c1fwd3_kernel<true, 31, true>; break;
+        default: break;
+    } else
+    switch (dbg) {        // timing experiments: 1 no stores, 2 no MFMAs, 4 no global loads, 8 no staging, 16 no mask ballots
+        case 1: kern = c1fwd3_kernel<true, 1>; break;   case 2: kern = c1fwd3_kernel<true, 2>; break;
+        case 4: kern = c1fwd3_kernel<true, 4>; break;   case 8: kern = c1fwd3_kernel<true, 8>; break;
+        case 16: kern = c1fwd3_kernel<true, 16>; break; case 17: kern = c1fwd3_kernel<true, 17>; break;
+        case 29: kern = c1fwd3_kernel<true, 29>; break; case 31: kern = c1fwd3_kernel<true, 31>; break;
+        case 12: kern = c1fwd3_kernel<true, 12>; break; case 3: kern = c1fwd3_kernel<true, 3>; break;
+        default: break;
+    }
+#endif
+    hipError_t e0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e0 != hipSuccess) return e0;
+    const size_t lds = (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * C1_IMG16;          // 163584
+    const int grid = std::max(1, std::min(B, num_cus));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B);
+    return hipGetLastError();
 }
 
 // hp != nullptr: transposed-accumulator kernel, also writes the plane tensor of the output (pstride elements per plane)

@@ -368,7 +368,7 @@ static const OptionDef kOptions[] = {
     // ---- product options (include/mrl.h)
     {"u8_bf16x3", "MRL_U8_BF16X3", 1}, {"f32_bf16x6", "MRL_F32_BF16X6", 2}, {"mlp_fused", "MRL_MLP_FUSED", 1},
     {"heads_wave", "MRL_HEADS_WAVE", 1}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 1},
-    {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 2},
+    {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 4},
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 2}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1},
@@ -1385,9 +1385,12 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     // NatureCNN's first layer: image-resident kernel (c1fwd.hip.h) -- images reach LDS once, coalesced,
                     // instead of 16-byte per-lane gathers of overlapping patches
                     if (l.H == C1_H && l.W == C1_W && l.C == C1_C && l.rf == C1_RF && l.stride == C1_S && l.NF == C1_NF &&
-                        l.act == ACT_RELU && get_option("c1_lds", "MRL_C1_LDS", 2)) {
+                        l.act == ACT_RELU && get_option("c1_lds", "MRL_C1_LDS", 4)) {
                         if (mbits) { if (mwrote) *mwrote = 1; }
-                        if (get_option("c1_lds", "MRL_C1_LDS", 2) >= 2) {
+                        if ((get_option("c1_lds", "MRL_C1_LDS", 4) & 15) >= 3 && !hp_out && !(act_planes_mode() & 16))
+                            return (int)launch_c1fwd3(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st, get_option("c1_lds", "MRL_C1_LDS", 4) >> 4,
+                                                      (get_option("c1_lds", "MRL_C1_LDS", 4) & 15) >= 4);   // software-pipelined phases (4: transposed accumulators)
+                        if ((get_option("c1_lds", "MRL_C1_LDS", 4) & 15) >= 2) {
                             if (hp_out && hpwrote) *hpwrote = 1;
                             return (int)launch_c1fwd2(in.obs, in.srow, W, bias, hout, mbits, B, num_cus(), st, hp_out,
                                                       (long)B * l.out_elems, (act_planes_mode() & 16) != 0);

@@ -403,8 +403,12 @@ int mrl_tune_set(const char* label, int variant);
  *                  with >= 128 outputs (fc1), 2 = conv2 / conv3 too, 0 = image-resident / tiled fp32-MFMA engines
  *   "c1_wgrad2"   [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
  *                  (c1wgrad.hip.h): 2 = half-image work units, two workgroups per CU; 1 = whole images; 0 = per-byte gathers
- *   "c1_lds"      [MRL_C1_LDS, 2]  first conv layer forward on the image-resident engines: 2 = pixels converted to bf16 while
- *                  staged, two tiles per wave; 1 = uint8 images converted per fragment; 0 = weights-resident gather engine
+ *   "c1_lds"      [MRL_C1_LDS, 4]  first conv layer forward on the image-resident engines: 4 = one software pipeline per wave
+ *                  (the previous image's stores / mask words, the next image's conversion and LDS writes and the loads of the
+ *                  one after it are issued between the MFMAs of the current image), transposed accumulators with 16-byte
+ *                  stores; 3 = the same pipeline with row-major accumulators; 2 = the same arithmetic in lock-step phases
+ *                  (multiply, epilogue, stage, barrier); 1 = uint8 images converted per fragment; 0 = weights-resident gather
+ *                  engine.  4, 3 and 2 are bit-identical (same products, same order of accumulation).
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
  *   "fused_norm"  [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions

@@ -326,6 +326,7 @@ def test_engine_options_agree():
     assert defaults['tr_epilogue'] == 1, 'transposed-accumulator epilogues are the default'
     assert defaults['f32_bf16x6'] == 2 and L.get_option('f32_products') in (6, 8), 'split engines are the default'
     assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 / fc1 weight gradients: transpose-read kernels by default'
+    assert defaults['c1_lds'] == 4, 'first conv layer forward: software-pipelined image-resident kernel by default'
     if experiments:
         assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
     try:
@@ -362,8 +363,10 @@ def test_engine_options_agree():
                  ('split engines, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
                  ('split engines, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
                  ('split engines, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
-                 ('split engines, first conv layer forward: the other image-resident kernel',
-                  dict(defaults, c1_lds=3 - defaults['c1_lds']), 3e-6),
+                 ('split engines, first conv layer forward: lock-step phases instead of the software pipeline',
+                  dict(defaults, c1_lds=2), 3e-6),
+                 ('split engines, first conv layer forward: software pipeline with row-major accumulators', dict(defaults, c1_lds=3), 3e-6),
+                 ('split engines, first conv layer forward: uint8 image in LDS, converted per fragment', dict(defaults, c1_lds=1), 3e-6),
                  ('split engines, conv1 weight gradient: whole-image workgroups', dict(defaults, c1_wgrad2=1), 3e-6),
                  ('split engines, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
                   dict(defaults, wgrad_x8=0, wgrad_tr=0), 3e-6),
@@ -437,3 +440,36 @@ def test_precomputed_advantage_statistics_feed_the_fused_mlp_step_bit_identicall
         assert not torch.equal(g0, g1)
     finally:
         L.set_option('mlp_waves', old)
+
+
+@pytest.mark.parametrize('B', [1, 257, 4109])
+def test_conv1_forward_engines_are_bit_identical(B):
+    """The image-resident first-layer kernels (c1fwd.hip.h: software pipeline with transposed / row-major accumulators,
+    lock-step phases) form the same exact products in the same order: logits, values and the whole
+    gradient (it goes through the ReLU bit masks the forward writes) are bit-identical between them -- one image, a batch that
+    leaves persistent workgroups with 1-2 images and one with 16 (two peeled phases + the steady-state loop)."""
+    from baselines_amd import _lib as L
+    from baselines_amd import ops
+    old = L.get_option('c1_lds')
+    outs = []
+    try:
+        for v in (4, 3, 2):
+            L.set_option('c1_lds', v)
+            dm = ops.DeviceModel(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6, chunk=B)
+            r = np.random.RandomState(B)
+            params = dev((r.randn(dm.P) * 0.05).astype(np.float32))
+            obs = dev(r.randint(0, 256, (B, 84, 84, 4)).astype(np.uint8))
+            act = dev(r.randint(0, 6, B).astype(np.int32))
+            ret, val_, nlp = (dev(r.randn(B).astype(np.float32)) for _ in range(3))
+            nlp = nlp.abs() + 1.0
+            _, vv, _, pd = dm.act(params, obs, None, want_actions=False, want_pdparam=True)
+            g = torch.empty(dm.P, dtype=torch.float32, device='cuda')
+            st = torch.empty(5, dtype=torch.float32, device='cuda')
+            dm.grad(params, obs, act, ret, val_, nlp, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
+            outs.append((vv.cpu(), pd.cpu(), g.cpu(), st.cpu()))
+    finally:
+        L.set_option('c1_lds', old)
+    assert float(outs[0][2].abs().max()) > 0 and bool(torch.isfinite(outs[0][2]).all())
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
