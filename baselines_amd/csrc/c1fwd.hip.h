@@ -525,8 +525,8 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
                         if (gu >= 24 && gu % 6 == 0) epi_tr_mask(u, (gu - 24) / 6);
                     }
                     else if (gap % 3 == 0) epi_row(gap / 3);                          // 32 (16) rows over 96 (48) gaps
-                    if (gap % 3 == 1 && gap / 3 < 2 * NLD && !(DBG & 8)) stage_half(nxt, gap / 6, (gap / 3) & 1);   // gaps 1, 4, .. 22: 8 half chunks
-                    if (gap % 3 == 1 && gap / 3 >= 2 * NLD && gap / 3 < 3 * NLD && !(DBG & 4))
+                    if (gap % 3 == 1 && gap / 3 < 2 * NLD && !(DBG & 8) && !((DBG & 32) && TWO)) stage_half(nxt, gap / 6, (gap / 3) & 1);   // gaps 1, 4, .. 22: 8 half chunks
+                    if (gap % 3 == 1 && gap / 3 >= 2 * NLD && gap / 3 < 3 * NLD && !(DBG & 4) && !((DBG & 32) && TWO))
                         st[gap / 3 - 2 * NLD] = *reinterpret_cast<const c1_u32x4*>(gnext + (long)cidx[gap / 3 - 2 * NLD] * 16);
                     __builtin_amdgcn_sched_barrier(0);
                     ++slot;
@@ -637,7 +637,7 @@ inline hipError_t launch_c1fwd3(const void* obs, const int32_t* srow, const floa
         case 1: kern = c1fwd3_kernel<true, 1, true>; break;   case 2: kern = c1fwd3_kernel<true, 2, true>; break;
         case 4: kern = c1fwd3_kernel<true, 4, true>; break;   case 8: kern = c1fwd3_kernel<true, 8, true>; break;
         case 16: kern = c1fwd3_kernel<true, 16, true>; break; case 3: kern = c1fwd3_kernel<true, 3, true>; break;
-        case 31: kern = c1fwd3_kernel<true, 31, true>; break;
+        case 31: kern = c1fwd3_kernel<true, 31, true>; break; case 32: kern = c1fwd3_kernel<true, 32, true>; break;
         default: break;
     } else
     switch (dbg) {        // timing experiments: 1 no stores, 2 no MFMAs, 4 no global loads, 8 no staging, 16 no mask ballots

@@ -389,7 +389,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         params_synced = bool(torch.equal(lo, hi))
-    res = dict(value=total_envs * T * steps / dt, dt=dt, t_rollout=t_rollout, loss=[float(x) for x in lossvals], prof=prof,
+    res = dict(value=total_envs * T * steps / dt, dt=dt, steps=steps, P=int(model.dm.P), t_rollout=t_rollout, loss=[float(x) for x in lossvals], prof=prof,
                prof_steps=prof_steps, hp=hp, N=N, nbatch_train=nbatch_train, chunk=model.dm.chunk, graph_mode=graph_mode,
                model_tflops=flops_per_sample_visit * total_envs * T * hp['noptepochs'] * steps / dt / 1e12,
                native_dp=bool(getattr(model, 'native_dp', False)), device_state=device_state,
@@ -397,6 +397,91 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
     del runner, model, env, ro
     torch.cuda.empty_cache()
     return res
+
+
+TRACE_LABELS = (('mlp_step_kernel', 'mlp_step'), ('mlp_tail_kernel', 'mlp_tail'), ('reduce_slabs_kernel', 'reduce_slabs'),
+                ('adam_kernel', 'clip+adam'), ('mlp_advstat_kernel', 'advstat'), ('gae_kernel', 'gae'))
+
+
+def graph_kernel_trace(workload, num_envs, nsteps):
+    """Per-kernel execution times of a workload whose epochs run as REPLAYED hipGraphs (HIP events cannot be recorded inside a
+    graph, and an eager update with events around every 40-us kernel reports more than the replayed step takes): a child
+    `rocprofv3 --kernel-trace` run of this script on the same workload; the window = whole updates (gae kernel to gae kernel)
+    of the child's timed region.  -> ({label: {'ms_per_update', 'launches_per_update', 'avg_us'}}, child ms_per_step) or
+    (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found'
+    d = tempfile.mkdtemp(prefix='mrl_trace_', dir='/tmp')
+    try:
+        cmd = ['rocprofv3', '--kernel-trace', '-d', d, '-o', 't', '--', sys.executable, os.path.abspath(__file__), '--workload', workload,
+               '--num-envs', str(num_envs), '--nsteps', str(nsteps), '--steps', '4', '--warmup', '2', '--no-prof', '--no-cpu-baseline',
+               '--no-other-configs']
+        env = dict(os.environ, MRL_BENCH_SMI='0', TMPDIR='/tmp', MRL_BENCH_TRACE_CHILD='1')
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd='/tmp')
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+        if out.returncode != 0 or not lines:
+            return None, 'traced child run failed (rc %d): %s' % (out.returncode, out.stderr[-300:])
+        child = json.loads(lines[-1])
+        dbs = glob.glob(os.path.join(d, '**', '*.db'), recursive=True)
+        if not dbs:
+            return None, 'no rocpd database written'
+        rows = sqlite3.connect(dbs[0]).execute('select name, start, end from kernels order by start').fetchall()
+        gae = [i for i, r in enumerate(rows) if 'gae_kernel' in r[0]]
+        if len(gae) < 3:
+            return None, 'fewer than 3 updates in the trace'
+        lo, hi = gae[-1 - child['steps']], gae[-1]          # the child's timed updates: whole updates, gae kernel to gae kernel
+        nupd = child['steps']
+        agg = {}
+        for name, t0, t1 in rows[lo:hi]:
+            label = next((lab for key, lab in TRACE_LABELS if key in name), None)
+            if label is None:                              # torch's copy / elementwise kernels between the epochs
+                label = 'other:' + name.split('(')[0].split('<')[0].split('::')[-1][-40:]
+            a = agg.setdefault(label, [0, 0.0])
+            a[0] += 1
+            a[1] += (t1 - t0) * 1e-6
+        res = {k: {'ms_per_update': v[1] / nupd, 'launches_per_update': v[0] / float(nupd), 'avg_us': v[1] / v[0] * 1e3}
+               for k, v in agg.items()}
+        return res, child['ms_per_step']
+    except Exception as exc:
+        return None, repr(exc)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def apply_graph_trace(res, workload, total_envs, T):
+    """graph-mode workloads: replace the eager per-kernel times in res['prof'] by the kernel trace of the replayed graphs (the
+    eager run keeps supplying each label's flops / bytes per launch); never leaves a breakdown that exceeds its own step"""
+    if not res.get('graph_mode') or not res.get('prof') or os.environ.get('MRL_BENCH_TRACE_CHILD'):
+        return
+    eager = res['prof']
+    tr, info = graph_kernel_trace(workload, total_envs, T) if os.environ.get('MRL_BENCH_GRAPH_TRACE', '1') != '0' else (None, 'disabled')
+    if tr:
+        prof = {}
+        for label, v in tr.items():
+            e = eager.get(label, {'count': 0, 'flops': 0.0, 'bytes': 0.0})
+            per = (e['flops'] / e['count'], e['bytes'] / e['count']) if e['count'] else (0.0, 0.0)
+            n = v['launches_per_update']
+            prof[label] = {'ms': v['ms_per_update'], 'count': n, 'flops': per[0] * n, 'bytes': per[1] * n}
+        res['prof'], res['prof_steps'] = prof, 1
+        res['kernel_times_source'] = ('rocprofv3 --kernel-trace of a child run of the same workload (replayed epoch graphs), whole '
+                                      'updates of its timed region; that run took %.3f ms per update' % info)
+        res['traced_ms_per_step'] = info
+        tot = sum(v['ms'] for v in prof.values())
+        assert tot <= info * 1.001, ('kernel trace exceeds its own run', tot, info)
+    else:
+        # no trace: the eager update's shares, scaled onto the timed graph-replay step (its kernels take longer with an event
+        # pair around each of them than inside the replayed graph)
+        tot = sum(v['ms'] for v in eager.values()) / max(1, res['prof_steps'])
+        step = res['dt'] / res['steps'] * 1e3
+        scale = min(1.0, step / tot) if tot > 0 else 1.0
+        for v in eager.values():
+            v['ms'] *= scale
+        res['kernel_times_source'] = ('one eager update with HIP events after the timed region, times scaled by %.3f onto the '
+                                      'replayed step (no kernel trace: %s)' % (scale, info))
 
 
 class DeviceStateSampler:
@@ -438,6 +523,14 @@ class DeviceStateSampler:
                 'source': 'rocm-smi --showclocks --showpower on a host thread during the timed region'}
 
 
+def check_breakdown(kernel_ms, ms_per_step, roof, what):
+    """a per-kernel breakdown is evidence only if it fits inside the step it was measured in"""
+    tot = sum(kernel_ms.values())
+    assert tot <= ms_per_step * 1.002 + 0.01, ('%s: kernel times sum to %.3f ms of a %.3f ms step' % (what, tot, ms_per_step))
+    if roof and roof.get('avg_ms') and roof.get('launches'):
+        assert roof['avg_ms'] * roof['launches'] <= ms_per_step * max(1, roof.get('prof_steps', 1)) * 1.002 + 0.01, (what, roof['avg_ms'], roof['launches'])
+
+
 def dominant_roofline(res, sites, workload):
     """roofline object of the kernel with the largest share of the timed region"""
     prof = res['prof']
@@ -450,6 +543,7 @@ def dominant_roofline(res, sites, workload):
     dom = max(per, key=lambda k: prof[k]['ms'])
     roof = dict(per[dom])
     roof['kernel'] = dom
+    roof['prof_steps'] = res['prof_steps']           # `launches` are counted over this many timed steps
     roof.setdefault('traffic', None)
     roof['share_of_kernel_time'] = prof[dom]['ms'] / tot_ms
     # HBM-side bytes per launch: PMC counters cannot be collected from inside this process; they come from the committed
@@ -546,6 +640,7 @@ def main():
 
     if rank == 0:
         hp = res['hp']
+        apply_graph_trace(res, args.workload, total_envs, T)
         roof, per = dominant_roofline(res, sites, args.workload)
         ds = res.get('device_state')
         if roof and ds and roof.get('bound') == 'mfma' and ds.get('sclk_mhz_median'):
@@ -576,10 +671,12 @@ def main():
             out['params_synced_across_ranks'] = res.get('params_synced')
             out['config']['native_dp'] = res.get('native_dp')
         if res['graph_mode']:
-            out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps); kernel times from a separate eager update'
+            out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps)'
+            out['kernel_times_source'] = res.get('kernel_times_source')
         if res['prof']:
             out['kernel_ms_per_step'] = {k: round(v['ms'] / res['prof_steps'], 3) for k, v in
                                          sorted(res['prof'].items(), key=lambda kv: -kv[1]['ms'])}
+            check_breakdown(out['kernel_ms_per_step'], res.get('traced_ms_per_step') or out['ms_per_step'], roof, out['config']['workload'])
             out['kernel_rooflines'] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                        for k, v in per.items()}
         default_run = (world == 1 and args.workload == 'atari' and args.num_envs is None and args.nsteps == 128
@@ -587,18 +684,34 @@ def main():
         if default_run and not args.no_other_configs:
             # BASELINE.json's other single-GPU configurations, short runs (3 timed updates each), own rooflines
             others = []
-            for wl, n_envs in (('mujoco', 1024), ('atari', 256), ('atari_lstm', 256)):
+            for wl, n_envs in (('mujoco', 1024), ('atari', 256), ('atari', 512), ('atari_lstm', 256)):
                 nst, nwu = (12, 3) if wl == 'mujoco' else (3, 1)      # the 28 ms MLP update needs a longer window to time stably
                 r = run_ppo2(wl, n_envs, 128, nst, nwu, None, 1, 0, None, not args.no_prof)
+                apply_graph_trace(r, wl, n_envs, 128)
                 rf, _ = dominant_roofline(r, sites, wl)
-                others.append({'workload': 'ppo2 update-only %s-shaped %s num_envs=%d nsteps=128'
-                                           % (wl.split('_')[0], r['hp']['network'], n_envs),
-                               'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['dt'] / nst * 1e3, 'steps': nst,
-                               'device_state': r.get('device_state'),          # this configuration's own rocm-smi samples
-                               'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / nst),
-                               'roofline': rf,
-                               'kernel_ms_per_step': {k: round(v['ms'] / r['prof_steps'], 3) for k, v in
-                                                      sorted(r['prof'].items(), key=lambda kv: -kv[1]['ms'])}})
+                name = 'ppo2 update-only %s-shaped %s num_envs=%d nsteps=128' % (wl.split('_')[0], r['hp']['network'], n_envs)
+                if wl == 'atari' and n_envs == 512:
+                    # what ONE rank of BASELINE config 4 computes per update (4096 envs sharded over 8 GPUs: 512 envs, 16384-sample
+                    # minibatches); the 8-GPU job adds 16 all-reduces of the 6.75 MB flat gradient per update, overlapped with the
+                    # conv layers' backward pass
+                    name += " (config 4's per-GPU shard: minibatch 16384)"
+                row = {'workload': name,
+                       'value': r['value'], 'unit': 'env-steps/s', 'ms_per_step': r['dt'] / nst * 1e3, 'steps': nst,
+                       'device_state': r.get('device_state'),          # this configuration's own rocm-smi samples
+                       'full_iteration_env_steps_per_s': n_envs * 128 / (r['t_rollout'] + r['dt'] / nst),
+                       'roofline': rf,
+                       'kernel_ms_per_step': {k: round(v['ms'] / r['prof_steps'], 3) for k, v in
+                                              sorted(r['prof'].items(), key=lambda kv: -kv[1]['ms'])}}
+                if r.get('kernel_times_source'):
+                    row['kernel_times_source'] = r['kernel_times_source']
+                if wl == 'atari' and n_envs == 512:
+                    row['projection_8_gpus'] = {
+                        'per_gpu_update_ms': row['ms_per_step'], 'allreduce_bytes_per_minibatch_step': 4 * r['P'],
+                        'whole_job_env_steps_per_s_if_the_allreduce_hides': 4096 * 128 / (row['ms_per_step'] * 1e-3),
+                        'note': 'upper bound from the measured single-GPU shard; the driver measures the real 8-GPU number'}
+                if r['prof']:
+                    check_breakdown(row['kernel_ms_per_step'], r.get('traced_ms_per_step') or row['ms_per_step'], rf, name)
+                others.append(row)
             others.append(replay_config())
             out['other_configs'] = others
         if world == 1 and not args.no_cpu_baseline and args.workload in ('atari', 'mujoco'):

@@ -17,11 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks_one_json_line_and_synced_parameters():
+@pytest.mark.parametrize('num_envs', [64, 1024])
+def test_bench_two_ranks_one_json_line_and_synced_parameters(num_envs):
+    """num_envs=1024: 512 envs per rank -> 16384-sample minibatches, i.e. every rank runs the engines of the benched shapes
+    (tiled split engines need B >= 1024)"""
     env = dict(os.environ, MRL_BENCH_BACKEND='gloo', MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--num-envs', '64',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--num-envs', str(num_envs),
            '--no-cpu-baseline', '--no-other-configs']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -29,7 +32,7 @@ def test_bench_two_ranks_one_json_line_and_synced_parameters():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['world_size_observed'] == 2
-    assert d['config']['envs_per_gpu'] == 32 and d['scaling'] == 'strong'
+    assert d['config']['envs_per_gpu'] == num_envs // 2 and d['scaling'] == 'strong'
     assert d['metric'].startswith('env-steps/sec') and d['value'] > 0
     assert all(abs(x) < 1e6 and x == x for x in d['loss'])                   # finite
     assert d['params_synced_across_ranks'] is True
