@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.hip.h"
 
@@ -205,6 +206,137 @@ __global__ __launch_bounds__(4 * NH) void lstm_bwd_kernel(LstmBwdArgs a) {
             }
             __syncthreads();
         }
+    }
+}
+
+// ---- one environment per workgroup (round 4).  A step of the scans above costs a workgroup ~3.7 us whatever it carries:
+// 128 dependent 4x4x1 MFMAs per wave are 2048 matrix-pipe cycles per SIMD, for four environments or for one, and a
+// 64-environment minibatch (cnn_lstm, N = 256, 4 minibatches) is 16 workgroups on 256 CUs.  With ONE environment per
+// workgroup the product h@wh is 128 plain fmaf per thread (512 VALU cycles per wave, half the matrix-pipe time of the
+// 4x4x1 form, which computes four rows whether they are used or not), 64 workgroups run side by side, and the thread that
+// owns unit k in the element-wise phases is the same in every phase, so the masked state moves to the next step in
+// registers: two barriers per step instead of three.  Same fmaf chains in the same k order, same gate functions: the
+// results are bit-identical to lstm_fwd_kernel / lstm_bwd_kernel.  Chosen by the launchers when the scan is long and
+// groups of four environments would leave CUs idle.
+template <int NH>
+__global__ __launch_bounds__(4 * NH) void lstm_fwd1_kernel(LstmFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float h_s[NH];
+    __shared__ float g_s[4 * NH];
+    const unsigned j = threadIdx.x;
+    constexpr unsigned N4 = 4u * NH;
+    float w[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) w[k] = a.wh[(unsigned)k * N4 + j];
+    const float bj = a.bias[j];
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    const bool unit = j < (unsigned)NH;                   // this thread also owns unit j of the element-wise phases
+    for (unsigned env = blockIdx.x; env < nenv; env += gridDim.x) {
+        float c = 0.f, hreg = 0.f;
+        if (unit && a.s0) { c = a.s0[env * 2u * NH + j]; hreg = a.s0[env * 2u * NH + NH + j]; }
+        if (unit) {                                       // mask of step 0 (a2c/utils.py:89-90)
+            const unsigned b = env * T;
+            const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+            c *= keep; hreg *= keep;
+            h_s[j] = hreg;
+            if (a.cm) { a.cm[b * NH + j] = c; a.hm[b * NH + j] = hreg; }
+        }
+        __syncthreads();
+        for (unsigned t = 0; t < T; ++t) {
+            const unsigned b = env * T + t;
+            const float zxv = a.zx[b * N4 + j];                                   // in flight during the product
+            uint8_t mnext = 0;
+            if (unit && t + 1 < T) mnext = a.mask[a.srow ? (unsigned)a.srow[b + 1] : b + 1];
+            float acc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < NH; k4 += 4) {
+                const float4 hv = *reinterpret_cast<const float4*>(h_s + k4);     // broadcast read
+                acc = fmaf(hv.x, w[k4], acc);
+                acc = fmaf(hv.y, w[k4 + 1], acc);
+                acc = fmaf(hv.z, w[k4 + 2], acc);
+                acc = fmaf(hv.w, w[k4 + 3], acc);
+            }
+            const float z = (zxv + acc) + bj;                                     // (x@wx + h@wh) + b, the reference's order
+            const float gv = j < 3 * NH ? lstm_sigmoid(z) : tanhf(z);
+            g_s[j] = gv;
+            if (a.gates) a.gates[b * N4 + j] = gv;
+            __syncthreads();
+            if (unit) {
+                const float iv = g_s[j], fv = g_s[NH + j], ov = g_s[2 * NH + j], uv = g_s[3 * NH + j];
+                c = fv * c + iv * uv;
+                const float tcv = tanhf(c);
+                hreg = ov * tcv;
+                if (a.tc) a.tc[b * NH + j] = tcv;
+                a.hout[b * NH + j] = hreg;
+                if (t + 1 < T) {                          // the next step's mask, applied here: its masked state is this phase's output
+                    const float keep = mnext ? 0.f : 1.f;
+                    c *= keep; hreg *= keep;
+                    if (a.cm) { a.cm[(b + 1) * NH + j] = c; a.hm[(b + 1) * NH + j] = hreg; }
+                }
+                h_s[j] = hreg;
+            }
+            __syncthreads();
+        }
+        if (a.s_out && unit) {
+            a.s_out[env * 2u * NH + j] = c;
+            a.s_out[env * 2u * NH + NH + j] = hreg;
+        }
+    }
+}
+
+template <int NH>
+__global__ __launch_bounds__(4 * NH) void lstm_bwd1_kernel(LstmBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dz_s[4 * NH];
+    __shared__ float p_s[4][NH];
+    const unsigned tid = threadIdx.x;
+    const unsigned k = tid % NH, q4 = tid / NH;
+    constexpr unsigned N4 = 4u * NH;
+    float w[NH];                                  // wh[k][q4*NH + jj]
+#pragma unroll
+    for (int jj = 0; jj < NH; ++jj) w[jj] = a.wh[k * N4 + q4 * NH + jj];
+    const unsigned T = (unsigned)a.T, nenv = (unsigned)a.nenv;
+    const bool unit = tid < (unsigned)NH;         // owner of unit tid in the element-wise phase
+    for (unsigned env = blockIdx.x; env < nenv; env += gridDim.x) {
+        float dhc = 0.f, dcc = 0.f;               // dL/dh and dL/dc carried from step t+1 (this thread's unit)
+        for (int ti = (int)T - 1; ti >= 0; --ti) {
+            const unsigned b = env * T + (unsigned)ti;
+            if (unit) {
+                const float* gr = a.gates + b * N4;
+                const float iv = gr[tid], fv = gr[NH + tid], ov = gr[2 * NH + tid], uv = gr[3 * NH + tid];
+                const float tcv = a.tc[b * NH + tid], cmv = a.cm[b * NH + tid];
+                const float dh = dhc + a.dhout[b * NH + tid];
+                const float dov = dh * tcv;
+                const float dc = dcc + dh * ov * (1.f - tcv * tcv);
+                const float dzi = (dc * uv) * iv * (1.f - iv);
+                const float dzf = (dc * cmv) * fv * (1.f - fv);
+                const float dzo = dov * ov * (1.f - ov);
+                const float dzu = (dc * iv) * (1.f - uv * uv);
+                float* dst = a.dzg + b * N4;
+                dst[tid] = dzi; dst[NH + tid] = dzf; dst[2 * NH + tid] = dzo; dst[3 * NH + tid] = dzu;
+                dz_s[tid] = dzi; dz_s[NH + tid] = dzf; dz_s[2 * NH + tid] = dzo; dz_s[3 * NH + tid] = dzu;
+                dcc = dc * fv;                    // (* keep below, with dh)
+            }
+            __syncthreads();
+            // p[q4][k] = sum_jj dz[q4*NH + jj] * wh[k][q4*NH + jj]: the lanes of a wave share q4 -> broadcast reads
+            float acc = 0.f;
+            const float* drow = dz_s + q4 * NH;
+#pragma unroll
+            for (int j4 = 0; j4 < NH; j4 += 4) {
+                const float4 dv = *reinterpret_cast<const float4*>(drow + j4);
+                acc = fmaf(dv.x, w[j4], acc);
+                acc = fmaf(dv.y, w[j4 + 1], acc);
+                acc = fmaf(dv.z, w[j4 + 2], acc);
+                acc = fmaf(dv.w, w[j4 + 3], acc);
+            }
+            p_s[q4][k] = acc;
+            __syncthreads();
+            if (unit) {
+                const float keep = a.mask[a.srow ? (unsigned)a.srow[b] : b] ? 0.f : 1.f;
+                dhc = ((p_s[0][tid] + p_s[1][tid]) + (p_s[2][tid] + p_s[3][tid])) * keep;
+                dcc = dcc * keep;
+            }
+            // (p_s is rewritten only behind the next step's first barrier, dz_s only by the unit owners that have just read p_s)
+        }
+        __syncthreads();
     }
 }
 
@@ -639,10 +771,21 @@ inline hipError_t launch_lnlstm_bwd(const LnLstmBwdArgs& p, int nh, int num_cus,
 inline bool lstm_nh_fast(int nh) { return nh == 32 || nh == 64 || nh == 96 || nh == 128; }
 inline bool lstm_nh_ok(int nh) { return nh >= 1 && nh <= 1024; }
 
+inline int& lstm_e1() { static int v = getenv("MRL_LSTM_E1") ? atoi(getenv("MRL_LSTM_E1")) : 1; return v; }     // mrl_set_option "lstm_e1"
+// one environment per workgroup: long scans whose groups of four environments would leave CUs idle
+inline bool lstm_use_e1(int nenv, int T, int nh, int num_cus) {
+    return lstm_e1() && (nh == 128 || nh == 64) && T >= 8 && (nenv + 3) / 4 < num_cus;
+}
 inline hipError_t launch_lstm_fwd(const LstmFwdArgs& a, int nh, int num_cus, hipStream_t st) {
     constexpr int E = 4;
     const int groups = (a.nenv + E - 1) / E;
     const int blocks = std::max(1, std::min(groups, 2 * num_cus));
+    if (lstm_use_e1(a.nenv, a.T, nh, num_cus)) {
+        const int b1 = std::max(1, std::min(a.nenv, 2 * num_cus));
+        if (nh == 128) hipLaunchKernelGGL((lstm_fwd1_kernel<128>), dim3(b1), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((lstm_fwd1_kernel<64>), dim3(b1), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (!lstm_nh_fast(nh)) {
         if (!lstm_nh_ok(nh)) return hipErrorInvalidValue;
         const int threads = std::min(1024, (4 * nh + 63) / 64 * 64);
@@ -660,6 +803,12 @@ inline hipError_t launch_lstm_bwd(const LstmBwdArgs& a, int nh, int num_cus, hip
     constexpr int E = 4;
     const int groups = (a.nenv + E - 1) / E;
     const int blocks = std::max(1, std::min(groups, 2 * num_cus));
+    if (lstm_use_e1(a.nenv, a.T, nh, num_cus)) {
+        const int b1 = std::max(1, std::min(a.nenv, 2 * num_cus));
+        if (nh == 128) hipLaunchKernelGGL((lstm_bwd1_kernel<128>), dim3(b1), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((lstm_bwd1_kernel<64>), dim3(b1), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (!lstm_nh_fast(nh)) {
         if (!lstm_nh_ok(nh)) return hipErrorInvalidValue;
         const int threads = std::min(1024, (E * nh + 63) / 64 * 64);

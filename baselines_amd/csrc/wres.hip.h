@@ -477,6 +477,12 @@ constexpr bool kCross21 = false;
 constexpr int kSplitProducts = kCross21 ? 8 : 6;
 // two floats -> three packed bf16 pairs (plane 0 / 1 / 2; x0 in the low half)
 __device__ __forceinline__ void split2_bf16x3(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+#ifdef MRL_FAKE_SPLIT      // timing experiment only (wrong results): 3 instead of 15 VALU instructions per pair
+    p0 = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    p1 = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x05040100u);
+    p2 = p0 ^ p1;
+    return;
+#endif
     const uint32_t t0 = __float_as_uint(x0) + 0x8000u, t1 = __float_as_uint(x1) + 0x8000u;
     p0 = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
     const float r0 = x0 - __uint_as_float(t0 & 0xffff0000u), r1 = x1 - __uint_as_float(t1 & 0xffff0000u);

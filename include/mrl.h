@@ -412,6 +412,9 @@ int mrl_tune_set(const char* label, int variant);
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
  *   "fused_norm"  [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
+ *   "lstm_e1"     [MRL_LSTM_E1, 1]  LSTM scans of long trajectories with ONE environment per workgroup (plain fmaf chains, two
+ *                  barriers per step) when groups of four environments would leave CUs idle; 0 = always four per workgroup
+ *                  (4x4x1 MFMA form).  Bit-identical.
  *   "mlp_fused"   [MRL_MLP_FUSED, 1]  whole-step kernel for the 2 x 64 tanh MLP; 0 = layer-wise launches
  *   "mlp_waves"   [MRL_MLP_WAVES, 8]  waves per workgroup of that kernel (8 | 4)
  *   "mlp_slice"   [MRL_MLP_SLICE, 1]  separate policy / value nets: one workgroup per (32-sample tile, net) instead of one per

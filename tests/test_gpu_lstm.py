@@ -215,3 +215,37 @@ def test_recurrent_model_reference_signature_host_env():
     stats = model.train(3e-4, 0.2, obs[flat], returns[flat], masks[flat], actions[flat], values[flat], neglogpacs[flat],
                         states[envinds])
     assert len(stats) == 5 and np.all(np.isfinite(stats)) and stats[3] < 1e-9     # same policy as the rollout: approxkl 0
+
+
+@pytest.mark.parametrize('nh,nseq,T', [(128, 9, 16), (64, 5, 33), (128, 64, 128)])
+def test_one_environment_per_workgroup_scans_are_bit_identical(nh, nseq, T):
+    """option lstm_e1 (csrc/lstm.hip.h lstm_fwd1_kernel / lstm_bwd1_kernel): the scans with one environment per workgroup
+    (plain fmaf chains in k order, the masked state carried in registers) against the four-environment 4x4x1-MFMA scans --
+    same chains, same gate functions: statistics and every gradient entry bit-identical (a2c/utils.py:81-102)."""
+    from baselines_amd import _lib as L
+    from baselines_amd import ops
+    B = nseq * T
+    rng = np.random.RandomState(nh + T)
+    dm = ops.DeviceModel(network='lstm', ob_shape=(24,), ob_dtype=np.float32, pd_kind='categorical', nact=4, nlstm=nh, chunk=B)
+    params = dev((rng.randn(dm.P) * 0.1).astype(np.float32))
+    obs = dev(rng.randn(B, 24).astype(np.float32))
+    masks = rng.rand(B) < 0.05
+    masks[0] = True
+    act = dev(rng.randint(0, 4, B).astype(np.int32))
+    ret, val_ = dev(rng.randn(B).astype(np.float32)), dev(rng.randn(B).astype(np.float32))
+    nlp = dev((np.log(4.0) + 0.1 * rng.randn(B)).astype(np.float32))
+    S0 = dev((0.5 * rng.randn(nseq, 2 * nh)).astype(np.float32))
+    d_m = dev(masks.view(np.uint8))
+    old = L.get_option('lstm_e1')
+    outs = []
+    try:
+        for v in (1, 0):
+            L.set_option('lstm_e1', v)
+            g = torch.empty(dm.P, dtype=torch.float32, device='cuda')
+            st = torch.empty(5, dtype=torch.float32, device='cuda')
+            dm.grad_rnn(params, obs, act, ret, val_, nlp, d_m, S0, nseq, None, B, 1, 1, 0.2, 0.01, 0.5, g, st)
+            outs.append((g.cpu(), st.cpu()))
+    finally:
+        L.set_option('lstm_e1', old)
+    assert float(outs[0][0].abs().max()) > 0 and bool(torch.isfinite(outs[0][0]).all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
