@@ -252,7 +252,9 @@ constexpr size_t CH_LDS = (size_t)CH_TBYTES + (size_t)3 * CH_PLANE * 2;       //
 constexpr int CH_NT = 256;
 constexpr int CH_NB = 13;                                // blocks of 16 pixels: 25 octets, the 26th is empty
 
-template <int DBG = 0>
+// PF2: the loads of unit u + 2 are issued while unit u is staged (two register sets, the unit loop unrolled by two): a
+// unit's 40 KB have two unit times to arrive instead of one MFMA phase (~1.3 us, about the loaded HBM latency).
+template <int DBG = 0, bool PF2 = false>
 __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
                                                                 const float* __restrict__ dz, int B, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) uint8_t cws[];
@@ -269,22 +271,22 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
     const int img_off = (iy * C1_W + 16 * iq) * C1_C;
     const bool dz_on = tid < 200;
     const int d_o = dz_on ? tid >> 3 : 0, d_nc = tid & 7;
-    u32x4v vi[5];
-    float4 vd[8];
+    u32x4v viA[5], viB[PF2 ? 5 : 1];
+    float4 vdA[8], vdB[PF2 ? 8 : 1];
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch_img = [&](long row, int half) {
+    auto fetch_img = [&](u32x4v* vi, long row, int half) {
         const uint8_t* gi = obs + row * C1_IMG + half * (40 * C1_W * C1_C) + img_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) vi[j] = *reinterpret_cast<const u32x4v*>(gi + 16 * j);
         if (img_tail) vi[4] = *reinterpret_cast<const u32x4v*>(gi + 64);
     };
-    auto fetch_dz = [&](int b, int half) {
+    auto fetch_dz = [&](float4* vd, int b, int half) {
         const float* gd = dz + ((long)b * C1_PIX + half * 200 + 8 * d_o) * C1_NF + 4 * d_nc;
 #pragma unroll
         for (int r = 0; r < 8; ++r) vd[r] = *reinterpret_cast<const float4*>(gd + r * C1_NF);
     };
     auto image_row = [&](int u) { return (u >> 1) < B ? (srow ? (long)srow[u >> 1] : (long)(u >> 1)) : 0L; };
-    auto stage_img = [&]() {
+    auto stage_img = [&](const u32x4v* vi) {
         if (img_on && !(DBG & 16)) {
             uint8_t* d = T + iy * CW_TROW + 8 * iq;
 #pragma unroll
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
             }
         }
     };
-    auto stage_dz = [&]() {
+    auto stage_dz = [&](const float4* vd) {
         if (dz_on && !(DBG & 32)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -358,22 +360,8 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
     }
 
     const int nunits = 2 * B;
-    int u = blockIdx.x;
-    long row_next = image_row(u + gridDim.x);
-    if (u < nunits && !(DBG & 4)) { fetch_img(image_row(u), u & 1); fetch_dz(u >> 1, u & 1); }
-    for (; u < nunits; u += gridDim.x) {
-        const int un = u + gridDim.x;
-        const bool more = un < nunits && !(DBG & 4);
-        __syncthreads();                                   // previous unit fully consumed
-        if (!(DBG & 2)) stage_img();
-        if (more) fetch_img(row_next, un & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(DBG & 2)) stage_dz();
-        if (more) fetch_dz(un >> 1, un & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        row_next = image_row(u + 2 * gridDim.x);
-        if (DBG & 1) continue;
+    const int G = gridDim.x;
+    auto mfma_phase = [&]() {
         __builtin_amdgcn_s_setprio(1);                     // the MFMA phase outranks the co-resident workgroup's staging pass
         __builtin_amdgcn_sched_barrier(0);
         uint32_t raw[2][NA][6];
@@ -412,6 +400,34 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
+    };
+    // one unit: stage the registers of set (vi, vd), refill them with unit `un` (clamped: past the end a valid unit is
+    // re-read and never staged), multiply
+    auto unit_step = [&](u32x4v* vi, float4* vd, int un) {
+        const int uc = min(un, nunits - 1);
+        __syncthreads();                                   // previous unit fully consumed
+        if (!(DBG & 2)) stage_img(vi);
+        if (!(DBG & 4)) fetch_img(vi, image_row(uc), uc & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 2)) stage_dz(vd);
+        if (!(DBG & 4)) fetch_dz(vd, uc >> 1, uc & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (!(DBG & 1)) mfma_phase();
+    };
+    int u = blockIdx.x;
+    if constexpr (PF2) {
+        if (u < nunits) {
+            { const int uc = u; fetch_img(viA, image_row(uc), uc & 1); fetch_dz(vdA, uc >> 1, uc & 1); }
+            { const int uc = min(u + G, nunits - 1); fetch_img(viB, image_row(uc), uc & 1); fetch_dz(vdB, uc >> 1, uc & 1); }
+        }
+        for (; u < nunits; u += 2 * G) {
+            unit_step(viA, vdA, u + 2 * G);
+            if (u + G < nunits) unit_step(viB, vdB, u + 3 * G);
+        }
+    } else {
+        if (u < nunits && !(DBG & 4)) { fetch_img(viA, image_row(u), u & 1); fetch_dz(vdA, u >> 1, u & 1); }
+        for (; u < nunits; u += G) unit_step(viA, vdA, u + G);
     }
 
     // ---- partial slab of this workgroup: [K][NF] weights / 255, then [NF] bias
@@ -440,14 +456,10 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
 }
 
 inline hipError_t launch_c1wgrad_half(const void* obs, const int32_t* srow, const float* dz, int B, float* part, int nblocks,
-                                      hipStream_t stream) {
-    auto kern = c1wgrad_half_kernel<0>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+                                      hipStream_t stream, bool pf2 = false) {
+    auto kern = pf2 ? c1wgrad_half_kernel<0, true> : c1wgrad_half_kernel<0, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CH_NT), CH_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part);
     return hipGetLastError();
 }

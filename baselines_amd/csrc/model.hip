@@ -369,7 +369,7 @@ static const OptionDef kOptions[] = {
     {"u8_bf16x3", "MRL_U8_BF16X3", 1}, {"f32_bf16x6", "MRL_F32_BF16X6", 2}, {"mlp_fused", "MRL_MLP_FUSED", 1},
     {"heads_wave", "MRL_HEADS_WAVE", 1}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 1},
     {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 4},
-    {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 2}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
+    {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1},
 #ifdef MRL_X6_EXPERIMENTS
@@ -1329,7 +1329,7 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
     hipError_t e;
     const int nacc = kExp ? get_option("imgres_nacc", "MRL_IMGRES_NACC", 0) : 0;   // accumulator replicas per wave (experiment knob)
     const int x3 = get_option("u8_bf16x3", "MRL_U8_BF16X3", 1);          // 0: fp32 MFMA path for the u8 layer
-    if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 2)) {
+    if (kind == 1 && x3 && !hcur && get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3)) {
         e = launch_c1wgrad(x, srow, dz, B, part, nblocks, st, std::max(0, dbg_option("c1_dbg", "MRL_C1_DBG") - 32));       // both operands transposed while staged (c1wgrad.hip.h)
     } else if (kind == 1 && x3 && !hcur) {
         e = launch_imgres_u8x3_wgrad<84, 84, 4, 8, 4, 32>(x, srow, dz, B, part, nblocks, st);
@@ -1698,7 +1698,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             rc = reduce_slabs(ws.part, slab, wx.nslab, grads + l.w_off, slab, accumulate, st, &ctx);
             if (rc) return rc;
         } else if (ik == 1 && first && !tuned(l, "wgrad") && get_option("u8_bf16x3", "MRL_U8_BF16X3", 1) &&
-                   get_option("c1_wgrad2", "MRL_C1_WGRAD2", 2) >= 2) {
+                   get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 2) {
             // conv1: half-image work units, two 4-wave workgroups per CU (c1wgrad.hip.h)
             int nblocks = (int)std::min<long>(std::min<long>(2L * num_cus(), 2L * B), (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;
@@ -1706,7 +1706,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
                 ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
-                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, st);
+                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, st, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3);
                 if (e != hipSuccess) return (int)e;
             }
             rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);

@@ -401,8 +401,10 @@ int mrl_tune_set(const char* label, int variant);
  *                  reads; needs f32_bf16x6 != 0); 0 = "wgrad_x8" / fp32-MFMA engines
  *   "wgrad_x8"    [MRL_WGRAD_X8, 1]  (wgrad_tr = 0) weight gradients on the transposed-staging tiles of wgradx8.hip.h: 1 = layers
  *                  with >= 128 outputs (fc1), 2 = conv2 / conv3 too, 0 = image-resident / tiled fp32-MFMA engines
- *   "c1_wgrad2"   [MRL_C1_WGRAD2, 2]  first conv layer weight gradient with both operands transposed while staged
- *                  (c1wgrad.hip.h): 2 = half-image work units, two workgroups per CU; 1 = whole images; 0 = per-byte gathers
+ *   "c1_wgrad2"   [MRL_C1_WGRAD2, 3]  first conv layer weight gradient with both operands transposed while staged
+ *                  (c1wgrad.hip.h): 3 = half-image work units, two workgroups per CU, operand loads two units ahead (two
+ *                  register sets); 2 = the same, one unit ahead; 1 = whole images; 0 = per-byte gathers.  3 and 2 are
+ *                  bit-identical.
  *   "c1_lds"      [MRL_C1_LDS, 4]  first conv layer forward on the image-resident engines: 4 = one software pipeline per wave
  *                  (the previous image's stores / mask words, the next image's conversion and LDS writes and the loads of the
  *                  one after it are issued between the MFMAs of the current image), transposed accumulators with 16-byte

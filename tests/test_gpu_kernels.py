@@ -368,6 +368,7 @@ def test_engine_options_agree():
                  ('split engines, first conv layer forward: software pipeline with row-major accumulators', dict(defaults, c1_lds=3), 3e-6),
                  ('split engines, first conv layer forward: uint8 image in LDS, converted per fragment', dict(defaults, c1_lds=1), 3e-6),
                  ('split engines, conv1 weight gradient: whole-image workgroups', dict(defaults, c1_wgrad2=1), 3e-6),
+                 ('split engines, conv1 weight gradient: half-image units, operand loads one unit ahead', dict(defaults, c1_wgrad2=2), 3e-6),
                  ('split engines, weight gradients of conv2 / conv3 / fc1 on the fp32 MFMA engines',
                   dict(defaults, wgrad_x8=0, wgrad_tr=0), 3e-6),
                  ('split engines, conv2 / conv3 weight gradients on the fp32-MFMA image-resident engine, fc1 on the transposed-staging tiles',
