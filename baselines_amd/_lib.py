@@ -18,7 +18,8 @@ class ModelDesc(ctypes.Structure):
     """mirror of mrl_model_desc (include/mrl.h)"""
     _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
                 ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('value_copy', c_int),
-                ('pd_kind', c_int), ('nact', c_int), ('nlstm', c_int), ('layer_norm', c_int)]
+                ('pd_kind', c_int), ('nact', c_int), ('nlstm', c_int), ('layer_norm', c_int),
+                ('nconv', c_int), ('convs', (c_int * 3) * 4), ('fc_hidden', c_int), ('conv_pad', c_int)]
 
 
 NET_MLP, NET_NATURE_CNN, NET_LSTM, NET_CNN_LSTM, NET_CONV_ONLY = 0, 1, 2, 3, 4

@@ -2,8 +2,8 @@
 looked up by name and called with the user's **network_kwargs.  A builder here returns a
 *description* that the HIP model layout (csrc/model.hip) understands, instead of a TF graph
 function.  Supported on the hot path: 'mlp' (models.py:74-103), 'cnn' = NatureCNN
-(models.py:15-26), 'lstm' and 'cnn_lstm' (models.py:132-206); every other name raises like get_network_builder does
-(models.py:275)."""
+(models.py:15-26, incl. pad='SAME'), 'cnn_small' (models.py:117-129), 'lstm', 'cnn_lstm' and 'cnn_lnlstm' (models.py:132-218);
+every other name raises like get_network_builder does (models.py:275)."""
 
 mapping = {}
 
@@ -47,11 +47,30 @@ def mlp(num_layers=2, num_hidden=64, activation=None, layer_norm=False):
                        activation=_activation_name(activation), layer_norm=bool(layer_norm))
 
 
+def _conv_kwargs(conv_kwargs):
+    """**conv_kwargs of a2c/utils.py:37 conv() that the HIP path honours: pad='VALID' | 'SAME' (NHWC, [1, nf, 1, 1] biases are
+    the only layout built)"""
+    kw = dict(conv_kwargs)
+    pad = kw.pop('pad', 'VALID')
+    if pad not in ('VALID', 'SAME'):
+        raise ValueError('pad must be VALID or SAME, got {!r}'.format(pad))
+    if kw.pop('data_format', 'NHWC') != 'NHWC' or kw.pop('one_dim_bias', False):
+        raise NotImplementedError('conv data_format / one_dim_bias other than the defaults are outside the supported hot path')
+    if kw:
+        raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(kw)))
+    return {} if pad == 'VALID' else {'pad': pad}
+
+
 @register('cnn')
 def cnn(**conv_kwargs):
-    if conv_kwargs:
-        raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(conv_kwargs)))
-    return NetworkDesc('cnn')
+    """models.py:106-110: nature_cnn(X, **conv_kwargs)"""
+    return NetworkDesc('cnn', **_conv_kwargs(conv_kwargs))
+
+
+@register('cnn_small')
+def cnn_small(**conv_kwargs):
+    """models.py:117-129: conv 8 x (8 x 8) stride 4, conv 16 x (4 x 4) stride 2, fc 128 (all ReLU, sqrt(2) orthogonal init)"""
+    return NetworkDesc('cnn', convs=((8, 8, 4), (16, 4, 2)), fc_hidden=128, **_conv_kwargs(conv_kwargs))
 
 
 @register('lstm')
@@ -64,9 +83,7 @@ def lstm(nlstm=128, layer_norm=False):
 @register('cnn_lstm')
 def cnn_lstm(nlstm=128, layer_norm=False, **conv_kwargs):
     """common/models.py:179-206: NatureCNN features -> LSTM cell (layer_norm=True: lnlstm)"""
-    if conv_kwargs:
-        raise NotImplementedError('conv kwargs {} are outside the supported hot path'.format(sorted(conv_kwargs)))
-    return NetworkDesc('cnn_lstm', nlstm=int(nlstm), layer_norm=bool(layer_norm))
+    return NetworkDesc('cnn_lstm', nlstm=int(nlstm), layer_norm=bool(layer_norm), **_conv_kwargs(conv_kwargs))
 
 
 @register('cnn_lnlstm')

@@ -161,30 +161,49 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
         // stacks) takes the image-resident first-layer kernels, everything else the generic tiled engine
         if (d.ob_ndim != 3 || d.ob_shape[2] < 1) return MRL_EUNSUP;
         int H = d.ob_shape[0], W = d.ob_shape[1], C = d.ob_shape[2];
-        const int nf[3] = {32, 64, 64}, rf[3] = {8, 4, 3}, st[3] = {4, 2, 1};
-        const char* nm[3] = {"c1", "c2", "c3"};
-        for (int i = 0; i < 3; ++i) {
+        // nature_cnn's stack unless the descriptor carries one (cnn_small, models.py:117-129)
+        int nf[4] = {32, 64, 64, 0}, rf[4] = {8, 4, 3, 0}, st[4] = {4, 2, 1, 0}, nconv = 3, fch = 512;
+        if (d.nconv != 0) {
+            if (d.nconv < 1 || d.nconv > 4 || d.fc_hidden < 1) return MRL_EUNSUP;
+            nconv = d.nconv; fch = d.fc_hidden;
+            for (int i = 0; i < nconv; ++i) {
+                nf[i] = d.convs[i][0]; rf[i] = d.convs[i][1]; st[i] = d.convs[i][2];
+                if (nf[i] < 4 || nf[i] % 4 != 0 || rf[i] < 1 || st[i] < 1) return MRL_EUNSUP;
+            }
+        }
+        const bool same = d.conv_pad == 1;
+        if (d.conv_pad != 0 && d.conv_pad != 1) return MRL_EUNSUP;
+        for (int i = 0; i < nconv; ++i) {
             Layer l{};
+            char nm[8];
+            snprintf(nm, sizeof nm, "c%d", i + 1);
             l.kind = 0; l.H = H; l.W = W; l.C = C; l.rf = rf[i]; l.stride = st[i]; l.NF = nf[i];
-            if (H < rf[i] || W < rf[i]) return MRL_EUNSUP;
-            l.OH = (H - rf[i]) / st[i] + 1;
-            l.OW = (W - rf[i]) / st[i] + 1;
+            if (same) {
+                // tf.nn.conv2d 'SAME': out = ceil(in / stride); total padding = max((out - 1)*stride + rf - in, 0), smaller half in front
+                l.OH = (H + st[i] - 1) / st[i]; l.OW = (W + st[i] - 1) / st[i];
+                l.pad_t = std::max((l.OH - 1) * st[i] + rf[i] - H, 0) / 2;
+                l.pad_l = std::max((l.OW - 1) * st[i] + rf[i] - W, 0) / 2;
+            } else {
+                if (H < rf[i] || W < rf[i]) return MRL_EUNSUP;
+                l.OH = (H - rf[i]) / st[i] + 1;
+                l.OW = (W - rf[i]) / st[i] + 1;
+            }
             l.K = rf[i] * rf[i] * C; l.N = nf[i]; l.act = ACT_RELU;
-            l.w_off = add_tensor(m, prefix + "/" + nm[i] + "/w", {rf[i], rf[i], C, nf[i]}, s2);
-            l.b_off = add_tensor(m, prefix + "/" + nm[i] + "/b", {1, nf[i], 1, 1}, -1.0);
+            l.w_off = add_tensor(m, prefix + "/" + nm + "/w", {rf[i], rf[i], C, nf[i]}, s2);
+            l.b_off = add_tensor(m, prefix + "/" + nm + "/b", {1, nf[i], 1, 1}, -1.0);
             l.out_elems = (long)l.OH * l.OW * l.NF;
-            snprintf(l.name, sizeof l.name, "%s", nm[i]);
+            snprintf(l.name, sizeof l.name, "%s", nm);
             net.L.push_back(l);
             H = l.OH; W = l.OW; C = l.NF;
         }
         Layer f{};
-        f.kind = 1; f.K = H * W * C; f.N = 512; f.act = ACT_RELU;
+        f.kind = 1; f.K = H * W * C; f.N = fch; f.act = ACT_RELU;
         f.w_off = add_tensor(m, prefix + "/fc1/w", {f.K, f.N}, s2);
         f.b_off = add_tensor(m, prefix + "/fc1/b", {f.N}, -1.0);
         f.out_elems = f.N;
         snprintf(f.name, sizeof f.name, "fc1");
         net.L.push_back(f);
-        net.nlat = 512; net.lat_act = ACT_RELU;
+        net.nlat = fch; net.lat_act = ACT_RELU;
         return 0;
     } else if (d.network == MRL_NET_MLP) {
         if (d.ob_dtype != MRL_OB_F32 || d.num_layers < 1 || d.num_layers > 8 || d.num_hidden < 1) return MRL_EUNSUP;

@@ -37,6 +37,8 @@ class QModel(object):
         self.lr = float(lr)
         d = _lib.QNetDesc()
         net = q_func.network
+        if net.kind == 'cnn' and (net.kw.get('convs') or net.kw.get('pad')):
+            raise NotImplementedError('Q-networks take nature_cnn or conv_only(convs=...) bodies; cnn_small / cnn(pad=...) are built for ppo2 only')
         d.network = {'mlp': _lib.NET_MLP, 'cnn': _lib.NET_NATURE_CNN, 'conv_only': _lib.NET_CONV_ONLY}[net.kind]
         # deepq/utils.py ObservationInput -> common/input.py:43-63: Discrete observations are fed one-hot encoded
         self.ob_onehot = int(observation_space.n) if type(observation_space).__name__ == 'Discrete' else 0

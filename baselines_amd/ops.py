@@ -85,7 +85,8 @@ class DeviceModel(object):
     """Handle on an `mrl_model` layout object + the device buffers it works on."""
 
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_copy=False, num_layers=2,
-                 num_hidden=64, activation='tanh', nlstm=128, layer_norm=False, chunk=None, device=None):
+                 num_hidden=64, activation='tanh', nlstm=128, layer_norm=False, convs=None, fc_hidden=512, pad='VALID',
+                 chunk=None, device=None):
         _lib.require_gpu()
         lib = _lib.load()
         d = _lib.ModelDesc()
@@ -96,6 +97,13 @@ class DeviceModel(object):
             ob_shape = (int(np.prod(ob_shape)),)
         d.nlstm = int(nlstm)
         d.layer_norm = 1 if layer_norm else 0
+        # conv stack other than nature_cnn's (cnn_small; models.py:117-129) / cnn(pad='SAME')
+        if convs is not None and d.network in (_lib.NET_NATURE_CNN, _lib.NET_CNN_LSTM):
+            d.nconv, d.fc_hidden = len(convs), int(fc_hidden)
+            for i, c in enumerate(convs):
+                for k in range(3):
+                    d.convs[i][k] = int(c[k])
+        d.conv_pad = {'VALID': 0, 'SAME': 1}[pad]
         d.ob_ndim = len(ob_shape)
         for i, s in enumerate(ob_shape):
             d.ob_shape[i] = s

@@ -78,6 +78,11 @@ typedef struct mrl_model_desc {
                            * register-resident for the whole scan; any other width up to 1024 (e.g. impala_cnn_lstm's 256): streamed from L2 */
     int layer_norm;       /* mlp(layer_norm=True), models.py:97-98: tf.contrib.layers.layer_norm(h, center=True, scale=True)
                            * between fc and activation; variables <scope>/LayerNorm[_i]/{beta,gamma} after each layer's w, b */
+    /* conv stack of MRL_NET_NATURE_CNN / MRL_NET_CNN_LSTM (models.py:15-26, 106-129).  nconv = 0: nature_cnn's
+     * (32, 8, 4), (64, 4, 2), (64, 3, 1) + fc 512.  nconv in 1..4: layers c1..c<nconv> with (filters, kernel size, stride),
+     * filters % 4 == 0, then conv_to_fc and fc1 of fc_hidden units -- cnn_small is nconv = 2, (8, 8, 4), (16, 4, 2), fc_hidden
+     * = 128.  conv_pad: 0 = 'VALID' (the default of a2c/utils.py:37 conv), 1 = 'SAME' (cnn(pad='SAME'), a conv_kwargs entry). */
+    int nconv;  int convs[4][3];  int fc_hidden;  int conv_pad;
 } mrl_model_desc;
 
 typedef struct mrl_model mrl_model;   /* host-side layout object; owns no device memory */

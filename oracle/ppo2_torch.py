@@ -26,44 +26,42 @@ import torch.nn.functional as F
 from .ppo2_numpy import ortho_init
 
 
+NATURE_CONVS = ((32, 8, 4), (64, 4, 2), (64, 3, 1))        # common/models.py:21-23; cnn_small (:123-124): ((8, 8, 4), (16, 4, 2)), fc 128
+
+
+def conv_out(n, k, s, pad):
+    """tf.nn.conv2d output size: VALID floor((n - k) / s) + 1, SAME ceil(n / s)"""
+    return (n + s - 1) // s if pad == 'SAME' else (n - k) // s + 1
+
+
 def build_param_specs(network, ob_shape, pd_kind, nact, value_network=None,
-                      num_layers=2, num_hidden=64, nlstm=128, layer_norm=False):
+                      num_layers=2, num_hidden=64, nlstm=128, layer_norm=False, convs=None, fc_hidden=512, pad='VALID'):
     """Ordered (name, shape, init_scale|None) list in TF variable-creation order
     (SURVEY.md App. A.6): policy net -> value net copy -> pi head -> [logstd] -> vf head."""
     specs = []
 
     def net(prefix):
         if network == 'cnn':
-            assert tuple(ob_shape) == (84, 84, 4) or len(ob_shape) == 3
             h, w, c = ob_shape
-            specs.append((prefix + '/c1/w', (8, 8, c, 32), math.sqrt(2)))
-            specs.append((prefix + '/c1/b', (1, 32, 1, 1), None))
-            specs.append((prefix + '/c2/w', (4, 4, 32, 64), math.sqrt(2)))
-            specs.append((prefix + '/c2/b', (1, 64, 1, 1), None))
-            specs.append((prefix + '/c3/w', (3, 3, 64, 64), math.sqrt(2)))
-            specs.append((prefix + '/c3/b', (1, 64, 1, 1), None))
-            h1, w1 = (h - 8) // 4 + 1, (w - 8) // 4 + 1
-            h2, w2 = (h1 - 4) // 2 + 1, (w1 - 4) // 2 + 1
-            h3, w3 = h2 - 2, w2 - 2
-            specs.append((prefix + '/fc1/w', (h3 * w3 * 64, 512), math.sqrt(2)))
-            specs.append((prefix + '/fc1/b', (512,), None))
-            return 512
+            for i, (nf, rf, st) in enumerate(convs or NATURE_CONVS):
+                specs.append((prefix + '/c%d/w' % (i + 1), (rf, rf, c, nf), math.sqrt(2)))
+                specs.append((prefix + '/c%d/b' % (i + 1), (1, nf, 1, 1), None))
+                h, w, c = conv_out(h, rf, st, pad), conv_out(w, rf, st, pad), nf
+            specs.append((prefix + '/fc1/w', (h * w * c, fc_hidden), math.sqrt(2)))
+            specs.append((prefix + '/fc1/b', (fc_hidden,), None))
+            return fc_hidden
         elif network in ('lstm', 'cnn_lstm'):
             # common/models.py:132-210: [nature_cnn ->] a2c/utils.py:81-102 lstm(scope='lstm', init_scale=1.0):
             # wx [nin, 4nh], wh [nh, 4nh] orthogonal, b [4nh] zeros; created in that order after the conv stack
             if network == 'cnn_lstm':
                 h, w, c = ob_shape
-                specs.append((prefix + '/c1/w', (8, 8, c, 32), math.sqrt(2)))
-                specs.append((prefix + '/c1/b', (1, 32, 1, 1), None))
-                specs.append((prefix + '/c2/w', (4, 4, 32, 64), math.sqrt(2)))
-                specs.append((prefix + '/c2/b', (1, 64, 1, 1), None))
-                specs.append((prefix + '/c3/w', (3, 3, 64, 64), math.sqrt(2)))
-                specs.append((prefix + '/c3/b', (1, 64, 1, 1), None))
-                h1, w1 = (h - 8) // 4 + 1, (w - 8) // 4 + 1
-                h2, w2 = (h1 - 4) // 2 + 1, (w1 - 4) // 2 + 1
-                specs.append((prefix + '/fc1/w', ((h2 - 2) * (w2 - 2) * 64, 512), math.sqrt(2)))
-                specs.append((prefix + '/fc1/b', (512,), None))
-                nin = 512
+                for i, (nf, rf, st) in enumerate(convs or NATURE_CONVS):
+                    specs.append((prefix + '/c%d/w' % (i + 1), (rf, rf, c, nf), math.sqrt(2)))
+                    specs.append((prefix + '/c%d/b' % (i + 1), (1, nf, 1, 1), None))
+                    h, w, c = conv_out(h, rf, st, pad), conv_out(w, rf, st, pad), nf
+                specs.append((prefix + '/fc1/w', (h * w * c, fc_hidden), math.sqrt(2)))
+                specs.append((prefix + '/fc1/b', (fc_hidden,), None))
+                nin = fc_hidden
             else:
                 nin = int(np.prod(ob_shape))
             if layer_norm:
@@ -135,16 +133,17 @@ class OracleModel(object):
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_network=None,
                  ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float32,
                  params=None, num_layers=2, num_hidden=64, total_weight=1.0, rank_weight=1.0,
-                 allreduce=None, nlstm=128, layer_norm=False):
+                 allreduce=None, nlstm=128, layer_norm=False, convs=None, fc_hidden=512, pad='VALID'):
         self.network, self.ob_shape, self.ob_dtype = network, tuple(ob_shape), np.dtype(ob_dtype)
         self.pd_kind, self.nact, self.value_network = pd_kind, nact, value_network
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.dtype = dtype
         self.num_layers, self.num_hidden, self.nlstm = num_layers, num_hidden, nlstm
         self.layer_norm = layer_norm
+        self.convs, self.fc_hidden, self.pad = tuple(convs) if convs else NATURE_CONVS, fc_hidden, pad
         self.recurrent = network in ('lstm', 'cnn_lstm')
         self.specs, self.has_pi_head = build_param_specs(network, ob_shape, pd_kind, nact, value_network,
-                                                         num_layers, num_hidden, nlstm, layer_norm)
+                                                         num_layers, num_hidden, nlstm, layer_norm, convs, fc_hidden, pad)
         if params is None:
             params = init_params(self.specs)
         self.names = [s[0] for s in self.specs]
@@ -204,9 +203,16 @@ class OracleModel(object):
             # models.py:19: tf.cast(float32) / 255.
             h = x.to(self.dtype) / 255.
             h = h.permute(0, 3, 1, 2)
-            for name, stride in (('c1', 4), ('c2', 2), ('c3', 1)):
+            for i, (nf, rf, stride) in enumerate(self.convs):
+                name = 'c%d' % (i + 1)
                 w = p[prefix + '/%s/w' % name].permute(3, 2, 0, 1)  # HWIO -> OIHW
                 b = p[prefix + '/%s/b' % name].reshape(-1)
+                if self.pad == 'SAME':     # tf.nn.conv2d SAME: total = max((ceil(n/s) - 1) s + k - n, 0), the smaller half in front
+                    def halves(n):
+                        tot = max(((n + stride - 1) // stride - 1) * stride + rf - n, 0)
+                        return tot // 2, tot - tot // 2
+                    (pt, pb), (pl, pr) = halves(h.shape[2]), halves(h.shape[3])
+                    h = F.pad(h, (pl, pr, pt, pb))
                 h = F.relu(F.conv2d(h, w, b, stride=stride))
             h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)  # conv_to_fc on NHWC
             return F.relu(h @ p[prefix + '/fc1/w'] + p[prefix + '/fc1/b'])

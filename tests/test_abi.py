@@ -198,6 +198,32 @@ def test_layout_qnet_mlp_body_layer_norm_variable_names(lib):
     lib.mrl_qnet_destroy(h)
 
 
+def test_layout_cnn_small_variable_names_and_shapes(lib):
+    """cnn_small (common/models.py:117-129): c1 [8, 8, C, 8], c2 [4, 4, 8, 16], fc1 [9 * 9 * 16, 128] on 84 x 84 x 4 frames"""
+    d = _lib.ModelDesc()
+    d.network, d.ob_ndim, d.ob_dtype, d.pd_kind, d.nact = _lib.NET_NATURE_CNN, 3, _lib.OB_U8, _lib.PD_CATEGORICAL, 6
+    d.ob_shape[0], d.ob_shape[1], d.ob_shape[2] = 84, 84, 4
+    d.nconv, d.fc_hidden = 2, 128
+    for i, c in enumerate(((8, 8, 4), (16, 4, 2))):
+        for k in range(3):
+            d.convs[i][k] = c[k]
+    h = ctypes.c_void_p()
+    assert lib.mrl_model_create(ctypes.byref(d), ctypes.byref(h)) == 0
+    name = ctypes.create_string_buffer(128)
+    got = []
+    for i in range(lib.mrl_model_num_tensors(h)):
+        nd, shp, off, sc = ctypes.c_int(), (ctypes.c_int * 4)(), ctypes.c_long(), ctypes.c_double()
+        assert lib.mrl_model_tensor_info(h, i, name, 128, ctypes.byref(nd), ctypes.byref(shp), ctypes.byref(off), ctypes.byref(sc)) == 0
+        got.append((name.value.decode(), tuple(shp[k] for k in range(nd.value))))
+    p = 'ppo2_model/pi/'
+    assert got == [(p + 'c1/w', (8, 8, 4, 8)), (p + 'c1/b', (1, 8, 1, 1)), (p + 'c2/w', (4, 4, 8, 16)), (p + 'c2/b', (1, 16, 1, 1)),
+                   (p + 'fc1/w', (1296, 128)), (p + 'fc1/b', (128,)), (p + 'w', (128, 6)), (p + 'b', (6,)),
+                   ('ppo2_model/vf/w', (128, 1)), ('ppo2_model/vf/b', (1,))]
+    lib.mrl_model_destroy(h)
+    d.convs[0][0] = 6                              # filters % 4 != 0: outside what the engines load
+    assert lib.mrl_model_create(ctypes.byref(d), ctypes.byref(h)) != 0
+
+
 def test_layout_rejects_unsupported(lib):
     rc, h = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 3), ob_dtype=_lib.OB_U8,
                     pd_kind=_lib.PD_CATEGORICAL, nact=6)

@@ -68,6 +68,9 @@ def test_gather_and_sf01(shape, dtype):
 
 
 # ------------------------------------------------------------------------------------------------
+NET_KW = ('layer_norm', 'num_layers', 'num_hidden', 'convs', 'fc_hidden', 'pad')
+
+
 def _make_pair(network, ob_shape, ob_dtype, pd_kind, nact, value_network, seed, chunk, **kw):
     ops = _ops()
     np.random.seed(seed)
@@ -77,7 +80,8 @@ def _make_pair(network, ob_shape, ob_dtype, pd_kind, nact, value_network, seed, 
     dm = ops.DeviceModel(network=network, ob_shape=ob_shape, ob_dtype=ob_dtype, pd_kind=pd_kind, nact=nact,
                          value_copy=(value_network == 'copy'), chunk=chunk,
                          num_layers=kw.get('num_layers', 2), num_hidden=kw.get('num_hidden', 64),
-                         layer_norm=kw.get('layer_norm', False))
+                         layer_norm=kw.get('layer_norm', False), convs=kw.get('convs'), fc_hidden=kw.get('fc_hidden', 512),
+                         pad=kw.get('pad', 'VALID'))
     # layout must equal the reference's variable order / shapes
     assert [t['name'] for t in dm.tensors] == om.names
     for t, (nm, shp, sc) in zip(dm.tensors, om.specs):
@@ -117,6 +121,15 @@ CONFIGS = {
                          value_network=None, kind='image', T=3, N=6, B=12, chunk=16),
     'cnn_f32_4ch': dict(network='cnn', ob_shape=(40, 40, 4), ob_dtype=np.float32, pd_kind='gaussian', nact=2,
                         value_network=None, kind='image', T=2, N=8, B=16, chunk=16),
+    # cnn_small (common/models.py:117-129): conv 8 x 8x8 / 4, conv 16 x 4x4 / 2, fc 128 -- on Atari frame stacks and with a
+    # separate value network
+    'cnn_small_atari': dict(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6,
+                            value_network=None, kind='atari', T=4, N=8, B=24, chunk=16, convs=((8, 8, 4), (16, 4, 2)), fc_hidden=128),
+    'cnn_small_copy': dict(network='cnn', ob_shape=(52, 44, 3), ob_dtype=np.uint8, pd_kind='categorical', nact=3,
+                           value_network='copy', kind='image', T=3, N=6, B=12, chunk=16, convs=((8, 8, 4), (16, 4, 2)), fc_hidden=128),
+    # cnn(pad='SAME') (a **conv_kwargs entry of nature_cnn, a2c/utils.py:37): zero padding, the smaller half in front
+    'cnn_same_pad': dict(network='cnn', ob_shape=(30, 34, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=4,
+                         value_network=None, kind='image', T=3, N=6, B=12, chunk=16, pad='SAME'),
 }
 
 
@@ -159,7 +172,7 @@ def test_model_act_grad_train_vs_oracle(name):
     om64 = OracleModel(network=cfg['network'], ob_shape=cfg['ob_shape'], ob_dtype=cfg['ob_dtype'],
                        pd_kind=cfg['pd_kind'], nact=cfg['nact'], value_network=cfg['value_network'],
                        ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float64,
-                       params=om.params_numpy(), **{k: cfg[k] for k in ('layer_norm', 'num_layers', 'num_hidden') if k in cfg})
+                       params=om.params_numpy(), **{k: cfg[k] for k in NET_KW if k in cfg})
     returns, _ = O.gae(ro['rewards'], ro['values'], ro['dones'], ro['last_values'], ro['last_dones'], 0.99, 0.95)
 
     # ---- act side (teacher-forced noise) ----

@@ -134,7 +134,8 @@ def test_runner_device_vs_host_env_vs_oracle(kind, N, T):
     np.testing.assert_array_equal(O.sf01(ret_o), returns)
 
 
-@pytest.mark.parametrize('kind,N,T,nmb,nep', [('cartpole', 8, 128, 4, 4), ('mujoco', 16, 32, 4, 2), ('atari', 8, 8, 2, 2)])
+@pytest.mark.parametrize('kind,N,T,nmb,nep', [('cartpole', 8, 128, 4, 4), ('mujoco', 16, 32, 4, 2), ('atari', 8, 8, 2, 2),
+                                              ('atari_cnn_small', 8, 8, 2, 2)])
 def test_learn_two_updates_match_oracle(kind, N, T, nmb, nep):
     """ppo2.learn on the device env vs the reference algorithm driven by the oracle model on the
     teacher-forced rollouts: same minibatch permutations (global NumPy stream), loss stats within
@@ -142,7 +143,11 @@ def test_learn_two_updates_match_oracle(kind, N, T, nmb, nep):
     from baselines_amd import ppo2
     from baselines_amd.ppo2 import Model
     from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
-    net = {'atari': 'cnn', 'mujoco': 'mlp', 'cartpole': 'mlp'}[kind]
+    okw = {}
+    if kind == 'atari_cnn_small':                     # learn(network='cnn_small') (common/models.py:117-129)
+        kind, net, onet, okw = 'atari', 'cnn_small', 'cnn', dict(convs=((8, 8, 4), (16, 4, 2)), fc_hidden=128)
+    else:
+        net = onet = {'atari': 'cnn', 'mujoco': 'mlp', 'cartpole': 'mlp'}[kind]
     vn = 'copy' if kind == 'mujoco' else None
     rec = {}
 
@@ -167,9 +172,9 @@ def test_learn_two_updates_match_oracle(kind, N, T, nmb, nep):
     assert len(calls) == 2 * nmb * nep
     # oracle replays: same init (seed 0), then for each recorded minibatch the reference's train()
     np.random.seed(0)
-    om = OracleModel(network=net, ob_shape=env.observation_space.shape, ob_dtype=env.observation_space.dtype,
+    om = OracleModel(network=onet, ob_shape=env.observation_space.shape, ob_dtype=env.observation_space.dtype,
                      pd_kind=model.pd_kind, nact=model.nact, value_network=vn, ent_coef=0.01, vf_coef=0.5,
-                     max_grad_norm=0.5)
+                     max_grad_norm=0.5, **okw)
     np.testing.assert_array_equal(calls[0]['params_before'], om.flat_params())
     fields = None
     for i, c in enumerate(calls):
@@ -182,7 +187,9 @@ def test_learn_two_updates_match_oracle(kind, N, T, nmb, nep):
         np.testing.assert_allclose(c['stats'], so, rtol=1e-4, atol=1e-5)
     # permutations: exactly the reference's stream (set_global_seeds(0) -> ortho draws -> shuffles)
     assert sorted(np.concatenate([c['idx'] for c in calls[:nmb]]).tolist()) == list(range(N * T))
-    np.testing.assert_allclose(model.get_flat_params(), om.flat_params(), rtol=0, atol=1e-5)
+    # (a free-running Adam trajectory: sign-like steps amplify fp32 noise on entries whose gradient is a cancellation residue --
+    # tests/test_gpu_benched_shapes.py measures that against an fp64 trajectory; cnn_small: 1 of 171039 entries at 1.2e-5)
+    np.testing.assert_allclose(model.get_flat_params(), om.flat_params(), rtol=0, atol=2e-5 if okw else 1e-5)
 
 
 def test_model_train_reference_signature_and_save_load(tmp_path):
