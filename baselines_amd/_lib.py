@@ -19,7 +19,8 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [('network', c_int), ('ob_ndim', c_int), ('ob_shape', c_int * 3), ('ob_dtype', c_int),
                 ('num_layers', c_int), ('num_hidden', c_int), ('activation', c_int), ('value_copy', c_int),
                 ('pd_kind', c_int), ('nact', c_int), ('nlstm', c_int), ('layer_norm', c_int),
-                ('nconv', c_int), ('convs', (c_int * 3) * 4), ('fc_hidden', c_int), ('conv_pad', c_int)]
+                ('nconv', c_int), ('convs', (c_int * 3) * 4), ('fc_hidden', c_int), ('conv_pad', c_int),
+                ('nsub', c_int), ('nvec', c_int * 16)]
 
 
 NET_MLP, NET_NATURE_CNN, NET_LSTM, NET_CNN_LSTM, NET_CONV_ONLY = 0, 1, 2, 3, 4
@@ -32,7 +33,7 @@ class QNetDesc(ctypes.Structure):
                 ('convs', (c_int * 3) * 4), ('nhidden', c_int), ('hiddens', c_int * 4), ('dueling', c_int), ('nact', c_int),
                 ('layer_norm', c_int), ('body_layer_norm', c_int)]
 
-PD_CATEGORICAL, PD_DIAG_GAUSSIAN = 0, 1
+PD_CATEGORICAL, PD_DIAG_GAUSSIAN, PD_MULTICATEGORICAL, PD_BERNOULLI = 0, 1, 2, 3
 OB_F32, OB_U8 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 

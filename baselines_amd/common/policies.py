@@ -4,7 +4,7 @@ spaces, value-network mode, probability-distribution type = common/distributions
 import numpy as np
 
 from .models import get_network_builder, NetworkDesc
-from .spaces import is_box, is_discrete
+from .spaces import is_box, is_discrete, is_multibinary, is_multidiscrete
 
 
 class PolicySpec(object):
@@ -14,6 +14,7 @@ class PolicySpec(object):
         if value_network not in (None, 'shared', 'copy'):
             raise NotImplementedError("value_network must be None, 'shared' or 'copy' on the HIP path")
         self.value_copy = (value_network == 'copy')
+        self.nvec = None
         self.recurrent = network.kind in ('lstm', 'cnn_lstm')
         self.nlstm = int(network.kw.get('nlstm', 0)) if self.recurrent else 0
         if self.recurrent and self.value_copy:
@@ -24,6 +25,13 @@ class PolicySpec(object):
         elif is_box(ac_space):
             assert len(ac_space.shape) == 1
             self.pd_kind, self.nact = 'gaussian', int(ac_space.shape[0])
+        elif is_multidiscrete(ac_space):              # MultiCategoricalPdType(ac_space.nvec), distributions.py:285-286
+            self.nvec = tuple(int(v) for v in np.asarray(ac_space.nvec).reshape(-1))
+            if len(self.nvec) > 16:
+                raise NotImplementedError('MultiDiscrete with more than 16 components')
+            self.pd_kind, self.nact = 'multicategorical', int(sum(self.nvec))
+        elif is_multibinary(ac_space):                # BernoulliPdType(ac_space.n), distributions.py:287-288
+            self.pd_kind, self.nact = 'bernoulli', int(ac_space.n)
         else:
             raise NotImplementedError('action space {} is outside the supported hot path'.format(ac_space))
         # common/input.py:43-63 encode_observation: Discrete observations become one-hot float32 rows (the device model
@@ -41,6 +49,8 @@ class PolicySpec(object):
     def device_model_kwargs(self):
         kw = dict(network=self.network.kind, ob_shape=self.ob_shape, ob_dtype=self.ob_dtype, pd_kind=self.pd_kind,
                   nact=self.nact, value_copy=self.value_copy)
+        if self.nvec:
+            kw['nvec'] = self.nvec
         kw.update(self.network.kw)
         return kw
 

@@ -59,6 +59,56 @@ class Discrete(Space):
         return isinstance(other, Discrete) and self.n == other.n
 
 
+class MultiDiscrete(Space):
+    """gym.spaces.MultiDiscrete: a vector of len(nvec) categorical choices (common/distributions.py:285-286)"""
+
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        super().__init__(self.nvec.shape, np.int64)
+
+    def sample(self):
+        return (self._rng.random_sample(self.nvec.shape) * self.nvec).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and np.all(x >= 0) and np.all(x < self.nvec)
+
+    def __repr__(self):
+        return 'MultiDiscrete(%s)' % (self.nvec.tolist(),)
+
+    def __eq__(self, other):
+        return isinstance(other, MultiDiscrete) and np.array_equal(self.nvec, other.nvec)
+
+
+class MultiBinary(Space):
+    """gym.spaces.MultiBinary(n) (common/distributions.py:287-288)"""
+
+    def __init__(self, n):
+        self.n = int(n)
+        super().__init__((self.n,), np.int8)
+
+    def sample(self):
+        return self._rng.randint(0, 2, self.n).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and np.all((x == 0) | (x == 1))
+
+    def __repr__(self):
+        return 'MultiBinary(%d)' % self.n
+
+    def __eq__(self, other):
+        return isinstance(other, MultiBinary) and self.n == other.n
+
+
+def is_multidiscrete(space):
+    return type(space).__name__ == 'MultiDiscrete'
+
+
+def is_multibinary(space):
+    return type(space).__name__ == 'MultiBinary'
+
+
 def is_discrete(space):
     return type(space).__name__ == 'Discrete'
 

@@ -239,7 +239,13 @@ static int build_net(mrl_model* m, Net& net, const std::string& prefix) {
 extern "C" int mrl_model_create(const mrl_model_desc* desc, mrl_model** out) {
     if (!desc || !out) return MRL_EINVAL;
     if (desc->nact < 1 || desc->ob_ndim < 1 || desc->ob_ndim > 3) return MRL_EINVAL;
-    if (desc->pd_kind != MRL_PD_CATEGORICAL && desc->pd_kind != MRL_PD_DIAG_GAUSSIAN) return MRL_EUNSUP;
+    if (desc->pd_kind < MRL_PD_CATEGORICAL || desc->pd_kind > MRL_PD_BERNOULLI) return MRL_EUNSUP;
+    if (desc->pd_kind == MRL_PD_MULTICATEGORICAL) {
+        if (desc->nsub < 1 || desc->nsub > 16) return MRL_EUNSUP;
+        int tot = 0;
+        for (int i = 0; i < desc->nsub; ++i) { if (desc->nvec[i] < 1) return MRL_EINVAL; tot += desc->nvec[i]; }
+        if (tot != desc->nact) return MRL_EINVAL;
+    }
     mrl_model* m = new mrl_model();
     m->d = *desc;
     m->P = 0;
@@ -694,6 +700,7 @@ struct HeadArgs {
     const float* lat; const float* vlat; int nlat, nlatv; int shared; int lat_act, vlat_act;
     const float* Wpi; const float* bpi; const float* logstd; const float* Wvf; const float* bvf;
     int has_pi_head, pd_kind, nact, HP, TS;
+    int nsub; int nvec[16];       // MRL_PD_MULTICATEGORICAL: slices of the flat logits
     // training inputs
     const void* actions; const float* returns; const float* values; const float* neglogp;
     const int64_t* idx; long row0; int T, N; int Bc;
@@ -829,6 +836,69 @@ __global__ __launch_bounds__(256) void heads_train_kernel(HeadArgs a) {
                     float p = expf(a0) / z0;
                     float logp = a0 - logz;
                     dpi[j] = dnlp * (p - (j == act ? 1.f : 0.f)) + ce * p * (logp + H);
+                }
+                st[0] += (double)fmaxf(pg1, pg2);
+                st[3] += 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
+                st[4] += (fabsf(ratio - 1.f) > eps) ? 1.0 : 0.0;
+            } else if (a.pd_kind == MRL_PD_MULTICATEGORICAL || a.pd_kind == MRL_PD_BERNOULLI) {
+                // distributions.py:206-225 / 253-276: neglogp and entropy are SUMS over independent sub-distributions; the
+                // gradient of a slice is the categorical one with that slice's own entropy.  Two passes: the sums first (they
+                // fix the ratio), then the logit gradients.
+                const bool multi = a.pd_kind == MRL_PD_MULTICATEGORICAL;
+                const int nsub = multi ? a.nsub : a.nact;
+                const int32_t* x = static_cast<const int32_t*>(a.actions) + r * nsub;
+                nlp = 0.f; H = 0.f;
+                int o = 0;
+                for (int q = 0; q < nsub; ++q) {
+                    if (multi) {
+                        const int nv = a.nvec[q];
+                        const float* l = pi + o;
+                        float mx = l[0];
+                        for (int j = 1; j < nv; ++j) mx = fmaxf(mx, l[j]);
+                        float z0 = 0.f;
+                        for (int j = 0; j < nv; ++j) z0 += expf(l[j] - mx);
+                        const float logz = logf(z0);
+                        nlp += logz - (l[x[q]] - mx);
+                        float Hq = 0.f;
+                        for (int j = 0; j < nv; ++j) { const float a0 = l[j] - mx; Hq += (expf(a0) / z0) * (logz - a0); }
+                        H += Hq;
+                        o += nv;
+                    } else {
+                        // tf.nn.sigmoid_cross_entropy_with_logits(l, z) = max(l, 0) - l z + log(1 + exp(-|l|))
+                        const float l = pi[q], sp = fmaxf(l, 0.f) + log1pf(expf(-fabsf(l)));
+                        const float p = 1.f / (1.f + expf(-l));
+                        nlp += sp - l * (float)x[q];
+                        H += sp - l * p;
+                    }
+                }
+                const float ratio = expf(oldnlp - nlp);
+                const float pg1 = -adv * ratio;
+                const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+                const float pg2 = -adv * rc;
+                float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+                const float dnlp = dr * (-ratio) * a.invB;
+                o = 0;
+                for (int q = 0; q < nsub; ++q) {
+                    if (multi) {
+                        const int nv = a.nvec[q];
+                        const float* l = pi + o;
+                        float mx = l[0];
+                        for (int j = 1; j < nv; ++j) mx = fmaxf(mx, l[j]);
+                        float z0 = 0.f;
+                        for (int j = 0; j < nv; ++j) z0 += expf(l[j] - mx);
+                        const float logz = logf(z0);
+                        float Hq = 0.f;
+                        for (int j = 0; j < nv; ++j) { const float a0 = l[j] - mx; Hq += (expf(a0) / z0) * (logz - a0); }
+                        for (int j = 0; j < nv; ++j) {
+                            const float a0 = l[j] - mx, p = expf(a0) / z0, logp = a0 - logz;
+                            dpi[o + j] = dnlp * (p - (j == x[q] ? 1.f : 0.f)) + ce * p * (logp + Hq);
+                        }
+                        o += nv;
+                    } else {
+                        // d neglogp / dl = sigmoid(l) - x;  d H / dl = -l p (1 - p)  (the binary entropy through p = sigmoid(l))
+                        const float l = pi[q], p = 1.f / (1.f + expf(-l));
+                        dpi[q] = dnlp * (p - (float)x[q]) + ce * l * p * (1.f - p);
+                    }
                 }
                 st[0] += (double)fmaxf(pg1, pg2);
                 st[3] += 0.5 * (double)((nlp - oldnlp) * (nlp - oldnlp));
@@ -1143,6 +1213,38 @@ __global__ __launch_bounds__(256) void heads_act_kernel(HeadArgs a) {
                     for (int j = 0; j < a.nact; ++j) z0 += expf(pi[j] - mx);
                     static_cast<int32_t*>(a.actions_out)[b] = best;
                     a.neglogp_out[b] = logf(z0) - (pi[best] - mx);
+                } else if (a.pd_kind == MRL_PD_MULTICATEGORICAL) {
+                    int32_t* ao = static_cast<int32_t*>(a.actions_out) + b * a.nsub;
+                    float nlp = 0.f;
+                    int o = 0;
+                    for (int q = 0; q < a.nsub; ++q) {                 // one Gumbel-max per slice (distributions.py:223-224)
+                        const int nv = a.nvec[q];
+                        const float* l = pi + o;
+                        int best = 0;
+                        float bv = l[0] - logf(-logf(nz[o]));
+                        float mx = l[0];
+                        for (int j = 1; j < nv; ++j) {
+                            const float c = l[j] - logf(-logf(nz[o + j]));
+                            if (c > bv) { bv = c; best = j; }
+                            mx = fmaxf(mx, l[j]);
+                        }
+                        float z0 = 0.f;
+                        for (int j = 0; j < nv; ++j) z0 += expf(l[j] - mx);
+                        ao[q] = best;
+                        nlp += logf(z0) - (l[best] - mx);
+                        o += nv;
+                    }
+                    a.neglogp_out[b] = nlp;
+                } else if (a.pd_kind == MRL_PD_BERNOULLI) {
+                    int32_t* ao = static_cast<int32_t*>(a.actions_out) + b * a.nact;
+                    float nlp = 0.f;
+                    for (int q = 0; q < a.nact; ++q) {                 // u < sigmoid(l) (distributions.py:271-273)
+                        const float l = pi[q], p = 1.f / (1.f + expf(-l));
+                        const int xb = nz[q] < p ? 1 : 0;
+                        ao[q] = xb;
+                        nlp += fmaxf(l, 0.f) + log1pf(expf(-fabsf(l))) - l * (float)xb;
+                    }
+                    a.neglogp_out[b] = nlp;
                 } else {
                     float* ao = static_cast<float*>(a.actions_out) + b * a.nact;
                     float ssum = 0.f, lsum = 0.f;
@@ -2067,6 +2169,8 @@ static void fill_head_args(const mrl_model* m, const float* params, const Ws& ws
     a.logstd = m->logstd >= 0 ? params + m->logstd : nullptr;
     a.Wvf = params + m->vf_w; a.bvf = params + m->vf_b;
     a.pd_kind = m->d.pd_kind; a.nact = m->d.nact; a.HP = m->HP;
+    a.nsub = m->d.nsub;
+    for (int i = 0; i < 16; ++i) a.nvec[i] = m->d.nvec[i];
 }
 
 static int pick_ts(HeadArgs& a, bool train) {
@@ -2194,7 +2298,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
     const bool mlp_fused = [&] {
         const mrl_model_desc& d = m->d;
         const int K0 = (int)m->ob_elems, nets = m->vf_copy ? 2 : 1, ntiles = (B0 + 31) / 32;
-        return get_option("mlp_fused", "MRL_MLP_FUSED", 1) && d.network == MRL_NET_MLP && d.num_layers == 2 && !d.layer_norm &&
+        return get_option("mlp_fused", "MRL_MLP_FUSED", 1) && d.network == MRL_NET_MLP && d.num_layers == 2 && !d.layer_norm && d.pd_kind <= MRL_PD_DIAG_GAUSSIAN &&
                d.num_hidden == MLP_NH && d.activation == MRL_ACT_TANH && m->has_pi_head && d.nact <= 32 && K0 % 4 == 0 &&
                B0 <= chunk && ntiles <= MLP_MAX_TILES && mlp_step_lds_bytes(K0, nets) <= 160 * 1024 &&
                (size_t)ntiles * m->P <= ws.part_floats && (uintptr_t)params % 16 == 0 && (uintptr_t)obs % 16 == 0;
@@ -2216,7 +2320,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         if (idx) {
             idx += mb0;
         } else {
-            const size_t act_bytes = m->d.pd_kind == MRL_PD_CATEGORICAL ? 4 : 4 * (size_t)m->d.nact;
+            const size_t act_bytes = m->d.pd_kind == MRL_PD_CATEGORICAL ? 4 : m->d.pd_kind == MRL_PD_MULTICATEGORICAL ? 4 * (size_t)m->d.nsub : 4 * (size_t)m->d.nact;
             obs = (const char*)obs + (size_t)mb0 * ob_bytes;
             actions = (const char*)actions + (size_t)mb0 * act_bytes;
             returns += mb0; values += mb0; neglogpacs += mb0;

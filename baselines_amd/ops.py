@@ -86,7 +86,7 @@ class DeviceModel(object):
 
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_copy=False, num_layers=2,
                  num_hidden=64, activation='tanh', nlstm=128, layer_norm=False, convs=None, fc_hidden=512, pad='VALID',
-                 chunk=None, device=None):
+                 nvec=None, chunk=None, device=None):
         _lib.require_gpu()
         lib = _lib.load()
         d = _lib.ModelDesc()
@@ -114,7 +114,14 @@ class DeviceModel(object):
         d.num_layers, d.num_hidden = int(num_layers), int(num_hidden)
         d.activation = {'tanh': _lib.ACT_TANH, 'relu': _lib.ACT_RELU}[activation]
         d.value_copy = 1 if value_copy else 0
-        d.pd_kind = {'categorical': _lib.PD_CATEGORICAL, 'gaussian': _lib.PD_DIAG_GAUSSIAN}[pd_kind]
+        d.pd_kind = {'categorical': _lib.PD_CATEGORICAL, 'gaussian': _lib.PD_DIAG_GAUSSIAN,
+                     'multicategorical': _lib.PD_MULTICATEGORICAL, 'bernoulli': _lib.PD_BERNOULLI}[pd_kind]
+        self.nvec = tuple(int(v) for v in nvec) if nvec is not None else None
+        if pd_kind == 'multicategorical':
+            assert self.nvec and sum(self.nvec) == int(nact), 'multicategorical: nact is the width of the flat logits = sum(nvec)'
+            d.nsub = len(self.nvec)
+            for i, v in enumerate(self.nvec):
+                d.nvec[i] = v
         d.nact = int(nact)
         self.desc = d
         h = c_void_p()
@@ -142,6 +149,19 @@ class DeviceModel(object):
         self.workspace = None
         if chunk:
             self.set_chunk(chunk)
+
+    @property
+    def action_dtype(self):
+        """device dtype of the actions: int32 for the discrete distributions (Categorical / MultiCategorical / Bernoulli)"""
+        return torch.float32 if self.pd_kind == 'gaussian' else torch.int32
+
+    def action_shape(self, n):
+        """[n] (Categorical), [n, len(nvec)] (MultiCategorical), [n, nact] (Bernoulli bits, DiagGaussian)"""
+        if self.pd_kind == 'categorical':
+            return (n,)
+        if self.pd_kind == 'multicategorical':
+            return (n, len(self.nvec))
+        return (n, self.nact)
 
     def set_chunk(self, chunk):
         chunk = int(chunk)
@@ -174,8 +194,7 @@ class DeviceModel(object):
         if want_actions:
             assert noise is not None and noise.shape == (n, self.nact) and noise.dtype == torch.float32
             noise = _dev(noise)
-            actions = (torch.empty(n, dtype=torch.int32, device=dev) if self.pd_kind == 'categorical'
-                       else torch.empty((n, self.nact), dtype=torch.float32, device=dev))
+            actions = torch.empty(self.action_shape(n), dtype=self.action_dtype, device=dev)
             neglogp = torch.empty(n, dtype=torch.float32, device=dev)
         if want_pdparam:
             pdparam = torch.empty((n, self.nact), dtype=torch.float32, device=dev)

@@ -80,7 +80,7 @@ class MicrobatchedModel(Model):
         assert states is None, 'microbatches with recurrent models are not supported yet'
         obs = self._to_dev_obs(obs)
         B = obs.shape[0]
-        act = self._field(actions, torch.int32 if self.pd_kind == 'categorical' else torch.float32)
+        act = self._field(actions, self.dm.action_dtype)
         ret, val, nlp = (self._field(x, torch.float32) for x in (returns, values, neglogpacs))
 
         def call(mb0, mbn, row):

@@ -129,7 +129,7 @@ class Model(object):
     def make_noise(self, n):
         """uniform(0,1) for the Gumbel-max sampler (distributions.py:199-201), N(0,1) for the Gaussian
         (:247-248); torch's Philox generator on the device stands in for TF's."""
-        if self.pd_kind == 'categorical':
+        if self.pd_kind != 'gaussian':              # Gumbel-max per (slice of the) logits / u < sigmoid(logit) (:271-273)
             return torch.rand((n, self.nact), generator=self._gen, device=self.device, dtype=torch.float32)
         return torch.randn((n, self.nact), generator=self._gen, device=self.device, dtype=torch.float32)
 
@@ -174,8 +174,7 @@ class Model(object):
         if self.recurrent:
             assert S is not None and M is not None, 'recurrent policy: step(obs, S=states, M=dones)'
             st = self._dev_state(S, n).clone()
-            a = (torch.empty(n, dtype=torch.int32, device=self.device) if self.pd_kind == 'categorical'
-                 else torch.empty((n, self.nact), dtype=torch.float32, device=self.device))
+            a = torch.empty(self.dm.action_shape(n), dtype=self.dm.action_dtype, device=self.device)
             v = torch.empty(n, dtype=torch.float32, device=self.device)
             nlp = torch.empty(n, dtype=torch.float32, device=self.device)
             self.dm.act_rnn_into(self.params, obs, noise.contiguous(), st, self._dev_mask(M, n), st, a, v, nlp)
@@ -185,6 +184,8 @@ class Model(object):
         a = a.cpu().numpy()
         if self.pd_kind == 'categorical':
             a = a.astype(np.int64)       # tf.argmax dtype
+        elif self.pd_kind == 'bernoulli':
+            a = a.astype(np.float32)     # tf.to_float(u < p), distributions.py:273 (MultiCategorical: tf.int32, :224)
         return a, v.cpu().numpy(), state, nlp.cpu().numpy()
 
     def value(self, ob, *args, S=None, M=None, **kwargs):
@@ -401,7 +402,7 @@ class Model(object):
         NumPy or device tensors).  Returns the 5 stats as Python floats."""
         obs = self._to_dev_obs(obs)
         B = obs.shape[0]
-        act = self._field(actions, torch.int32 if self.pd_kind == 'categorical' else torch.float32)
+        act = self._field(actions, self.dm.action_dtype)
         ret, val, nlp = (self._field(x, torch.float32) for x in (returns, values, neglogpacs))
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
         if self.recurrent:             # model.py:153-155: td_map[S] = states, td_map[M] = masks

@@ -33,12 +33,16 @@ def _defines(obj, name):
 class Rollout(object):
     """Device-resident SoA rollout buffer (time-major)."""
 
-    def __init__(self, T, N, ob_shape, ob_dtype, pd_kind, nact, device):
+    def __init__(self, T, N, ob_shape, ob_dtype, pd_kind, nact, device, nsub=None):
         self.T, self.N = T, N
         f32 = dict(dtype=torch.float32, device=device)
         self.obs = torch.empty((T, N) + tuple(ob_shape), dtype=ob_dtype, device=device)
         if pd_kind == 'categorical':
             self.actions = torch.empty((T, N), dtype=torch.int32, device=device)
+        elif pd_kind == 'multicategorical':           # one int32 per component of the MultiDiscrete space
+            self.actions = torch.empty((T, N, nsub), dtype=torch.int32, device=device)
+        elif pd_kind == 'bernoulli':                  # one bit per component of the MultiBinary space
+            self.actions = torch.empty((T, N, nact), dtype=torch.int32, device=device)
         else:
             self.actions = torch.empty((T, N, nact), **f32)
         self.rewards = torch.empty((T, N), **f32)
@@ -96,10 +100,13 @@ class Runner(AbstractEnvRunner):
             ob_np, ob_t = np.dtype(np.float32), torch.float32
         pd_kind = getattr(model, 'pd_kind', None)
         if pd_kind is None:
-            pd_kind = 'categorical' if type(env.action_space).__name__ == 'Discrete' else 'gaussian'
-        nact = getattr(model, 'nact', None) or (env.action_space.n if pd_kind == 'categorical'
+            pd_kind = {'Discrete': 'categorical', 'MultiDiscrete': 'multicategorical',
+                       'MultiBinary': 'bernoulli'}.get(type(env.action_space).__name__, 'gaussian')
+        nact = getattr(model, 'nact', None) or (env.action_space.n if pd_kind in ('categorical', 'bernoulli')
+                                                else int(np.sum(env.action_space.nvec)) if pd_kind == 'multicategorical'
                                                 else env.action_space.shape[0])
-        self.rollout = Rollout(nsteps, self.nenv, ob_shape, ob_t, pd_kind, nact, self.device)
+        nsub = len(np.asarray(env.action_space.nvec).reshape(-1)) if pd_kind == 'multicategorical' else None
+        self.rollout = Rollout(nsteps, self.nenv, ob_shape, ob_t, pd_kind, nact, self.device, nsub=nsub)
         self.return_host = (not self.device_env) if return_host is None else return_host
         self.fast_step = hasattr(model, 'step_into')
         self._dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=self.device)
@@ -234,6 +241,8 @@ class Runner(AbstractEnvRunner):
                 actions = ro.actions[t].cpu().numpy()
                 if ro.pd_kind == 'categorical':
                     actions = actions.astype(np.int64)
+                elif ro.pd_kind == 'bernoulli':
+                    actions = actions.astype(np.float32)
             else:
                 actions, values, self.states, neglogpacs = self.model.step(self.obs, S=self.states, M=self.dones)
                 ro.actions[t].copy_(torch.from_numpy(np.asarray(actions)).to(ro.actions.dtype))
@@ -274,7 +283,7 @@ class Runner(AbstractEnvRunner):
         # GAE(lambda) + returns: one HIP kernel, bit-exact vs runner.py:52-65
         ops.gae(ro.rewards, ro.values, ro.dones, last_values, self._dones_dev, self.gamma, self.lam, out=ro.returns)
         T, N = ro.T, ro.N
-        act_dtype = np.int64 if ro.pd_kind == 'categorical' else np.float32
+        act_dtype = {'categorical': np.int64, 'multicategorical': np.int32}.get(ro.pd_kind, np.float32)
         fields = (RolloutField(ro.obs, T, N, self._ob_np), RolloutField(ro.returns, T, N, np.float32),
                   RolloutField(ro.dones, T, N, np.bool_), RolloutField(ro.actions, T, N, act_dtype),
                   RolloutField(ro.values, T, N, np.float32), RolloutField(ro.neglogpacs, T, N, np.float32))

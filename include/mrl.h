@@ -59,7 +59,9 @@ int mrl_sf01(const void* src, void* dst, int T, int N, int row_bytes, void* stre
 /* ---- model description --- common/policies.py:121-179, common/models.py:15-26,74-103 ------ */
 enum { MRL_NET_MLP = 0, MRL_NET_NATURE_CNN = 1, MRL_NET_LSTM = 2, MRL_NET_CNN_LSTM = 3,
        MRL_NET_CONV_ONLY = 4 /* Q-networks only */ };                            /* models.py:74-249 */
-enum { MRL_PD_CATEGORICAL = 0, MRL_PD_DIAG_GAUSSIAN = 1 };
+enum { MRL_PD_CATEGORICAL = 0, MRL_PD_DIAG_GAUSSIAN = 1,
+       MRL_PD_MULTICATEGORICAL = 2,   /* MultiDiscrete(nvec): independent categoricals over the slices of the flat logits (distributions.py:206-225) */
+       MRL_PD_BERNOULLI = 3 };         /* MultiBinary(n): independent Bernoullis, logits -> sigmoid (distributions.py:253-276) */
 enum { MRL_OB_F32 = 0, MRL_OB_U8 = 1 };
 enum { MRL_ACT_NONE = 0, MRL_ACT_RELU = 1, MRL_ACT_TANH = 2 };
 
@@ -83,6 +85,10 @@ typedef struct mrl_model_desc {
      * filters % 4 == 0, then conv_to_fc and fc1 of fc_hidden units -- cnn_small is nconv = 2, (8, 8, 4), (16, 4, 2), fc_hidden
      * = 128.  conv_pad: 0 = 'VALID' (the default of a2c/utils.py:37 conv), 1 = 'SAME' (cnn(pad='SAME'), a conv_kwargs entry). */
     int nconv;  int convs[4][3];  int fc_hidden;  int conv_pad;
+    /* MRL_PD_MULTICATEGORICAL: nsub categoricals with nvec[i] classes each, nact = sum nvec (the width of the flat pdparam);
+     * actions are int32 [n][nsub].  MRL_PD_BERNOULLI: nact bits, actions int32 [n][nact] (0 / 1); both sample from
+     * uniform(0, 1) noise [n][nact] (Gumbel-max per slice / u < sigmoid(logit)). */
+    int nsub;  int nvec[16];
 } mrl_model_desc;
 
 typedef struct mrl_model mrl_model;   /* host-side layout object; owns no device memory */

@@ -133,7 +133,8 @@ class OracleModel(object):
     def __init__(self, *, network, ob_shape, ob_dtype, pd_kind, nact, value_network=None,
                  ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, dtype=torch.float32,
                  params=None, num_layers=2, num_hidden=64, total_weight=1.0, rank_weight=1.0,
-                 allreduce=None, nlstm=128, layer_norm=False, convs=None, fc_hidden=512, pad='VALID'):
+                 allreduce=None, nlstm=128, layer_norm=False, convs=None, fc_hidden=512, pad='VALID', nvec=None):
+        self.nvec = tuple(int(v) for v in nvec) if nvec is not None else None      # MultiCategorical: slices of the flat logits
         self.network, self.ob_shape, self.ob_dtype = network, tuple(ob_shape), np.dtype(ob_dtype)
         self.pd_kind, self.nact, self.value_network = pd_kind, nact, value_network
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
@@ -248,7 +249,28 @@ class OracleModel(object):
         return pi, vf
 
     # ---- pd maths -----------------------------------------------------------
+    def _slices(self, pi):
+        """tf.split(flat, nvec, axis=-1) (distributions.py:209)"""
+        out, o = [], 0
+        for nv in self.nvec:
+            out.append(pi[:, o:o + nv])
+            o += nv
+        return out
+
     def _neglogp(self, pi, a):
+        if self.pd_kind == 'multicategorical':
+            # distributions.py:215-216: add_n of the slices' Categorical neglogp
+            a = a.long().reshape(pi.shape[0], -1)
+            tot = 0.0
+            for q, l in enumerate(self._slices(pi)):
+                a0 = l - l.max(dim=-1, keepdim=True)[0]
+                tot = tot + torch.log(torch.exp(a0).sum(-1)) - a0.gather(1, a[:, q:q + 1])[:, 0]
+            return tot
+        if self.pd_kind == 'bernoulli':
+            # distributions.py:264-265: sum of sigmoid_cross_entropy_with_logits(logits, labels = x) =
+            # max(l, 0) - l x + log(1 + exp(-|l|))
+            x = a.to(pi.dtype).reshape(pi.shape)
+            return (torch.clamp(pi, min=0) - pi * x + torch.log1p(torch.exp(-pi.abs()))).sum(-1)
         if self.pd_kind == 'categorical':
             # softmax_cross_entropy_with_logits_v2(logits, onehot)
             a0 = pi - pi.max(dim=-1, keepdim=True)[0]
@@ -261,6 +283,17 @@ class OracleModel(object):
             + logstd_b.sum(-1)
 
     def _entropy(self, pi):
+        if self.pd_kind == 'multicategorical':       # distributions.py:219-220
+            tot = 0.0
+            for l in self._slices(pi):
+                a0 = l - l.max(dim=-1, keepdim=True)[0]
+                ea0 = torch.exp(a0)
+                z0 = ea0.sum(-1, keepdim=True)
+                tot = tot + ((ea0 / z0) * (torch.log(z0) - a0)).sum(-1)
+            return tot
+        if self.pd_kind == 'bernoulli':              # distributions.py:268-269: labels = sigmoid(logits), differentiable
+            ps = torch.sigmoid(pi)
+            return (torch.clamp(pi, min=0) - pi * ps + torch.log1p(torch.exp(-pi.abs()))).sum(-1)
         if self.pd_kind == 'categorical':
             a0 = pi - pi.max(dim=-1, keepdim=True)[0]
             ea0 = torch.exp(a0)
@@ -277,10 +310,16 @@ class OracleModel(object):
             nz = torch.as_tensor(np.asarray(noise)).to(self.dtype)
             if self.pd_kind == 'categorical':
                 a = torch.argmax(pi - torch.log(-torch.log(nz)), dim=-1)
+            elif self.pd_kind == 'multicategorical':       # one Gumbel-max per slice, stacked (distributions.py:223-224)
+                g = pi - torch.log(-torch.log(nz))
+                a = torch.stack([torch.argmax(x, dim=-1) for x in self._slices(g)], dim=-1)
+            elif self.pd_kind == 'bernoulli':              # tf.to_float(u < sigmoid(l)), distributions.py:271-273
+                a = (nz < torch.sigmoid(pi)).to(self.dtype)
             else:
                 a = pi + torch.exp(pi * 0.0 + self.p['ppo2_model/pi/logstd']) * nz
             nlp = self._neglogp(pi, a)
-        a_np = a.numpy().astype(np.int64) if self.pd_kind == 'categorical' else a.numpy().astype(np.float32)
+        a_np = (a.numpy().astype(np.int64) if self.pd_kind == 'categorical' else
+                a.numpy().astype(np.int32) if self.pd_kind == 'multicategorical' else a.numpy().astype(np.float32))
         state = self.last_state.numpy().astype(np.float32) if self.recurrent else None
         return a_np, vf.numpy().astype(np.float32), state, nlp.numpy().astype(np.float32)
 
@@ -296,7 +335,7 @@ class OracleModel(object):
         OLDNLP = torch.as_tensor(np.asarray(neglogpacs)).to(dt)
         ADV = torch.as_tensor(np.asarray(advs)).to(dt)
         A = torch.as_tensor(np.asarray(actions))
-        if self.pd_kind != 'categorical':
+        if self.pd_kind in ('gaussian', 'bernoulli'):
             A = A.to(dt)
         if self.recurrent:      # model.py:153-155: S = states, M = masks; train model built with nsteps (model.py:40-43)
             pi, vpred = self.forward(obs, states, masks, nenv=np.asarray(states).shape[0])

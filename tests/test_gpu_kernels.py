@@ -68,7 +68,7 @@ def test_gather_and_sf01(shape, dtype):
 
 
 # ------------------------------------------------------------------------------------------------
-NET_KW = ('layer_norm', 'num_layers', 'num_hidden', 'convs', 'fc_hidden', 'pad')
+NET_KW = ('layer_norm', 'num_layers', 'num_hidden', 'convs', 'fc_hidden', 'pad', 'nvec')
 
 
 def _make_pair(network, ob_shape, ob_dtype, pd_kind, nact, value_network, seed, chunk, **kw):
@@ -81,7 +81,7 @@ def _make_pair(network, ob_shape, ob_dtype, pd_kind, nact, value_network, seed, 
                          value_copy=(value_network == 'copy'), chunk=chunk,
                          num_layers=kw.get('num_layers', 2), num_hidden=kw.get('num_hidden', 64),
                          layer_norm=kw.get('layer_norm', False), convs=kw.get('convs'), fc_hidden=kw.get('fc_hidden', 512),
-                         pad=kw.get('pad', 'VALID'))
+                         pad=kw.get('pad', 'VALID'), nvec=kw.get('nvec'))
     # layout must equal the reference's variable order / shapes
     assert [t['name'] for t in dm.tensors] == om.names
     for t, (nm, shp, sc) in zip(dm.tensors, om.specs):
@@ -128,6 +128,13 @@ CONFIGS = {
     'cnn_small_copy': dict(network='cnn', ob_shape=(52, 44, 3), ob_dtype=np.uint8, pd_kind='categorical', nact=3,
                            value_network='copy', kind='image', T=3, N=6, B=12, chunk=16, convs=((8, 8, 4), (16, 4, 2)), fc_hidden=128),
     # cnn(pad='SAME') (a **conv_kwargs entry of nature_cnn, a2c/utils.py:37): zero padding, the smaller half in front
+    # MultiDiscrete / MultiBinary action spaces (common/distributions.py:206-225, 253-276, 285-288)
+    'mlp_multidiscrete': dict(network='mlp', ob_shape=(9,), ob_dtype=np.float32, pd_kind='multicategorical', nact=9, nvec=(2, 3, 4),
+                              value_network='copy', kind=None, T=8, N=8, B=48, chunk=32),
+    'cnn_multidiscrete': dict(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='multicategorical', nact=7, nvec=(1, 2, 4),
+                              value_network=None, kind='atari', T=3, N=6, B=12, chunk=16),
+    'mlp_multibinary': dict(network='mlp', ob_shape=(7,), ob_dtype=np.float32, pd_kind='bernoulli', nact=5,
+                            value_network=None, kind=None, T=8, N=8, B=40, chunk=64),
     'cnn_same_pad': dict(network='cnn', ob_shape=(30, 34, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=4,
                          value_network=None, kind='image', T=3, N=6, B=12, chunk=16, pad='SAME'),
 }
@@ -149,7 +156,7 @@ def _rollout(cfg, om, seed):
         ro['obs'] = rng.randn(*((T, N) + cfg['ob_shape'])).astype(np.float32)
     acts, vals, nlps = [], [], []
     for t in range(T):
-        nz = (rng.rand(N, cfg['nact']) if cfg['pd_kind'] == 'categorical' else rng.randn(N, cfg['nact']))
+        nz = (rng.rand(N, cfg['nact']) if cfg['pd_kind'] != 'gaussian' else rng.randn(N, cfg['nact']))
         a, v, _, nlp = om.step(ro['obs'][t], nz.astype(np.float32))
         acts.append(a); vals.append(v); nlps.append(nlp)
     ro['actions'], ro['values'], ro['neglogpacs'] = np.stack(acts), np.stack(vals), np.stack(nlps)
@@ -178,15 +185,16 @@ def test_model_act_grad_train_vs_oracle(name):
     # ---- act side (teacher-forced noise) ----
     rng = np.random.RandomState(5)
     obs0 = ro['obs'][0]
-    noise = (rng.rand(N, cfg['nact']) if cfg['pd_kind'] == 'categorical' else rng.randn(N, cfg['nact'])).astype(np.float32)
+    noise = (rng.rand(N, cfg['nact']) if cfg['pd_kind'] != 'gaussian' else rng.randn(N, cfg['nact'])).astype(np.float32)
     a_o, v_o, _, nlp_o = om.step(obs0, noise)
     a_d, v_d, nlp_d, pd_d = dm.act(params, dev(obs0), dev(noise), want_pdparam=True)
     with torch.no_grad():
         pd_o, _ = om.forward(obs0)
     np.testing.assert_allclose(pd_d.cpu().numpy(), pd_o.numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(v_d.cpu().numpy(), v_o, rtol=1e-4, atol=2e-5)
-    if cfg['pd_kind'] == 'categorical':
-        np.testing.assert_array_equal(a_d.cpu().numpy().astype(np.int64), a_o)
+    if cfg['pd_kind'] != 'gaussian':
+        assert a_d.dtype == torch.int32 and tuple(a_d.shape) == tuple(a_o.shape)
+        np.testing.assert_array_equal(a_d.cpu().numpy().astype(np.int64), a_o.astype(np.int64))
     else:
         np.testing.assert_allclose(a_d.cpu().numpy(), a_o, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(nlp_d.cpu().numpy(), nlp_o, rtol=1e-4, atol=2e-5)
@@ -204,7 +212,7 @@ def test_model_act_grad_train_vs_oracle(name):
     stats_o, g_o = om.compute_grads(cliprange, mb['obs'], mb['returns'], mb['actions'], mb['values'], mb['neglogpacs'])
     stats_64, g_64 = om64.compute_grads(cliprange, mb['obs'], mb['returns'], mb['actions'], mb['values'],
                                         mb['neglogpacs'])
-    acts = ro['actions'].astype(np.int32) if cfg['pd_kind'] == 'categorical' else ro['actions']
+    acts = ro['actions'].astype(np.int32) if cfg['pd_kind'] != 'gaussian' else ro['actions']
     d_obs, d_act, d_ret = dev(ro['obs']), dev(acts), dev(returns)
     d_val, d_nlp, d_idx = dev(ro['values']), dev(ro['neglogpacs']), dev(idx)
     grads = torch.empty(dm.P, dtype=torch.float32, device='cuda')
@@ -230,7 +238,7 @@ def test_model_act_grad_train_vs_oracle(name):
     # same minibatch passed directly (idx == NULL path)
     grads2 = torch.empty_like(grads)
     stats2 = torch.empty_like(stats)
-    mb_act = mb['actions'].astype(np.int32) if cfg['pd_kind'] == 'categorical' else mb['actions']
+    mb_act = mb['actions'].astype(np.int32) if cfg['pd_kind'] != 'gaussian' else mb['actions']
     dm.grad(params, dev(mb['obs']), dev(mb_act), dev(mb['returns']), dev(mb['values']), dev(mb['neglogpacs']), None,
             B, 1, 1, cliprange, 0.01, 0.5, grads2, stats2)
     np.testing.assert_array_equal(grads2.cpu().numpy(), grads.cpu().numpy())

@@ -107,13 +107,31 @@ def _kl_gaussian(m0, ls0, m1, ls1):
     return (ls1 - ls0 + (s0 ** 2 + (m0 - m1) ** 2) / (2.0 * s1 ** 2) - 0.5).sum(-1)
 
 
+def _kl_bernoulli(l0, l1):
+    """distributions.py:266-267: sum ce(logits = other, labels = ps) - sum ce(logits = self, labels = ps)"""
+    ps = torch.sigmoid(l0)
+    ce = lambda l, z: torch.clamp(l, min=0) - l * z + torch.log1p(torch.exp(-l.abs()))
+    return ce(l1, ps).sum(-1) - ce(l0, ps).sum(-1)
+
+
+def _kl_multicategorical(l0, l1, nvec):
+    """distributions.py:217-218: add_n of the slices' Categorical kl"""
+    tot, o = 0.0, 0
+    for nv in nvec:
+        tot = tot + _kl_categorical(l0[:, o:o + nv], l1[:, o:o + nv])
+        o += nv
+    return tot
+
+
+PDPARAM_MULTICATEGORICAL, NVEC_MULTICATEGORICAL = np.array([-.2, .3, .5, .1, 1, -.1]), (1, 2, 3)     # distributions.py:311-312
+PDPARAM_BERNOULLI = np.array([-.2, .3, .5])                               # distributions.py:316
 PDPARAM_DIAG_GAUSS = np.array([-.2, .3, .4, -.5, .1, -.5, .1, 0.8])     # distributions.py:303
 PDPARAM_CATEGORICAL = np.array([-.2, .3, .5])                             # distributions.py:307
 N_SAMPLES = 100000
 
 
-def _oracle_for(pd_kind, nact):
-    return OracleModel(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind=pd_kind, nact=nact, dtype=torch.float64)
+def _oracle_for(pd_kind, nact, nvec=None):
+    return OracleModel(network='mlp', ob_shape=(4,), ob_dtype=np.float32, pd_kind=pd_kind, nact=nact, dtype=torch.float64, nvec=nvec)
 
 
 def _validate(neglogp, entropy, kl, sample, pdparam, q):
@@ -405,3 +423,41 @@ def test_oracle_layer_norm_variants_equal_their_formulas_in_numpy():
 
     a, v = head('action_value'), head('state_value')
     np.testing.assert_allclose(oq.q_values(obs), v + (a - a.mean(axis=1, keepdims=True)), rtol=1e-12, atol=1e-13)
+
+
+def test_validate_probtype_multicategorical_on_oracle():
+    """distributions.py:310-313: MultiCategoricalPdType([1, 2, 3]) on the reference's pdparam"""
+    np.random.seed(0)
+    om = _oracle_for('multicategorical', PDPARAM_MULTICATEGORICAL.size, NVEC_MULTICATEGORICAL)
+    rep = lambda v, n: torch.tensor(np.repeat(v[None, :], n, axis=0))
+
+    def sample(pdparam, n):
+        u = torch.tensor(np.random.rand(n, pdparam.size))
+        g = rep(pdparam, n) - torch.log(-torch.log(u))
+        return torch.stack([torch.argmax(x, dim=-1) for x in om._slices(g)], dim=-1)
+    q = PDPARAM_MULTICATEGORICAL + np.random.randn(PDPARAM_MULTICATEGORICAL.size) * 0.1
+    _validate(neglogp=lambda pdp, X: om._neglogp(rep(pdp, N_SAMPLES), X).numpy(),
+              entropy=lambda pdp, n: om._entropy(rep(pdp, n)).numpy(),
+              kl=lambda p, q_, n: _kl_multicategorical(rep(p, n), rep(q_, n), NVEC_MULTICATEGORICAL).numpy(),
+              sample=sample, pdparam=PDPARAM_MULTICATEGORICAL, q=q)
+    # known answer: entropies of softmax([.3, .5]) and softmax([.1, 1, -.1]); the one-class slice contributes 0
+    ent = 0.0
+    for l in (np.array([.3, .5]), np.array([.1, 1, -.1])):
+        p = np.exp(l) / np.exp(l).sum()
+        ent += float(-(p * np.log(p)).sum())
+    assert abs(float(om._entropy(rep(PDPARAM_MULTICATEGORICAL, 1))[0]) - ent) < 1e-12
+
+
+def test_validate_probtype_bernoulli_on_oracle():
+    """distributions.py:315-317: BernoulliPdType(3) on the reference's pdparam"""
+    np.random.seed(0)
+    om = _oracle_for('bernoulli', PDPARAM_BERNOULLI.size)
+    rep = lambda v, n: torch.tensor(np.repeat(v[None, :], n, axis=0))
+    sample = lambda pdparam, n: (torch.tensor(np.random.rand(n, pdparam.size)) < torch.sigmoid(rep(pdparam, n))).double()
+    q = PDPARAM_BERNOULLI + np.random.randn(PDPARAM_BERNOULLI.size) * 0.1
+    _validate(neglogp=lambda pdp, X: om._neglogp(rep(pdp, N_SAMPLES), X).numpy(),
+              entropy=lambda pdp, n: om._entropy(rep(pdp, n)).numpy(),
+              kl=lambda p, q_, n: _kl_bernoulli(rep(p, n), rep(q_, n)).numpy(),
+              sample=sample, pdparam=PDPARAM_BERNOULLI, q=q)
+    p = 1.0 / (1.0 + np.exp(-PDPARAM_BERNOULLI))
+    assert abs(float(om._entropy(rep(PDPARAM_BERNOULLI, 1))[0]) - float(-(p * np.log(p) + (1 - p) * np.log(1 - p)).sum())) < 1e-12
