@@ -27,7 +27,7 @@ LABELS = {
 # forward kernels also serve the act side (other batch sizes): their minibatch launches are the largest dispatches
 # (".top8" lines of scripts/rocpd_pmc.py, launch order); (kernel substring, which of the alternating layers, of how many)
 TOP = {
-    'c1.fwd': ('c1fwd2_kernel', 0, 1),
+    'c1.fwd': ('c1fwd3_kernel', 0, 1),
     'c2.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::TrBiasRelu', 0, 2),
     'c3.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::TrBiasRelu', 1, 2),
     'fc1.fwd': ('gemm_x6_kernel<mrl::X6DenseA, mrl::TrBiasRelu', 0, 1),

@@ -256,16 +256,36 @@ def test_full_size_minibatch_backward_vs_oracle_every_entry():
     assert np.abs(g_m - g_d).max() <= 3e-6 * scale, (np.abs(g_m - g_d).max(), scale)
     np.testing.assert_allclose(s_d, s_m, rtol=1e-5, atol=1e-5)
 
-    # ---- fp64 oracle over the same slices
+    # ---- fp64 oracle over the same slices ($MRL_PARITY_REPORT set: the fp32 CPU restatement too, so that the device's error
+    #      can be quoted next to the error of an fp32 implementation, per tensor -- VERDICT r03 weak 3)
+    import json
+    report_path = os.environ.get('MRL_PARITY_REPORT')
     advs = om64._normalised_advs(rets, vals)
     g64 = np.zeros(dm.P, np.float64)
     s64 = np.zeros(5, np.float64)
+    g32 = np.zeros(dm.P, np.float64) if report_path else None
+    advs32 = om._normalised_advs(rets, vals) if report_path else None
     for sl in _sliced(B, S):
         st, fl = om64.compute_grads(clip, obs[sl], rets[sl], acts[sl], vals[sl], nlps[sl], advs=advs[sl])
         g64 += fl.numpy()
         s64 += np.array(st)
+        if report_path:
+            _, fl32 = om.compute_grads(clip, obs[sl], rets[sl], acts[sl], vals[sl], nlps[sl], advs=advs32[sl])
+            g32 += fl32.numpy().astype(np.float64)
     g64 /= B // S
     s64 /= B // S
+    if report_path:
+        g32 /= B // S
+        errs = {}
+        for t in dm.tensors:
+            sl = slice(t['offset'], t['offset'] + t['size'])
+            sc = float(np.abs(g64[sl]).max())
+            errs[t['name']] = dict(scale=sc, err_device=float(np.abs(g_d[sl] - g64[sl]).max()) / sc,
+                                   err_fp32_oracle_summed_over_16_slices=float(np.abs(g32[sl] - g64[sl]).max()) / sc)
+        with open(report_path, 'a') as fh:
+            fh.write(json.dumps(dict(test='full_size_minibatch_backward', B=B, chunk=B,
+                                     stats_abs_diff_vs_fp64=[float(x) for x in np.abs(s_d - s64)],
+                                     grad_errors_over_tensor_scale=errs)) + '\n')
     np.testing.assert_allclose(s_d, s64, rtol=1e-5, atol=1e-5)
     scale = np.abs(g64).max()
     for t in dm.tensors:
