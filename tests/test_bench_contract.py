@@ -1,5 +1,5 @@
 """CPU: the one-line JSON contract of bench.py, checked on the committed result of the last GPU run
-(profiles/r03z_bench_atari4096.json) and on bench.py's own argument defaults."""
+(profiles/r04x_bench_atari4096.json) and on bench.py's own argument defaults."""
 import ast
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r03z_bench_atari4096.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04x_bench_atari4096.json')))
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert d['metric'] == base['metric']
     for key in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
@@ -20,7 +20,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
     assert r['traffic'] is None or r['traffic'] > 0
-    assert (r['traffic'] is None or r['traffic_source'].startswith('profiles/r03')) and d['dtype'] == 'f32'
+    assert (r['traffic'] is None or r['traffic_source'].startswith("profiles/r04")) and d['dtype'] == 'f32'
     assert r['bound'] == 'mfma' and abs(r['frac'] - r['mfma_frac']) < 1e-12 and 0 < r['hbm_frac'] < r['frac']
     # the headline runs the split engines: six exact bf16 products per fp32 multiply, nearest-rounded planes
     assert d['config']['arithmetic_mode'] == 'bf16x6-rn-split'
@@ -29,10 +29,20 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(kr['c2.wgrad']['peak'] - 2516.6 / 6) < 1e-3 and abs(kr['c2.fwd']['peak'] - 2516.6 / 6) < 1e-3
     assert kr['c1.fwd']['bound'] == 'hbm' and kr['c1.fwd']['peak'] == 8000.0 and abs(kr['c1.fwd']['mfma_peak_tflops'] - 2516.6 / 3) < 1e-3
     assert d['self_check']['stats_max_abs_diff'] <= 1e-5 and d['self_check']['grad_max_abs_diff_over_scale'] <= 1e-5
-    assert {o['workload'].split()[0] for o in d['other_configs']} == {'ppo2', 'deepq'} and len(d['other_configs']) == 4
+    assert {o['workload'].split()[0] for o in d['other_configs']} == {'ppo2', 'deepq'} and len(d['other_configs']) == 5
     c = d['cpu_baseline']
     assert c['host_cpu_count'] >= c['cores'] and c['host_cpu_model']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    # every per-kernel breakdown fits inside the step it belongs to; the graph-replayed MLP row takes its
+    # kernel times from a rocprofv3 trace of the replay
+    assert sum(d['kernel_ms_per_step'].values()) <= d['ms_per_step'] * 1.003
+    for o in d['other_configs']:
+        if 'kernel_ms_per_step' in o and o.get('ms_per_step'):
+            bound = o['ms_per_step'] if 'rocprofv3' not in (o.get('kernel_times_source') or '') else 1e9
+            assert sum(o['kernel_ms_per_step'].values()) <= bound * 1.003, o['workload']
+    mlp = [o for o in d['other_configs'] if 'mlp' in o['workload']][0]
+    assert 'rocprofv3' in mlp['kernel_times_source'] and sum(mlp['kernel_ms_per_step'].values()) <= mlp['ms_per_step']
+    assert any("config 4's per-GPU shard" in o['workload'] and 'projection_8_gpus' in o for o in d['other_configs'])
     # value = env-steps of K timed steps / time:  num_envs * nsteps / (ms_per_step / 1000)
     assert abs(d['value'] - 4096 * 128 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
 
