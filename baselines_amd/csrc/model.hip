@@ -366,7 +366,7 @@ static int get_option(const char* name, const char* env, int dflt) {
 }
 // fp32 x fp32 GEMM sites that run on the bf16 pipe: 0 = fp32 MFMA (bitwise fmaf chain), 1 = six bf16 products per
 // multiply (dropped part < 2^-21 of a product), 2 = eight products (dropped part < 2^-29: below one fp32 rounding).
-// Default 2: every product of the update is then at least as accurate as an IEEE fp32 multiply.
+// Default 2: every product of the update is then at least as accurate as an IEEE fp32 multiply (the sums: DESIGN.md 3.1).
 // 0: fp32 MFMA engines; anything else: the split engines (kSplitProducts exact bf16 products per multiply, wres.hip.h).
 // (Callers compare with 2, the value the option has carried since the eight-product form became the only tuned one.)
 static int f32_split_mode() { return get_option("f32_bf16x6", "MRL_F32_BF16X6", 2) ? 2 : 0; }
