@@ -166,7 +166,7 @@ typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
 
 struct C1TrRelu {            // h = relu(acc) (bias folded into the accumulator), fp32 + bit mask + planes
     float* out; uint32_t* mask; uint16_t* hp; long pstride;
-    __device__ __forceinline__ float4 apply(const TrAux&, int, int, float4 a) const {
+    __device__ __forceinline__ float4 apply(const TrAux&, int, int, float4 a, float) const {
         return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
     }
 };

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
                                                        float* __restrict__ dx, int act, int B, int btiles,
                                                        long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dbg, int prio,
                                                        const uint16_t* __restrict__ dzp, long dz_ps,
-                                                       uint16_t* __restrict__ dxp, long dx_ps) {
+                                                       uint16_t* __restrict__ dxp, long dx_ps, int dither) {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    // dither (gemmx6.hip.h): the rows of a tile are IMAGES; every other group of 8 is staged negated and un-negated in the epilogue
+    const bool sg_odd = !PA && dither && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
+    const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
+    const float sg_s = sg_odd ? -1.f : 1.f;
     if (dbg & 1) { hmask = nullptr; mbits = nullptr; }     // timing experiments (MRL_DGX6_DBG): 1 = no mask loads,
     for (long slot = blockIdx.x >> 3; slot < tiles_per_xcd; slot += slots_per_xcd) {      // 2 = no stores, 4 = no main loop
     const long lt = (long)xcd * tiles_per_xcd + slot;
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
-            split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
-            split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
+            split2_bf16x3_sg(ra[p].x, ra[p].y, sg_k, sg_s, a0x, a1x, a2x);
+            split2_bf16x3_sg(ra[p].z, ra[p].w, sg_k, sg_s, a0y, a1y, a2y);
             uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
             *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
@@ -297,9 +301,18 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b]);
+            for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b], (!PA && dither && (i & 8)) ? -1.f : 1.f);
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!PA && dither) {                   // registers with r & 4 hold the images 8..15, 24..31 that were staged negated
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r & 4) acc[a][b][r] = -acc[a][b][r];
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -375,7 +388,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
         const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);      // two workgroups per CU
         hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, mbits,
                            dx, act, B, btiles, per_xcd, total, slots, dbg, x6_prio(), dzp, (long)B * G::OH * G::OW * NF, dxp,
-                           (long)B * H * W * C);
+                           (long)B * H * W * C, x6_dither());
         return hipGetLastError();
     };
     if constexpr (C % 32 == 0) {

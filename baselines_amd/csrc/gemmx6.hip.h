@@ -84,7 +84,7 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 //     cycles during which it feeds nothing to the matrix pipe).
 template <class AF, class EF, int WM, int WN, bool X8, int xd = 0, bool PA = false, bool TR = false, int IL = 0>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
-                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride, int pg) {
+                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride, int pg, int dither) {
     // xd (timing experiments, builds with -DMRL_X6_EXPERIMENTS, option x6_dbg = 100 + bits): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global loads in the
     // main loop, 8 = no split arithmetic (raw halves are staged), 16 = every step re-reads k tile 0 (cache hits)
     static_assert(WM * WN == 4, "4 waves");
@@ -124,6 +124,13 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // dither (option x6_dither): every other group of 8 A rows is staged NEGATED (split2_bf16x3_sg: no extra instruction) and the
+    // epilogue multiplies their results by -1 -- the matrix instruction's bias toward -inf for products far below the accumulator
+    //  then changes sign every 8 rows (samples / pixels) and cancels in every later sum over rows.  A thread stages
+    // rows p*32 + tid/8: groups of 8 rows = waves, so the sign and the rounding constant are wave-uniform (scalar registers).
+    const bool sg_odd = !PA && dither && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
+    const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
+    const float sg_s = sg_odd ? -1.f : 1.f;
     // staging addresses: A rows p*32 + tid/8, 4 floats at k = (tid&7)*4;  B rows (q*256 + tid)/4, 8 bf16 at ((..)&3)*8
     const float* ap[NA];
     const uint16_t* app[NAP];          // PA: rows p*64 + tid/4, 8 bf16 at k = (tid&3)*8, plane 0
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 a0x = a1x = a2x = __float_as_uint(ra[p].x) ^ __float_as_uint(ra[p].y);
                 a0y = a1y = a2y = __float_as_uint(ra[p].z) ^ __float_as_uint(ra[p].w);
             } else {
-                split2_bf16x3(ra[p].x, ra[p].y, a0x, a1x, a2x);
-                split2_bf16x3(ra[p].z, ra[p].w, a0y, a1y, a2y);
+                split2_bf16x3_sg(ra[p].x, ra[p].y, sg_k, sg_s, a0x, a1x, a2x);
+                split2_bf16x3_sg(ra[p].z, ra[p].w, sg_k, sg_s, a0y, a1y, a2y);
             }
             uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             for (int b = 0; b < 2; ++b) {
                 const int row = m0 + (wm * 2 + a) * 32 + i, cb = n0 + (wn * 2 + b) * 32;
                 const bool valid = row < M && cb < N;
-                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? (long)row * ef.ld + cb : 0L, h, valid);
+                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? (long)row * ef.ld + cb : 0L, h, valid,
+                                  (!PA && dither && (i & 8)) ? -1.f : 1.f);
             }
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -330,6 +338,15 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     // wave's 32 rows x 2 column blocks are collected into lane (row_in_block*2 + b) and stored with ONE instruction
     const int mk_row = lane >> 1, mk_b = lane & 1;
     const int mk_r = (mk_row & 3) + 4 * (mk_row >> 3), mk_h = (mk_row >> 2) & 1;
+    if (!PA && dither) {                   // rows (r&3) + 8*(r>>2) + 4h: registers with r & 4 hold the rows 8..15, 24..31 that were staged negated
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r & 4) acc[a][b][r] = -acc[a][b][r];
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         uint32_t mword = 0;
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 }
 
 inline int& x6_prio() { static int p = 0; return p; }
+inline int& x6_dither() { static int p = getenv("MRL_X6_DITHER") ? atoi(getenv("MRL_X6_DITHER")) : 1; return p; }     // mrl_set_option "x6_dither": alternate the sign of the staged A rows
 inline int& x6_xd() { static int p = 0; return p; }        // experiment bits (mrl_set_option "x6_dbg" = 100 + bits)      // experiment knob (mrl_set_option "x6_prio")
 inline bool gemm_x6_ok(const void* A, long lda, int K) {
     return K % X6_BK == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;
@@ -425,7 +443,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride, pg);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride, pg, x6_dither());
     return hipGetLastError();
 }
 // Pre-split operands (planes.hip.h).  PA: A is a plane tensor (af.p = plane 0, a_pstride elements between planes; Bp must

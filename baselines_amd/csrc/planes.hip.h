@@ -59,10 +59,11 @@ struct TrBiasRelu {          // h = relu(acc + bias[c])  (+ ReLU bit mask of h, 
         for (int g = 0; g < 4; ++g) x.v[g] = *reinterpret_cast<const float4*>(b + 8 * g);
         return x;
     }
-    __device__ __forceinline__ float4 apply(const TrAux& x, int g, int, float4 a) const {
+    // sg = +-1: the sign this row's A operand was staged with (x6_dither); folded into the bias add
+    __device__ __forceinline__ float4 apply(const TrAux& x, int g, int, float4 a, float sg) const {
         float4 v;
-        v.x = act_fwd(a.x + x.v[g].x, ACT_RELU); v.y = act_fwd(a.y + x.v[g].y, ACT_RELU);
-        v.z = act_fwd(a.z + x.v[g].z, ACT_RELU); v.w = act_fwd(a.w + x.v[g].w, ACT_RELU);
+        v.x = act_fwd(__builtin_fmaf(a.x, sg, x.v[g].x), ACT_RELU); v.y = act_fwd(__builtin_fmaf(a.y, sg, x.v[g].y), ACT_RELU);
+        v.z = act_fwd(__builtin_fmaf(a.z, sg, x.v[g].z), ACT_RELU); v.w = act_fwd(__builtin_fmaf(a.w, sg, x.v[g].w), ACT_RELU);
         return v;
     }
 };
@@ -79,13 +80,16 @@ struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of th
         }
         return x;
     }
-    __device__ __forceinline__ float4 apply(const TrAux& x, int g, int cin, float4 a) const {
+    // sg = +-1: the sign this row's A operand was staged with (x6_dither); folded into the mask factor
+    __device__ __forceinline__ float4 apply(const TrAux& x, int g, int cin, float4 a, float sg) const {
         if (hbits) {
-            a.x *= ((x.w >> cin) & 1u) ? 1.f : 0.f; a.y *= ((x.w >> (cin + 1)) & 1u) ? 1.f : 0.f;
-            a.z *= ((x.w >> (cin + 2)) & 1u) ? 1.f : 0.f; a.w *= ((x.w >> (cin + 3)) & 1u) ? 1.f : 0.f;
+            a.x *= ((x.w >> cin) & 1u) ? sg : 0.f; a.y *= ((x.w >> (cin + 1)) & 1u) ? sg : 0.f;
+            a.z *= ((x.w >> (cin + 2)) & 1u) ? sg : 0.f; a.w *= ((x.w >> (cin + 3)) & 1u) ? sg : 0.f;
         } else if (h) {
-            a.x *= act_bwd_from_out(x.v[g].x, ACT_RELU); a.y *= act_bwd_from_out(x.v[g].y, ACT_RELU);
-            a.z *= act_bwd_from_out(x.v[g].z, ACT_RELU); a.w *= act_bwd_from_out(x.v[g].w, ACT_RELU);
+            a.x *= x.v[g].x > 0.f ? sg : 0.f; a.y *= x.v[g].y > 0.f ? sg : 0.f;
+            a.z *= x.v[g].z > 0.f ? sg : 0.f; a.w *= x.v[g].w > 0.f ? sg : 0.f;
+        } else {
+            a.x *= sg; a.y *= sg; a.z *= sg; a.w *= sg;
         }
         return a;
     }
@@ -96,13 +100,13 @@ struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of th
 // (ef.out), the plane tensor (ef.hp) and the ReLU bit mask (ef.mask: one word per block, bit = column).  All 64 lanes
 // must call it (the two halves of a block exchange their mask bits); `valid` gates the memory accesses.
 template <class EF>
-__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, const TrAux& aux, long o, int h, bool valid) {
+__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, const TrAux& aux, long o, int h, bool valid, float sg = 1.f) {
     uint32_t bits = 0;
     uint32_t pk[3][8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int cin = 8 * g + 4 * h;
-        const float4 v = ef.apply(aux, g, cin, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+        const float4 v = ef.apply(aux, g, cin, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]), sg);
         if (ef.mask)
             bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << cin;
         if (ef.out && valid) *reinterpret_cast<float4*>(ef.out + o + cin) = v;

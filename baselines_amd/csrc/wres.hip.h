@@ -491,6 +491,20 @@ __device__ __forceinline__ void split2_bf16x3(float x0, float x1, uint32_t& p0, 
     const float l0 = r0 - __uint_as_float(v0 & 0xffff0000u), l1 = r1 - __uint_as_float(v1 & 0xffff0000u);
     p2 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);      // exact: <= 8 significant bits left
 }
+// The same split of (s x0, s x1) for a sign s = +-1 that is a run-time value of the thread, at the same 15 instructions: adding 2^31
+// to the bit pattern flips the sign bit, so the rounding constant k = 0x8000 (s = +1) or 0x80008000 (s = -1) yields the rounded
+// first plane of s x directly, and the first residual s x - plane0 is one fma (exact, as above).  The tiled engines stage every
+// other A row negated and undo it in the epilogue (x6_dither): the bf16 matrix instruction's small bias toward
+// -inf then alternates from row to row instead of being common to all samples.
+__device__ __forceinline__ void split2_bf16x3_sg(float x0, float x1, uint32_t k, float s, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    const uint32_t t0 = __float_as_uint(x0) + k, t1 = __float_as_uint(x1) + k;
+    p0 = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+    const float r0 = __builtin_fmaf(s, x0, -__uint_as_float(t0 & 0xffff0000u)), r1 = __builtin_fmaf(s, x1, -__uint_as_float(t1 & 0xffff0000u));
+    const uint32_t v0 = __float_as_uint(r0) + 0x8000u, v1 = __float_as_uint(r1) + 0x8000u;
+    p1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float l0 = r0 - __uint_as_float(v0 & 0xffff0000u), l1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
 // one value -> the bf16 bit patterns of its three planes (the weight-plane kernels)
 __device__ __forceinline__ void split1_bf16x3(float v, uint16_t& b0, uint16_t& b1, uint16_t& b2) {
     uint32_t q0, q1, q2;

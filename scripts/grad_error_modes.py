@@ -20,7 +20,7 @@ _, g32 = om.compute_grads(0.2, mb['obs'], mb['returns'], mb['actions'], mb['valu
 g64, g32 = g64.numpy(), g32.numpy().astype(np.float64)
 params = dev(om.flat_params().astype(np.float32))
 res = {}
-ref_opts = dict(f32_bf16x6=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0, tr_epilogue=0, wgrad_tr=0, u8_bf16x3=0)
+ref_opts = dict(f32_bf16x6=0, x6_dither=0, dgrad_x6=0, relu_bits=0, c1_lds=0, wgrad_x8=0, c1_wgrad2=0, tr_epilogue=0, wgrad_tr=0, u8_bf16x3=0)
 old = {k: L.get_option(k) for k in ref_opts}
 dm = _device_model(B)
 res['device (product)'] = _device_grad(dm, params, mb, 0.2)[0]

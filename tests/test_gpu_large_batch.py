@@ -15,6 +15,8 @@ which changes that sample's gradient by a finite amount -- a property of the fun
 The minibatches are therefore screened with the fp64 oracle: samples with any pre-activation closer to zero than
 MARGIN are replaced by spare ones, after which every entry of the gradient has to agree.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -74,6 +76,21 @@ def _problem(B, seed):
     return om, om64, mb
 
 
+def _report(name, dm, g_d, g32, g64):
+    """one JSON line per call into $MRL_PARITY_REPORT: per tensor, max error over the tensor's scale against the fp64 oracle"""
+    path = os.environ.get('MRL_PARITY_REPORT')
+    if not path:
+        return
+    import json
+    errs = {}
+    for t in dm.tensors:
+        sl = slice(t['offset'], t['offset'] + t['size'])
+        sc = float(np.abs(g64[sl]).max())
+        errs[t['name']] = dict(err_device=float(np.abs(g_d[sl] - g64[sl]).max()) / sc, err_fp32_oracle=float(np.abs(g32[sl] - g64[sl]).max()) / sc)
+    with open(path, 'a') as fh:
+        fh.write(json.dumps(dict(test=name, per_tensor=errs)) + '\n')
+
+
 def _device_model(B):
     from baselines_amd import ops
     return ops.DeviceModel(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6, chunk=B)
@@ -109,7 +126,23 @@ def test_nature_cnn_gradient_at_b2048_vs_oracle_every_entry():
         err_d = np.abs(g_d[sl] - ref).max()
         err_o = np.abs(g32[sl] - ref).max()
         assert err_d <= tol, (t['name'], err_d, err_o, tol)          # every entry, no percentile
-        assert err_d <= max(16.0 * err_o, 0.5 * tol), (t['name'], err_d, err_o)  # same class as the fp32 CPU restatement
+        # the same class as the fp32 CPU restatement (measured: 0.9-1.1e-6 of a tensor's scale, oracle 0.2-1.3e-6; without the sign
+        # alternation of the staged rows -- option x6_dither, DESIGN.md 3.1 -- the split engines sit at 3-4.6e-6)
+        assert err_d <= max(8.0 * err_o, 2.5e-6 * max(np.abs(ref).max(), 1e-3 * scale)), (t['name'], err_d, err_o)
+    _report('b2048_backward', dm, g_d, g32, g64)
+    # the common part of the split engines' error: with every row staged as is the matrix instruction's bias toward -inf has the same
+    # sign for all samples and survives the sums over the minibatch
+    from baselines_amd import _lib
+    _lib.set_option('x6_dither', 0)
+    try:
+        g_0, _ = _device_grad(_device_model(B), dev(om.flat_params().astype(np.float32)), mb, clip)
+    finally:
+        _lib.set_option('x6_dither', 1)
+    _report('b2048_backward_x6_dither_0', dm, g_0, g32, g64)
+    for t in dm.tensors:
+        if t['name'].endswith(('c1/w', 'vf/b')):
+            sl = slice(t['offset'], t['offset'] + t['size'])
+            assert np.abs(g_d[sl] - g64[sl]).max() < 0.6 * np.abs(g_0[sl] - g64[sl]).max(), t['name']
 
 
 def test_nature_cnn_train_step_at_b8192_vs_oracle():
