@@ -256,7 +256,11 @@ constexpr int CH_NB = 13;                                // blocks of 16 pixels:
 // unit's 40 KB have two unit times to arrive instead of one MFMA phase (~1.3 us, about the loaded HBM latency).
 template <int DBG = 0, bool PF2 = false>
 __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
-                                                                const float* __restrict__ dz, int B, float* __restrict__ part) {
+                                                                const float* __restrict__ dz, int B, float* __restrict__ part, int dither) {
+    // dither (x6_dither, wres.hip.h): every other workgroup stages dz negated and writes its slab with the sign undone
+    const bool sg_odd = dither && (blockIdx.x & 1);
+    const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
+    const float sg_s = sg_odd ? -1.f : 1.f;
     extern __shared__ __attribute__((aligned(16))) uint8_t cws[];
     uint8_t* T = cws;                                     // bf16 [44 rows][x & 3][c][x >> 2]
     uint16_t* dzt = reinterpret_cast<uint16_t*>(cws + CH_TBYTES);
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
                 for (int r = 0; r < 8; r += 2) {
                     const float x0 = j == 0 ? vd[r].x : j == 1 ? vd[r].y : j == 2 ? vd[r].z : vd[r].w;
                     const float x1 = j == 0 ? vd[r + 1].x : j == 1 ? vd[r + 1].y : j == 2 ? vd[r + 1].z : vd[r + 1].w;
-                    split2_bf16x3(x0, x1, p[0][r / 2], p[1][r / 2], p[2][r / 2]);
+                    split2_bf16x3_sg(x0, x1, sg_k, sg_s, p[0][r / 2], p[1][r / 2], p[2][r / 2]);
                 }
                 const int n = 4 * d_nc + j;
                 uint16_t* d = dzt + n * CH_PP + ((d_o & ~3) | ((d_o & 3) ^ (d_nc >> 1))) * 8;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (NA * kg + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            out[(long)m * C1_NF + i] = acc[a][r] / 255.f;
+            out[(long)m * C1_NF + i] = (sg_s * acc[a][r]) / 255.f;
         }
     __syncthreads();
     float4* rb4 = reinterpret_cast<float4*>(cws);
@@ -460,7 +464,7 @@ inline hipError_t launch_c1wgrad_half(const void* obs, const int32_t* srow, cons
     auto kern = pf2 ? c1wgrad_half_kernel<0, true> : c1wgrad_half_kernel<0, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CH_NT), CH_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CH_NT), CH_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part, x6_dither());
     return hipGetLastError();
 }
 

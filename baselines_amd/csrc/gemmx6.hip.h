@@ -384,7 +384,6 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 }
 
 inline int& x6_prio() { static int p = 0; return p; }
-inline int& x6_dither() { static int p = getenv("MRL_X6_DITHER") ? atoi(getenv("MRL_X6_DITHER")) : 1; return p; }     // mrl_set_option "x6_dither": alternate the sign of the staged A rows
 inline int& x6_xd() { static int p = 0; return p; }        // experiment bits (mrl_set_option "x6_dbg" = 100 + bits)      // experiment knob (mrl_set_option "x6_prio")
 inline bool gemm_x6_ok(const void* A, long lda, int K) {
     return K % X6_BK == 0 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;

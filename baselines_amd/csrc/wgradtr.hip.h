@@ -80,7 +80,7 @@ struct WgTrCfg {
 // immediates (one pixel stride each) -- and TN consecutive n tiles.
 template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, int dither) {
     using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
     static_assert(RF % TM == 0, "the m tiles of a wave are taps of one kernel row");
     extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
@@ -90,6 +90,12 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     constexpr int NGRP = G::NTN / TN;
     const int mt0 = (wave / NGRP) * TM, nt0 = (wave % NGRP) * TN;
 
+    // dither (x6_dither, wres.hip.h): every other workgroup stages dz NEGATED (no extra instruction) and writes its partial slab with
+    // the sign undone -- the matrix instruction's bias toward -inf then has opposite signs in neighbouring slabs
+    // and cancels in reduce_slabs' sum instead of adding up over the 256 slabs
+    const bool sg_odd = dither && (blockIdx.x & 1);
+    const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
+    const float sg_s = sg_odd ? -1.f : 1.f;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -157,8 +163,8 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
             const int e = tid + q * G::NT;
             if (e < G::DZV) {
                 uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
-                split2_bf16x3(rd[q].x, rd[q].y, a0x, a1x, a2x);
-                split2_bf16x3(rd[q].z, rd[q].w, a0y, a1y, a2y);
+                split2_bf16x3_sg(rd[q].x, rd[q].y, sg_k, sg_s, a0x, a1x, a2x);
+                split2_bf16x3_sg(rd[q].z, rd[q].w, sg_k, sg_s, a0y, a1y, a2y);
                 uint8_t* d = ds + dw0 + q * (G::NT / DQ) * G::DPS;
                 *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
                 *reinterpret_cast<uint2*>(d + NF * 2) = make_uint2(a1x, a1y);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
             for (int r = 0; r < 16; ++r) {
                 const int m = ((ky * RF + kx0 + a) * G::CB + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // K index (ky, kx, c)
                 const int n = (nt0 + c) * 32 + i;
-                out[(long)m * NF + n] = acc[a][c][r];
+                out[(long)m * NF + n] = sg_s * acc[a][c][r];
             }
     // bias: thread t owns filter columns (4t % NF .. +3); combine the NT*4/NF threads of a column in fixed order
     float4* red = reinterpret_cast<float4*>(wt_lds);
@@ -257,7 +263,7 @@ inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float*
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part, x6_dither());
     return hipGetLastError();
 }
 
@@ -291,7 +297,7 @@ struct WgTrDenseCfg {
 template <int MT>
 __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __restrict__ A, long lda, const float* __restrict__ dz,
                                                              float* __restrict__ part, long slab, int M, int K, int N,
-                                                             int ktiles, int ntiles, int rows_per_slab) {
+                                                             int ktiles, int ntiles, int rows_per_slab, int dither) {
     using G = WgTrDenseCfg<MT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
     uint8_t* as = wt_lds;
@@ -304,6 +310,9 @@ __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __rest
     const long m_begin = (long)s * rows_per_slab;
     const long m_end = min((long)M, m_begin + rows_per_slab);
     const int nsteps = (int)((m_end - m_begin + G::R - 1) / G::R);
+    const bool sg_odd = dither && (s & 1);               // every other slab: dz staged negated, the slab written with the sign undone
+    const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
+    const float sg_s = sg_odd ? -1.f : 1.f;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -362,8 +371,8 @@ __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __rest
             const int row = brow + q * (G::NT / G::BQ);
             if (m0 + row >= m_end) v = f4zero();
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
-            split2_bf16x3(v.x, v.y, a0x, a1x, a2x);
-            split2_bf16x3(v.z, v.w, a0y, a1y, a2y);
+            split2_bf16x3_sg(v.x, v.y, sg_k, sg_s, a0x, a1x, a2x);
+            split2_bf16x3_sg(v.z, v.w, sg_k, sg_s, a0y, a1y, a2y);
             uint8_t* d = bs + row * G::BRS + boff * 2;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
             *reinterpret_cast<uint2*>(d + G::BN * 2) = make_uint2(a1x, a1y);
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = k0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(long)m * N + n0 + wave * 32 + i] = acc[j][r];
+            out[(long)m * N + n0 + wave * 32 + i] = sg_s * acc[j][r];
         }
     if (kt == 0) {      // bias: thread t owns filter columns n0 + 4 (t % BQ) .. + 3; the NT / BQ threads of a quad in fixed order
         float4* red = reinterpret_cast<float4*>(wt_lds);
@@ -475,7 +484,7 @@ inline hipError_t launch_wgrad_tr_dense(const float* A, long lda, const float* d
             raised = true;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, stream, A, lda, dz, part, slab, M, K, N, p.ktiles, p.ntiles,
-                           p.rows_per_slab);
+                           p.rows_per_slab, x6_dither());
         return hipGetLastError();
     };
     if (p.mt == 7) return go(wgrad_tr_dense_kernel<7>, WgTrDenseCfg<7>::LDS_BYTES);

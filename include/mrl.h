@@ -427,7 +427,8 @@ int mrl_tune_set(const char* label, int variant);
  *   "x6_dither"   [MRL_X6_DITHER, 1]  the tiled split engines (forward and data-gradient GEMMs) stage every other row of their
  *                  streamed operand with its sign flipped and undo that in the epilogue (no extra instructions): the small
  *                  bias toward -inf that v_mfma_f32_32x32x16_bf16 has for products far below its accumulator then alternates
- *                  from sample to sample instead of adding up in the sums over a minibatch; 0 = all rows as is
+ *                  from sample to sample instead of adding up in the sums over a minibatch; the weight-gradient
+ *                  engines do the same with every other partial slab; 0 = everything staged as is
  *   "fused_norm"  [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "lstm_e1"     [MRL_LSTM_E1, 1]  LSTM scans of long trajectories with ONE environment per workgroup (plain fmaf chains, two
  *                  barriers per step) when groups of four environments would leave CUs idle; 0 = always four per workgroup

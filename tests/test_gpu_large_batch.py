@@ -324,6 +324,8 @@ def test_full_size_minibatch_backward_vs_oracle_every_entry():
     for t in dm.tensors:
         sl = slice(t['offset'], t['offset'] + t['size'])
         ref = g64[sl]
-        tol = 5e-5 * max(np.abs(ref).max(), 1e-3 * scale)          # the bar of test_nature_cnn_gradient_at_b2048
+        # 5e-6 of the tensor's scale, every entry (measured 0.9e-7 .. 1.2e-6 with the sign alternation of x6_dither; 1.35e-5 on the
+        # first layer's weights before it, which is why this bar used to be 5e-5)
+        tol = 5e-6 * max(np.abs(ref).max(), 1e-3 * scale)
         err = np.abs(g_d[sl] - ref).max()
         assert err <= tol, (t['name'], err, tol)

@@ -72,7 +72,8 @@ def test_recurrent_act_and_bptt_gradient_vs_oracle(name):
     np.testing.assert_array_equal(a_d.cpu().numpy().astype(np.int64), a_o)
     np.testing.assert_allclose(v_d.cpu().numpy(), v_o, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(nlp_d.cpu().numpy(), nlp_o, rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(st.cpu().numpy(), s_o, rtol=1e-4, atol=2e-6)          # (c | h) after the step
+    # (c | h) after the step; two fp32 implementations of gate pre-activations of size O(10) differ by a few 1e-6 in a cell state
+    np.testing.assert_allclose(st.cpu().numpy(), s_o, rtol=1e-4, atol=1e-5)
 
     # ---- learner: loss + gradient through all T steps of the nseq trajectories
     actions = rng.randint(0, 4, B)
