@@ -1,5 +1,5 @@
 """CPU: the one-line JSON contract of bench.py, checked on the committed result of the last GPU run
-(profiles/r04x_bench_atari4096.json) and on bench.py's own argument defaults."""
+(profiles/r04z_bench_atari4096.json) and on bench.py's own argument defaults."""
 import ast
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04x_bench_atari4096.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04z_bench_atari4096.json')))
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert d['metric'] == base['metric']
     for key in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
