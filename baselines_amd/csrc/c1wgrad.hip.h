@@ -250,6 +250,17 @@ constexpr int CH_PP = 240;                               // bf16 per dzT row: 20
 constexpr int CH_PLANE = C1_NF * CH_PP;
 constexpr size_t CH_LDS = (size_t)CH_TBYTES + (size_t)3 * CH_PLANE * 2;       // 81632
 constexpr int CH_NT = 256;
+// LDS bank conflicts (scripts/lds_conflicts.py; measured with SQ_LDS_BANK_CONFLICT: 0.36 of the LDS cycles of a kernel whose LDS is
+// busy 0.69 of the time before these two, 0.08 predicted after):
+//  * the runs (x & 3, c) of an image row are 48 bytes apart, 12 dwords: the 4-byte tail reads of the 12-byte operand windows (bank =
+//    dword mod 32) of the runs j and j + 8 hit the same bank; the runs 8 .. 15 are shifted by 8 bytes into the row's padding
+constexpr int CH_SKEW = 8;
+//  * octet slot of (filter row n, pixel octet oo) in dzT: oo with its low two bits XORed by (n >> 4) | parity(n >> 2) << 1.  The 16-byte
+//    fragment reads of a 16-lane group {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} start 30 n quads apart, -2 n mod 16: the rows n and
+//    n +- 8 / 24 of a group share a start and are told apart by bit 0 (one of each pair is below 16); bit 1 is constant inside a group
+//    (the parity of n >> 2 is what distinguishes the two groups), so it cannot make neighbours collide, and it spreads the 8 rows
+//    4 d + j that one staging store covers over four quads instead of two.  (n >> 3, the previous choice, made the reads 2-way.)
+__device__ __forceinline__ int ch_dz_swz(int n4 /* n >> 2 */) { return (n4 >> 2) | (((n4 ^ (n4 >> 1) ^ (n4 >> 2)) & 1) << 1); }
 constexpr int CH_NB = 13;                                // blocks of 16 pixels: 25 octets, the 26th is empty
 
 // PF2: the loads of unit u + 2 are issued while unit u is staged (two register sets, the unit loop unrolled by two): a
@@ -258,7 +269,7 @@ template <int DBG = 0, bool PF2 = false>
 __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* __restrict__ obs, const int32_t* __restrict__ srow,
                                                                 const float* __restrict__ dz, int B, float* __restrict__ part, int dither) {
     // dither (x6_dither, wres.hip.h): every other workgroup stages dz negated and writes its slab with the sign undone
-    const bool sg_odd = dither && (blockIdx.x & 1);
+    const bool sg_odd = (dither & 1) && (blockIdx.x & 1);
     const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
     const float sg_s = sg_odd ? -1.f : 1.f;
     extern __shared__ __attribute__((aligned(16))) uint8_t cws[];
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
                     const uint32_t f1 = __float_as_uint((float)((vi[1][p] >> (8 * c)) & 0xff));
                     const uint32_t f2 = __float_as_uint((float)((vi[2][p] >> (8 * c)) & 0xff));
                     const uint32_t f3 = __float_as_uint((float)((vi[3][p] >> (8 * c)) & 0xff));
-                    *reinterpret_cast<uint2*>(d + (p * 4 + c) * (CW_XI * 2)) =
+                    *reinterpret_cast<uint2*>(d + (p * 4 + c) * (CW_XI * 2) + CH_SKEW * (p >> 1)) =
                         make_uint2(__builtin_amdgcn_perm(f1, f0, 0x07060302u), __builtin_amdgcn_perm(f3, f2, 0x07060302u));
                 }
             if (img_tail) {
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        *reinterpret_cast<uint16_t*>(d + 8 + (p * 4 + c) * (CW_XI * 2)) =
+                        *reinterpret_cast<uint16_t*>(d + 8 + (p * 4 + c) * (CW_XI * 2) + CH_SKEW * (p >> 1)) =
                             (uint16_t)(__float_as_uint((float)((vi[4][p] >> (8 * c)) & 0xff)) >> 16);
             }
         }
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
                     split2_bf16x3_sg(x0, x1, sg_k, sg_s, p[0][r / 2], p[1][r / 2], p[2][r / 2]);
                 }
                 const int n = 4 * d_nc + j;
-                uint16_t* d = dzt + n * CH_PP + ((d_o & ~3) | ((d_o & 3) ^ (d_nc >> 1))) * 8;
+                uint16_t* d = dzt + n * CH_PP + ((d_o & ~3) | ((d_o & 3) ^ ch_dz_swz(d_nc))) * 8;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     *reinterpret_cast<u32x4v*>(d + pl * CH_PLANE) = u32x4v{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
@@ -349,9 +360,9 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     const int kx = i >> 2, cc = i & 3, shb = (kx >> 2) * 2;
-    const uint8_t* tl = T + ((kx & 3) * 4 + cc) * (CW_XI * 2) + (NA * kg) * CW_TROW;
+    const uint8_t* tl = T + ((kx & 3) * 4 + cc) * (CW_XI * 2) + CH_SKEW * ((kx & 3) >> 1) + (NA * kg) * CW_TROW;
     const uint8_t* bl = reinterpret_cast<const uint8_t*>(dzt + i * CH_PP);
-    const int bsw = i >> 3;
+    const int bsw = ch_dz_swz(i >> 2);
     uint32_t offT[CH_NB], offD[CH_NB];
 #pragma unroll
     for (int q = 0; q < CH_NB; ++q) {

@@ -93,9 +93,15 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     // dither (gemmx6.hip.h): the rows of a tile are IMAGES; every other group of 8 is staged negated and un-negated in the epilogue
-    const bool sg_odd = !PA && dither && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
+    const bool sg_odd = !PA && (dither & 1) && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
     const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
     const float sg_s = sg_odd ? -1.f : 1.f;
+    // dither & 2: which row a thread stages is permuted inside each group of 8 (b -> (b & 1) * 4 + (b >> 1)), so that the 16 lanes of a
+    // ds_write_b64 group (8 lanes of a ds_write_b128 group) hold rows r and r + 4 instead of r and r + 1: with the 80-byte row pitch
+    // their bank windows are then disjoint (r + 1 overlaps r on 4 of 32 banks: every staging store took two LDS cycles per group)
+    const bool rowperm = (dither & 2) != 0;
+    auto stage_row = [&](int r) { return rowperm ? ((r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)) : r; };
+    const int arow = stage_row(tid >> 3);
     if (dbg & 1) { hmask = nullptr; mbits = nullptr; }     // timing experiments (MRL_DGX6_DBG): 1 = no mask loads,
     for (long slot = blockIdx.x >> 3; slot < tiles_per_xcd; slot += slots_per_xcd) {      // 2 = no stores, 4 = no main loop
     const long lt = (long)xcd * tiles_per_xcd + slot;
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     } else {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
-        const int b = min(b0 + p * 32 + (tid >> 3), B - 1);
+        const int b = min(b0 + p * 32 + arow, B - 1);
         ap[p] = dz + ((long)(b * OH + yy) * OW + xx) * NF + (tid & 7) * 4;
     }
     }
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = q * 256 + tid;
-        bp[q] = Bp + (long)min(n0 + (c >> 2), G::N - 1) * G::K + (c & 3) * 8;
+        bp[q] = Bp + (long)min(n0 + stage_row(c >> 2), G::N - 1) * G::K + (c & 3) * 8;
     }
     constexpr long bplane = (long)G::N * G::K;
     // k tiles whose tap reads inside the dz map at this position (uniform over the workgroup)
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
             split2_bf16x3_sg(ra[p].x, ra[p].y, sg_k, sg_s, a0x, a1x, a2x);
             split2_bf16x3_sg(ra[p].z, ra[p].w, sg_k, sg_s, a0y, a1y, a2y);
-            uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
+            uint16_t* d = As + (p * 32 + arow) * X6_LDK + (tid & 7) * 4;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
             *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
             *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = q * 256 + tid;
-                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
+                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + stage_row(c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
             }
     };
     auto mma = [&](const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -301,10 +307,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b], (!PA && dither && (i & 8)) ? -1.f : 1.f);
+            for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b], (!PA && (dither & 1) && (i & 8)) ? -1.f : 1.f);
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (!PA && dither) {                   // registers with r & 4 hold the images 8..15, 24..31 that were staged negated
+    if (!PA && (dither & 1)) {                   // registers with r & 4 hold the images 8..15, 24..31 that were staged negated
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -128,9 +128,15 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     // epilogue multiplies their results by -1 -- the matrix instruction's bias toward -inf for products far below the accumulator
     //  then changes sign every 8 rows (samples / pixels) and cancels in every later sum over rows.  A thread stages
     // rows p*32 + tid/8: groups of 8 rows = waves, so the sign and the rounding constant are wave-uniform (scalar registers).
-    const bool sg_odd = !PA && dither && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
+    const bool sg_odd = !PA && (dither & 1) && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
     const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
     const float sg_s = sg_odd ? -1.f : 1.f;
+    // dither & 2: which row a thread stages is permuted inside each group of 8 (b -> (b & 1) * 4 + (b >> 1)), so that the 16 lanes of a
+    // ds_write_b64 group (8 lanes of a ds_write_b128 group) hold rows r and r + 4 instead of r and r + 1: with the 80-byte row pitch
+    // their bank windows are then disjoint (r + 1 overlaps r on 4 of 32 banks: every staging store took two LDS cycles per group)
+    const bool rowperm = (dither & 2) != 0;
+    auto stage_row = [&](int r) { return rowperm ? ((r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)) : r; };
+    const int arow = stage_row(tid >> 3);
     // staging addresses: A rows p*32 + tid/8, 4 floats at k = (tid&7)*4;  B rows (q*256 + tid)/4, 8 bf16 at ((..)&3)*8
     const float* ap[NA];
     const uint16_t* app[NAP];          // PA: rows p*64 + tid/4, 8 bf16 at k = (tid&3)*8, plane 0
@@ -141,13 +147,13 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     } else {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
-            ap[p] = static_cast<const float*>(af.p) + af.row_base(min(m0 + p * 32 + (tid >> 3), M - 1)) + (tid & 7) * 4;
+            ap[p] = static_cast<const float*>(af.p) + af.row_base(min(m0 + p * 32 + arow, M - 1)) + (tid & 7) * 4;
     }
     const uint16_t* bp[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = q * 256 + tid;
-        bp[q] = Bp + (long)min(n0 + (c >> 2), N - 1) * K + (c & 3) * 8;
+        bp[q] = Bp + (long)min(n0 + stage_row(c >> 2), N - 1) * K + (c & 3) * 8;
     }
     const long bplane = (long)N * K;
     const int ntile = K / X6_BK;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 split2_bf16x3_sg(ra[p].x, ra[p].y, sg_k, sg_s, a0x, a1x, a2x);
                 split2_bf16x3_sg(ra[p].z, ra[p].w, sg_k, sg_s, a0y, a1y, a2y);
             }
-            uint16_t* d = As + (p * 32 + (tid >> 3)) * X6_LDK + (tid & 7) * 4;
+            uint16_t* d = As + (p * 32 + arow) * X6_LDK + (tid & 7) * 4;
             *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
             *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
             *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = q * 256 + tid;
-                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + (c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
+                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + stage_row(c >> 2)) * X6_LDK + (c & 3) * 8) = rb[pl * NQ + q];
             }
     };
     // TR: D^T = B A^T -- the first MFMA operand supplies the accumulator's register-indexed dimension
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
                 const int row = m0 + (wm * 2 + a) * 32 + i, cb = n0 + (wn * 2 + b) * 32;
                 const bool valid = row < M && cb < N;
                 tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? (long)row * ef.ld + cb : 0L, h, valid,
-                                  (!PA && dither && (i & 8)) ? -1.f : 1.f);
+                                  (!PA && (dither & 1) && (i & 8)) ? -1.f : 1.f);
             }
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
     // wave's 32 rows x 2 column blocks are collected into lane (row_in_block*2 + b) and stored with ONE instruction
     const int mk_row = lane >> 1, mk_b = lane & 1;
     const int mk_r = (mk_row & 3) + 4 * (mk_row >> 3), mk_h = (mk_row >> 2) & 1;
-    if (!PA && dither) {                   // rows (r&3) + 8*(r>>2) + 4h: registers with r & 4 hold the rows 8..15, 24..31 that were staged negated
+    if (!PA && (dither & 1)) {                   // rows (r&3) + 8*(r>>2) + 4h: registers with r & 4 hold the rows 8..15, 24..31 that were staged negated
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll

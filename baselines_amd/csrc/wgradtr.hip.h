@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     // dither (x6_dither, wres.hip.h): every other workgroup stages dz NEGATED (no extra instruction) and writes its partial slab with
     // the sign undone -- the matrix instruction's bias toward -inf then has opposite signs in neighbouring slabs
     // and cancels in reduce_slabs' sum instead of adding up over the 256 slabs
-    const bool sg_odd = dither && (blockIdx.x & 1);
+    const bool sg_odd = (dither & 1) && (blockIdx.x & 1);
     const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
     const float sg_s = sg_odd ? -1.f : 1.f;
     f32x16 acc[TM][TN];
@@ -132,22 +132,27 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     constexpr int A_STEP = G::XPS;                                              // next tap of the kernel row: one pixel
 
     // ---- staging: global -> registers (16-byte loads) -> split -> LDS [pixel][plane][c]
+    // (C = 32: the 16 lanes of an 8-byte LDS store group hold two pixels whose bank windows overlap on 8 of 32 banks with the
+    // 224-byte pixel pitch; taking the pixels of a group of four in the order 0 2 1 3 removes those conflicts -- SQ_LDS_BANK_CONFLICT
+    // 0.23 -> 0.10 of the LDS cycles -- and made the kernel 6 % SLOWER, 3.85 -> 4.07 ms: the global loads of a wave then walk its
+    // 1 KB in the order 0 2 1 3 as well.  Not used.)
+    const int xtid = tid;
     float4 rx[G::NXV], rd[G::NDV];
     auto issue_loads = [&](int bb) {
         const float4* gx = reinterpret_cast<const float4*>(x + (long)bb * (H * W * C));
         const float4* gd = reinterpret_cast<const float4*>(dz + (long)bb * (G::NPIX * NF));
 #pragma unroll
-        for (int q = 0; q < G::NXV; ++q) { const int e = tid + q * G::NT; rx[q] = gx[e < G::XV ? e : G::XV - 1]; }
+        for (int q = 0; q < G::NXV; ++q) { const int e = xtid + q * G::NT; rx[q] = gx[e < G::XV ? e : G::XV - 1]; }
 #pragma unroll
         for (int q = 0; q < G::NDV; ++q) { const int e = tid + q * G::NT; rd[q] = gd[e < G::DZV ? e : G::DZV - 1]; }
     };
     constexpr int XQ = C / 4, DQ = NF / 4;                     // float4 per pixel
-    const int xw0 = (tid / XQ) * G::XPS + (tid % XQ) * 8;      // + q * (NT / XQ) * XPS
+    const int xw0 = (xtid / XQ) * G::XPS + (xtid % XQ) * 8;    // + q * (NT / XQ) * XPS
     const int dw0 = (tid / DQ) * G::DPS + (tid % DQ) * 8;
     auto write_stage = [&]() {
 #pragma unroll
         for (int q = 0; q < G::NXV; ++q) {
-            const int e = tid + q * G::NT;
+            const int e = xtid + q * G::NT;
             if (e < G::XV) {
                 uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
                 split2_bf16x3(rx[q].x, rx[q].y, a0x, a1x, a2x);
@@ -284,7 +289,11 @@ inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float*
 template <int MT>
 struct WgTrDenseCfg {
     static constexpr int BK = MT * 32, BN = 256, R = 32, NT = 512;
-    static constexpr int ARS = 3 * BK * 2 + 64, BRS = 3 * BN * 2 + 64;      // LDS bytes per sample row: [plane][column] + pad
+    // LDS bytes per sample row: [plane][column] + pad so that consecutive rows start 16 dwords apart mod 64: the four sample rows of a
+    // transpose read (64 bytes each) and the two rows a staging store group can straddle then use disjoint banks.  MT = 7: 336
+    // dwords = 16 mod 64 without padding (the fixed 64-byte pad of round 3 made it 32: two-way conflicts, scripts/lds_conflicts.py)
+    static constexpr int row_pad(int bytes) { return ((16 - (bytes / 4) % 64 + 64) % 64) * 4; }
+    static constexpr int ARS = 3 * BK * 2 + row_pad(3 * BK * 2), BRS = 3 * BN * 2 + row_pad(3 * BN * 2);
     static constexpr int A_BYTES = R * ARS, B_BYTES = R * BRS;
     static constexpr size_t LDS_BYTES = (size_t)A_BYTES + B_BYTES;
     static constexpr int AQ = BK / 4, BQ = BN / 4;                           // float4 per row
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __rest
     const long m_begin = (long)s * rows_per_slab;
     const long m_end = min((long)M, m_begin + rows_per_slab);
     const int nsteps = (int)((m_end - m_begin + G::R - 1) / G::R);
-    const bool sg_odd = dither && (s & 1);               // every other slab: dz staged negated, the slab written with the sign undone
+    const bool sg_odd = (dither & 1) && (s & 1);               // every other slab: dz staged negated, the slab written with the sign undone
     const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
     const float sg_s = sg_odd ? -1.f : 1.f;
 

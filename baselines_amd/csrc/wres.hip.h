@@ -505,9 +505,11 @@ __device__ __forceinline__ void split2_bf16x3_sg(float x0, float x1, uint32_t k,
     const float l0 = r0 - __uint_as_float(v0 & 0xffff0000u), l1 = r1 - __uint_as_float(v1 & 0xffff0000u);
     p2 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
 }
-// mrl_set_option "x6_dither" [MRL_X6_DITHER, 1]: forward / data-gradient engines alternate the sign of groups of 8 staged rows, the
-// weight-gradient engines the sign of every other partial slab (one operand staged negated, the slab written with the sign undone)
-inline int& x6_dither() { static int p = getenv("MRL_X6_DITHER") ? atoi(getenv("MRL_X6_DITHER")) : 1; return p; }
+// mrl_set_option "x6_dither" [MRL_X6_DITHER, 3], two bits.  1: forward / data-gradient engines alternate the sign of groups of 8
+// staged rows, the weight-gradient engines the sign of every other partial slab (one operand staged negated, the result written
+// with the sign undone).  2: the tiled engines permute which row of a group of 8 a thread stages so that their LDS stores are free
+// of bank conflicts (gemmx6.hip.h; bit-identical results).
+inline int& x6_dither() { static int p = getenv("MRL_X6_DITHER") ? atoi(getenv("MRL_X6_DITHER")) : 3; return p; }
 // one value -> the bf16 bit patterns of its three planes (the weight-plane kernels)
 __device__ __forceinline__ void split1_bf16x3(float v, uint16_t& b0, uint16_t& b1, uint16_t& b2) {
     uint32_t q0, q1, q2;

@@ -424,11 +424,13 @@ int mrl_tune_set(const char* label, int variant);
  *                  engine.  4, 3 and 2 are bit-identical (same products, same order of accumulation).
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
- *   "x6_dither"   [MRL_X6_DITHER, 1]  the tiled split engines (forward and data-gradient GEMMs) stage every other row of their
- *                  streamed operand with its sign flipped and undo that in the epilogue (no extra instructions): the small
+ *   "x6_dither"   [MRL_X6_DITHER, 3]  two bits.  Bit 0: the tiled split engines (forward and data-gradient GEMMs) stage every other
+ *                  group of 8 rows of their streamed operand with its sign flipped and undo that in the epilogue (no extra instructions): the small
  *                  bias toward -inf that v_mfma_f32_32x32x16_bf16 has for products far below its accumulator then alternates
  *                  from sample to sample instead of adding up in the sums over a minibatch; the weight-gradient
- *                  engines do the same with every other partial slab; 0 = everything staged as is
+ *                  engines do the same with every other partial slab.  Bit 1: the tiled engines' staging threads take the rows of
+ *                  a group of 8 in the order 0 4 1 5 2 6 3 7, which keeps their LDS stores free of bank conflicts (bit-identical,
+ *                  c2.fwd / c3.fwd -1.5 .. -2 %).  0 = everything staged as is
  *   "fused_norm"  [MRL_FUSED_NORM, 1]  mrl_model_train_step takes the global norm from the gradient reductions
  *   "lstm_e1"     [MRL_LSTM_E1, 1]  LSTM scans of long trajectories with ONE environment per workgroup (plain fmaf chains, two
  *                  barriers per step) when groups of four environments would leave CUs idle; 0 = always four per workgroup

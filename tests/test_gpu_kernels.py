@@ -348,7 +348,7 @@ def test_engine_options_agree():
     assert defaults['f32_bf16x6'] == 2 and L.get_option('f32_products') in (6, 8), 'split engines are the default'
     assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 / fc1 weight gradients: transpose-read kernels by default'
     assert defaults['c1_lds'] == 4, 'first conv layer forward: software-pipelined image-resident kernel by default'
-    assert defaults['x6_dither'] == 1, 'tiled split engines: sign of the staged rows alternates by default'
+    assert defaults['x6_dither'] == 3, 'tiled split engines: sign alternation of the staged rows and conflict-free staging order by default'
     if experiments:
         assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
     try:
@@ -356,7 +356,7 @@ def test_engine_options_agree():
         # ---- small batches (screened samples for the NatureCNN cases, plain random data for the MLPs)
         om_s, _, mb_s = _problem(168, 23)
         small = [(cnn, 160, 'u8_bf16x3', 1), (cnn, 161, 'c1_lds', 1), (cnn, 163, 'c1_wgrad2', 1), (cnn, 165, 'tr_epilogue', 1),
-                 (cnn, 168, 'x6_pg', 8), (cnn, 164, 'x6_dither', 1),
+                 (cnn, 168, 'x6_pg', 8), (cnn, 164, 'x6_dither', 3),
                  (('mlp', (376,), np.float32, 'gaussian', 17, True), 200, 'mlp_fused', 1),
                  (('mlp', (376,), np.float32, 'gaussian', 17, True), 203, 'mlp_slice', 1),       # (tile, net) workgroups vs one per tile
                  (('mlp', (12,), np.float32, 'categorical', 5, True), 97, 'mlp_slice', 1),
@@ -385,6 +385,8 @@ def test_engine_options_agree():
                  ('split engines, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
                  ('split engines, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
                  ('split engines, every row staged as is (no sign alternation)', dict(defaults, x6_dither=0), 3e-6),
+                 ('split engines, sign alternation without the conflict-free staging order', dict(defaults, x6_dither=1), 3e-6),
+                 ('split engines, conflict-free staging order without the sign alternation', dict(defaults, x6_dither=2), 3e-6),
                  ('split engines, no sign alternation, row-major accumulators', dict(defaults, x6_dither=0, tr_epilogue=0), 3e-6),
                  ('split engines, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
                  ('split engines, first conv layer forward: lock-step phases instead of the software pipeline',
