@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmrl.so')
+LIB_PATH = os.environ.get('MRL_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmrl.so')      # MRL_LIB_PATH: A/B of two builds on one box
 
 c_void_p, c_int, c_long, c_float, c_double, c_size_t, c_char_p = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_char_p)

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     // dither (x6_dither, wres.hip.h): every other workgroup stages dz NEGATED (no extra instruction) and writes its partial slab with
     // the sign undone -- the matrix instruction's bias toward -inf then has opposite signs in neighbouring slabs
     // and cancels in reduce_slabs' sum instead of adding up over the 256 slabs
-    const bool sg_odd = (dither & 1) && (blockIdx.x & 1);
+    const bool sg_odd = dither && (blockIdx.x & 1);              // the launcher passes bit 0 of x6_dither
     const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
     const float sg_s = sg_odd ? -1.f : 1.f;
     f32x16 acc[TM][TN];
@@ -134,25 +134,23 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     // ---- staging: global -> registers (16-byte loads) -> split -> LDS [pixel][plane][c]
     // (C = 32: the 16 lanes of an 8-byte LDS store group hold two pixels whose bank windows overlap on 8 of 32 banks with the
     // 224-byte pixel pitch; taking the pixels of a group of four in the order 0 2 1 3 removes those conflicts -- SQ_LDS_BANK_CONFLICT
-    // 0.23 -> 0.10 of the LDS cycles -- and made the kernel 6 % SLOWER, 3.85 -> 4.07 ms: the global loads of a wave then walk its
-    // 1 KB in the order 0 2 1 3 as well.  Not used.)
-    const int xtid = tid;
+    // 0.23 -> 0.10 of the LDS cycles -- without making the kernel faster (same-box A/B: 4.13 / 4.13 ms).  Not used.)
     float4 rx[G::NXV], rd[G::NDV];
     auto issue_loads = [&](int bb) {
         const float4* gx = reinterpret_cast<const float4*>(x + (long)bb * (H * W * C));
         const float4* gd = reinterpret_cast<const float4*>(dz + (long)bb * (G::NPIX * NF));
 #pragma unroll
-        for (int q = 0; q < G::NXV; ++q) { const int e = xtid + q * G::NT; rx[q] = gx[e < G::XV ? e : G::XV - 1]; }
+        for (int q = 0; q < G::NXV; ++q) { const int e = tid + q * G::NT; rx[q] = gx[e < G::XV ? e : G::XV - 1]; }
 #pragma unroll
         for (int q = 0; q < G::NDV; ++q) { const int e = tid + q * G::NT; rd[q] = gd[e < G::DZV ? e : G::DZV - 1]; }
     };
     constexpr int XQ = C / 4, DQ = NF / 4;                     // float4 per pixel
-    const int xw0 = (xtid / XQ) * G::XPS + (xtid % XQ) * 8;    // + q * (NT / XQ) * XPS
+    const int xw0 = (tid / XQ) * G::XPS + (tid % XQ) * 8;      // + q * (NT / XQ) * XPS
     const int dw0 = (tid / DQ) * G::DPS + (tid % DQ) * 8;
     auto write_stage = [&]() {
 #pragma unroll
         for (int q = 0; q < G::NXV; ++q) {
-            const int e = xtid + q * G::NT;
+            const int e = tid + q * G::NT;
             if (e < G::XV) {
                 uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
                 split2_bf16x3(rx[q].x, rx[q].y, a0x, a1x, a2x);
@@ -268,7 +266,7 @@ inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float*
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part, x6_dither());
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part, x6_dither() & 1);
     return hipGetLastError();
 }
 
