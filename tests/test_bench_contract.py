@@ -59,3 +59,32 @@ def test_bench_defaults_to_one_gpu_and_a_short_run():
                     defaults[name] = kw.value.value
     assert defaults['--gpus'] == 1 and defaults['--steps'] <= 5 and defaults['--warmup'] <= 2
     assert 'oracle' in src and 'cpu_baseline' in src            # the only product-side file allowed to touch oracle/
+
+
+def test_committed_counter_traffic_belongs_to_the_committed_kernel_sources():
+    """bench.py attaches roofline.traffic only when profiles/*_pmc_hbm.json was collected from the sources that run: the newest committed
+    file must carry the hash of the kernel sources in the tree (a kernel edit without a new counter pass shows up here, on CPU)"""
+    import glob
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')))[-1]
+    assert json.load(open(newest))['source_sha16'] == bench.source_sha16(), newest
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04z_bench_atari4096.json')))
+    assert os.path.basename(newest) in d['roofline']['traffic_source']
+
+
+def test_lds_bank_conflict_model_reproduces_the_measured_ratios():
+    """scripts/lds_conflicts.py (lane groups / bank moduli of MI355X_MICROARCH.md): the ratios SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    measured before the layouts were changed (profiles/README.md, round 4), and zero for the tiled engines' permuted staging order"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import lds_conflicts as L
+
+    def ratio(t):
+        c = sum(r[2] for r in t.rows)
+        i = sum(r[3] for r in t.rows)
+        return (c - i) / c
+    assert abs(ratio(L.gemm_x6(False)) - 0.36) < 0.01 and abs(ratio(L.gemm_x6(False, 128, 128)) - 0.33) < 0.01
+    assert ratio(L.gemm_x6(True)) == 0 and ratio(L.gemm_x6(True, 128, 128)) == 0
+    assert abs(ratio(L.c1wgrad_half()) - 0.36) < 0.02
