@@ -1165,14 +1165,26 @@ __global__ __launch_bounds__(256) void heads_train_wave_kernel(HeadArgs a) {
     if (tid < 5) a.spart[blockIdx.x * 5 + tid] = ((sst[0][tid] + sst[1][tid]) + sst[2][tid]) + sst[3][tid];
 }
 
-// stats_acc[j] += sum_blk spart[blk][j]
-__global__ void heads_stats_reduce_kernel(const double* __restrict__ spart, int nblk, double* __restrict__ acc) {
-    int j = threadIdx.x;
-    if (j < 5) {
-        double s = acc[j];
-        for (int b = 0; b < nblk; ++b) s += spart[b * 5 + j];
-        acc[j] = s;
+// stats_acc[j] += sum_blk spart[blk][j].  One workgroup: thread t adds the blocks t, t + 256, ... of statistic j in that order, the 256
+// partial sums are combined by a fixed tree (run-to-run identical).  (A single thread per statistic walking all blocks took 60 us per
+// minibatch step -- 2.4 % of config 3's update, rocprofv3 trace of the N = 512 row.)
+__global__ __launch_bounds__(256) void heads_stats_reduce_kernel(const double* __restrict__ spart, int nblk, double* __restrict__ acc) {
+    __shared__ double red[5][256];
+    const int t = threadIdx.x;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = t; b < nblk; b += 256)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) s[j] += spart[b * 5 + j];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) red[j][t] = s[j];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) red[j][t] += red[j][t + w];
+        __syncthreads();
     }
+    if (t < 5) acc[t] += red[t][0];
 }
 __global__ void stats_finalize_kernel(const double* __restrict__ acc, float invB, float* __restrict__ out) {
     int j = threadIdx.x;
@@ -2447,7 +2459,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         }
         MRL_LAUNCH_CHECK();
         if ((rc = reduce_slabs(ws.part, m->HP, nblk, grads_out + m->head_off, m->HP, accumulate, st, &ctx))) return rc;
-        hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(64), 0, st, spart, nblk, stats_acc);
+        hipLaunchKernelGGL(heads_stats_reduce_kernel, dim3(1), dim3(256), 0, st, spart, nblk, stats_acc);
         MRL_LAUNCH_CHECK();
         if (m->pi.lstm && (rc = lstm_backward(m->pi, in, params, ws.pi, ws, grads_out, rnn->nseq, Bc / rnn->nseq, rnn->masks,
                                               in.srow, st, ctx)))
