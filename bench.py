@@ -524,11 +524,20 @@ class DeviceStateSampler:
 
 
 def check_breakdown(kernel_ms, ms_per_step, roof, what):
-    """a per-kernel breakdown is evidence only if it fits inside the step it was measured in"""
+    """a per-kernel breakdown is evidence only if it fits inside the step it was measured in.
+    -> None when it does, else the violation as text: the caller records it in the JSON line (`breakdown_check`) and on stderr
+    instead of losing the whole measurement to an exception; tests/test_bench_contract.py asserts on the committed line."""
     tot = sum(kernel_ms.values())
-    assert tot <= ms_per_step * 1.002 + 0.01, ('%s: kernel times sum to %.3f ms of a %.3f ms step' % (what, tot, ms_per_step))
+    bad = []
+    if tot > ms_per_step * 1.002 + 0.01:
+        bad.append('%s: kernel times sum to %.3f ms of a %.3f ms step' % (what, tot, ms_per_step))
     if roof and roof.get('avg_ms') and roof.get('launches'):
-        assert roof['avg_ms'] * roof['launches'] <= ms_per_step * max(1, roof.get('prof_steps', 1)) * 1.002 + 0.01, (what, roof['avg_ms'], roof['launches'])
+        if roof['avg_ms'] * roof['launches'] > ms_per_step * max(1, roof.get('prof_steps', 1)) * 1.002 + 0.01:
+            bad.append('%s: dominant kernel %.3f ms x %d launches exceeds its steps' % (what, roof['avg_ms'], roof['launches']))
+    if bad:
+        sys.stderr.write('bench.py: breakdown check FAILED: %s\n' % '; '.join(bad))
+        return '; '.join(bad)
+    return None
 
 
 def dominant_roofline(res, sites, workload):
@@ -676,7 +685,8 @@ def main():
         if res['prof']:
             out['kernel_ms_per_step'] = {k: round(v['ms'] / res['prof_steps'], 3) for k, v in
                                          sorted(res['prof'].items(), key=lambda kv: -kv[1]['ms'])}
-            check_breakdown(out['kernel_ms_per_step'], res.get('traced_ms_per_step') or out['ms_per_step'], roof, out['config']['workload'])
+            out['breakdown_check'] = check_breakdown(out['kernel_ms_per_step'], res.get('traced_ms_per_step') or out['ms_per_step'], roof,
+                                                     out['config']['workload']) or 'ok: kernel times fit inside the timed step'
             out['kernel_rooflines'] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                        for k, v in per.items()}
         default_run = (world == 1 and args.workload == 'atari' and args.num_envs is None and args.nsteps == 128
@@ -684,7 +694,7 @@ def main():
         if default_run and not args.no_other_configs:
             # BASELINE.json's other single-GPU configurations, short runs (3 timed updates each), own rooflines
             others = []
-            for wl, n_envs in (('mujoco', 1024), ('atari', 256), ('atari', 512), ('atari_lstm', 256)):
+            def other_row(wl, n_envs):
                 nst, nwu = (12, 3) if wl == 'mujoco' else (3, 1)      # the 28 ms MLP update needs a longer window to time stably
                 r = run_ppo2(wl, n_envs, 128, nst, nwu, None, 1, 0, None, not args.no_prof)
                 apply_graph_trace(r, wl, n_envs, 128)
@@ -710,12 +720,27 @@ def main():
                         'whole_job_env_steps_per_s_if_the_allreduce_hides': 4096 * 128 / (row['ms_per_step'] * 1e-3),
                         'note': 'upper bound from the measured single-GPU shard; the driver measures the real 8-GPU number'}
                 if r['prof']:
-                    check_breakdown(row['kernel_ms_per_step'], r.get('traced_ms_per_step') or row['ms_per_step'], rf, name)
-                others.append(row)
-            others.append(replay_config())
+                    row['breakdown_check'] = check_breakdown(row['kernel_ms_per_step'], r.get('traced_ms_per_step') or row['ms_per_step'], rf, name) or 'ok'
+                return row
+            # the headline above is already measured: a failure in one of the secondary rows is recorded in that row, not raised
+            for wl, n_envs in (('mujoco', 1024), ('atari', 256), ('atari', 512), ('atari_lstm', 256)):
+                try:
+                    others.append(other_row(wl, n_envs))
+                except Exception as exc:
+                    sys.stderr.write('bench.py: other config %s num_envs=%d FAILED: %r\n' % (wl, n_envs, exc))
+                    others.append({'workload': 'ppo2 update-only %s num_envs=%d nsteps=128' % (wl, n_envs), 'error': repr(exc)})
+            try:
+                others.append(replay_config())
+            except Exception as exc:
+                sys.stderr.write('bench.py: replay config FAILED: %r\n' % (exc,))
+                others.append({'workload': 'deepq replay', 'error': repr(exc)})
             out['other_configs'] = others
         if world == 1 and not args.no_cpu_baseline and args.workload in ('atari', 'mujoco'):
-            out['cpu_baseline'] = cpu_baseline(args.workload)
+            try:
+                out['cpu_baseline'] = cpu_baseline(args.workload)
+            except Exception as exc:
+                sys.stderr.write('bench.py: cpu_baseline FAILED: %r\n' % (exc,))
+                out['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
