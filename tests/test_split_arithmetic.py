@@ -140,3 +140,35 @@ def test_transposed_accumulator_layout_and_plane_order():
     ap, bp = np.empty(64), np.empty(64)
     ap[kp], bp[kp] = a, b
     assert abs(ap @ bp - a @ b) < 1e-12
+
+
+def split3_sg(x, negate):
+    """NumPy emulation of `split2_bf16x3_sg` (csrc/wres.hip.h): the planes of s x, s = -1 when `negate`, from the bits of x -- the
+    rounding constant carries the sign flip (adding 2^31 flips bit 31), the first residual is one fma s x - plane0"""
+    x = np.asarray(x, np.float32)
+    k = 0x80008000 if negate else 0x8000
+    s = np.float32(-1.0 if negate else 1.0)
+    t = (x.view(np.uint32).astype(np.uint64) + k) & 0xffffffff
+    p0 = (t & 0xffff0000).astype(np.uint32).view(np.float32)
+    r1 = (s.astype(np.float64) * x.astype(np.float64) - p0.astype(np.float64)).astype(np.float32)     # fma: one rounding (exact here)
+    p1 = round_bf16(r1)
+    r2 = r1 - p1
+    return p0, p1, round_bf16(r2), r2
+
+
+def test_signed_split_yields_exactly_the_planes_of_the_negated_value():
+    """the sign alternation of the staged rows (x6_dither) costs no instruction because the split of -x falls out of
+    the bits of x: every plane equals the plane of split3(-x), for every mantissa and both signs; s = +1 is the plain split"""
+    x = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3f800000)).view(np.float32)
+    for sign in (1.0, -1.0):
+        v = np.float32(sign) * x
+        ref = split3(-v)
+        got = split3_sg(v, True)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(split3_sg(v, False), split3(v)):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    rng = np.random.RandomState(3)
+    v = _values(rng, 200000)
+    for a, b in zip(split3_sg(v, True)[:3], split3(-v)[:3]):
+        np.testing.assert_array_equal(a, b)
