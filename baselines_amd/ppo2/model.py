@@ -42,6 +42,50 @@ def ortho_init(shape, scale):
     return (scale * q[:shape[0], :shape[1]]).astype(np.float32)
 
 
+def checkpoint_to_flat(loaded, tensors):
+    """Host-only half of `Model.load` (no device needed): maps what `joblib.load` returned from a checkpoint written by
+    the reference's `save_variables` (tf_util.py:345-355) onto the flat parameter / Adam-slot buffers.
+
+    tensors: [(tf_variable_name, shape, offset, size)] in variable-creation order (`mrl_model_tensor_info`).
+    loaded:  * dict {var.name: ndarray} -- `ppo2_model/.../w:0`, `.../w/Adam:0`, `.../w/Adam_1:0`, `beta1_power:0`,
+               `beta2_power:0` (tf_util.py:367-369 assigns by name; here parameters are required, optimizer state optional);
+             * list (legacy format, tf_util.py:362-366) -- one array per GLOBAL variable in creation order: the n model
+               variables, then what `AdamOptimizer._create_slots` adds when `apply_gradients` runs outside the
+               `ppo2_model` scope (model.py:100-114): beta1_power, beta2_power, then (m, v) for each variable in turn.
+               A list of only the n model variables (saved with `variables=trainable`) is accepted too; any other length
+               fails with the reference's message.
+    Returns {'params' | 'adam_m' | 'adam_v': [(offset, flat float32 array)], 'beta_powers': (b1, b2) | None}."""
+    out = {'params': [], 'adam_m': [], 'adam_v': [], 'beta_powers': None}
+
+    def put(key, t, arr):
+        name, shape, off, size = t
+        a = np.asarray(arr, np.float32)
+        if a.size != size or (a.ndim and tuple(a.shape) != tuple(shape) and a.ndim != 1):
+            raise ValueError('checkpoint variable %s has shape %s, the model expects %s' % (name, a.shape, tuple(shape)))
+        out[key].append((off, a.reshape(-1)))
+
+    n = len(tensors)
+    if isinstance(loaded, list):
+        assert len(loaded) in (n, 3 * n + 2), 'number of variables loaded mismatches len(variables)'
+        for t, a in zip(tensors, loaded[:n]):
+            put('params', t, a)
+        if len(loaded) > n:
+            out['beta_powers'] = (np.float32(loaded[n]), np.float32(loaded[n + 1]))
+            for i, t in enumerate(tensors):
+                put('adam_m', t, loaded[n + 2 + 2 * i])
+                put('adam_v', t, loaded[n + 3 + 2 * i])
+        return out
+    for t in tensors:
+        put('params', t, loaded[t[0] + ':0'])          # KeyError for a missing model variable, like tf_util.py:369
+        if t[0] + '/Adam:0' in loaded:
+            put('adam_m', t, loaded[t[0] + '/Adam:0'])
+        if t[0] + '/Adam_1:0' in loaded:
+            put('adam_v', t, loaded[t[0] + '/Adam_1:0'])
+    if 'beta1_power:0' in loaded:
+        out['beta_powers'] = (np.float32(loaded['beta1_power:0']), np.float32(loaded['beta2_power:0']))
+    return out
+
+
 class Model(object):
     loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
 
@@ -442,26 +486,19 @@ class Model(object):
         joblib.dump(d, save_path)
 
     def load(self, load_path):
-        """tf_util.py:357-372: assigns by variable name (missing Adam slots keep their values)."""
+        """tf_util.py:357-372: a dict is assigned by variable name (missing Adam slots keep their values), the legacy
+        LIST format (`:362-366`) by position in GLOBAL_VARIABLES order -- see `checkpoint_to_flat`."""
         import joblib
-        d = joblib.load(os.path.expanduser(load_path))
-
-        def fill(dst, suffix, required):
+        loaded = joblib.load(os.path.expanduser(load_path))
+        tensors = [(t['name'], tuple(t['shape']), t['offset'], t['size']) for t in self.dm.tensors]
+        out = checkpoint_to_flat(loaded, tensors)
+        for dst, key in ((self.params, 'params'), (self.adam_m, 'adam_m'), (self.adam_v, 'adam_v')):
             host = dst.detach().cpu().numpy()
-            for t in self.dm.tensors:
-                key = t['name'] + suffix
-                if key in d:
-                    host[t['offset']:t['offset'] + t['size']] = np.asarray(d[key], np.float32).reshape(-1)
-                elif required:
-                    raise KeyError(key)
+            for off, arr in out[key]:
+                host[off:off + arr.size] = arr
             dst.copy_(torch.from_numpy(host))
-
-        fill(self.params, ':0', True)
-        fill(self.adam_m, '/Adam:0', False)
-        fill(self.adam_v, '/Adam_1:0', False)
-        if 'beta1_power:0' in d:
-            self.beta1_power = np.float32(d['beta1_power:0'])
-            self.beta2_power = np.float32(d['beta2_power:0'])
+        if out['beta_powers'] is not None:
+            self.beta1_power, self.beta2_power = out['beta_powers']
 
     # helpers for tests / users
     def get_flat_params(self):

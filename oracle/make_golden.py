@@ -7,7 +7,10 @@ own code (imported from /root/reference, never copied) in the build container:
   * baselines.common.segment_tree.{Sum,Min}SegmentTree and
     baselines.deepq.replay_buffer.PrioritizedReplayBuffer (loaded by file path because
     deepq/__init__.py imports tensorflow) driven by a seeded op stream;
-  * baselines.common.math_util.explained_variance, baselines.common.schedules.
+  * baselines.common.math_util.explained_variance, baselines.common.schedules;
+  * baselines/a2c/utils.py:20-35 ``ortho_init`` -- pure NumPy inside a module that imports
+    tensorflow, so the FUNCTION's source is cut out of the file with ``ast`` and exec'd as it
+    stands; seeded outputs -> ortho_init.npz.
 
 The reference cannot travel to the GPU box, so the vectors are committed.
 Run:  python oracle/make_golden.py      (needs /root/reference; a stub `gym` module is
@@ -226,6 +229,58 @@ def gen_replay(segment_tree, rb):
     np.savez_compressed(os.path.join(OUT, 'segment_tree.npz'), log=np.array(log, np.float64))
 
 
+ORTHO_SHAPES = [((8, 8, 4, 32), 2 ** 0.5), ((3136, 512), 2 ** 0.5), ((512, 6), 0.01), ((376, 64), 2 ** 0.5)]
+# TF variable-creation order of nature_cnn + heads (models.py:15-26, policies.py:49,63) and of
+# mlp(2x64) with value_network='copy' on a Box(376,) / 17-dim Gaussian policy (policies.py:141-166)
+ORTHO_NETS = {
+    'nature_cnn_nact6': [((8, 8, 4, 32), 2 ** 0.5), ((4, 4, 32, 64), 2 ** 0.5), ((3, 3, 64, 64), 2 ** 0.5),
+                         ((3136, 512), 2 ** 0.5), ((512, 6), 0.01), ((512, 1), 1.0)],
+    'mlp_copy_376_17': [((376, 64), 2 ** 0.5), ((64, 64), 2 ** 0.5), ((376, 64), 2 ** 0.5), ((64, 64), 2 ** 0.5),
+                        ((64, 17), 0.01), ((64, 1), 1.0)],
+}
+ORTHO_STRIDE = 37      # large tensors are committed as every 37th entry + float64 sums
+
+
+def reference_ortho_init():
+    """The reference's own ``ortho_init`` (a2c/utils.py:20-35), cut out of its source file by name and
+    exec'd unmodified with only ``np`` in scope -- the enclosing module imports tensorflow and cannot
+    be imported here."""
+    import ast
+    path = os.path.join(REF, 'baselines', 'a2c', 'utils.py')
+    src = open(path).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'ortho_init']
+    assert len(fn) == 1
+    ns = {'np': np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, 'exec'), ns)
+    return ns['ortho_init']
+
+
+def ortho_digest(w):
+    f = w.reshape(-1)
+    return f[::ORTHO_STRIDE].copy(), np.array([f.astype(np.float64).sum(), np.abs(f.astype(np.float64)).sum()])
+
+
+def gen_ortho():
+    ref = reference_ortho_init()
+    out = {}
+    for seed in (0, 1):
+        for shape, scale in ORTHO_SHAPES:
+            np.random.seed(seed)
+            w = ref(scale)(shape, np.float32)
+            assert w.dtype == np.float32 and w.shape == tuple(shape)
+            key = 's%d_%s' % (seed, 'x'.join(map(str, shape)))
+            if w.size <= 20000:
+                out[key + '_full'] = w
+            out[key + '_sample'], out[key + '_sums'] = ortho_digest(w)
+    for name, layers in ORTHO_NETS.items():
+        np.random.seed(3)
+        for i, (shape, scale) in enumerate(layers):
+            w = ref(scale)(shape, np.float32)
+            out['%s_%d_sample' % (name, i)], out['%s_%d_sums' % (name, i)] = ortho_digest(w)
+        out[name + '_next_uniform'] = np.array([np.random.uniform()])     # the stream position afterwards
+    np.savez_compressed(os.path.join(OUT, 'ortho_init.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     Runner, sf01, segment_tree, math_util, schedules, rb = _import_reference()
@@ -233,6 +288,7 @@ def main():
     gen_shuffle()
     gen_misc(math_util, schedules)
     gen_replay(segment_tree, rb)
+    gen_ortho()
     print('golden vectors written to', OUT)
 
 

@@ -249,3 +249,74 @@ def test_product_has_no_cpu_path():
             if f.endswith('.py'):
                 src += open(os.path.join(dirpath, f)).read()
     assert 'import oracle' not in src and 'from oracle' not in src
+
+
+# ---- f1: checkpoint wire format (tf_util.py:345-372), host half of Model.load --------------------------------
+def _reference_shaped_checkpoint(kind, rng):
+    """What the reference's save_variables would write for this model -- built from SURVEY.md App. A.6 by hand,
+    independently of mrl_model_tensor_info: GLOBAL_VARIABLES = model variables in creation order, then beta1_power,
+    beta2_power, then the Adam slots (m, v) of each variable in turn."""
+    if kind == 'nature_cnn':
+        pv = [('ppo2_model/pi/c1/w', (8, 8, 4, 32)), ('ppo2_model/pi/c1/b', (1, 32, 1, 1)),
+              ('ppo2_model/pi/c2/w', (4, 4, 32, 64)), ('ppo2_model/pi/c2/b', (1, 64, 1, 1)),
+              ('ppo2_model/pi/c3/w', (3, 3, 64, 64)), ('ppo2_model/pi/c3/b', (1, 64, 1, 1)),
+              ('ppo2_model/pi/fc1/w', (3136, 512)), ('ppo2_model/pi/fc1/b', (512,)),
+              ('ppo2_model/pi/w', (512, 6)), ('ppo2_model/pi/b', (6,)), ('ppo2_model/vf/w', (512, 1)), ('ppo2_model/vf/b', (1,))]
+    else:      # mlp 2x64, value_network='copy', Box(376,) observations, 17-dim DiagGaussian
+        pv = []
+        for net in ('pi', 'vf'):
+            pv += [('ppo2_model/%s/mlp_fc0/w' % net, (376, 64)), ('ppo2_model/%s/mlp_fc0/b' % net, (64,)),
+                   ('ppo2_model/%s/mlp_fc1/w' % net, (64, 64)), ('ppo2_model/%s/mlp_fc1/b' % net, (64,))]
+        pv += [('ppo2_model/pi/w', (64, 17)), ('ppo2_model/pi/b', (17,)), ('ppo2_model/pi/logstd', (1, 17)),
+               ('ppo2_model/vf/w', (64, 1)), ('ppo2_model/vf/b', (1,))]
+    names = [n + ':0' for n, _ in pv] + ['beta1_power:0', 'beta2_power:0']
+    arrays = [rng.randn(*s).astype(np.float32) for _, s in pv] + [np.float32(0.9 ** 7), np.float32(0.999 ** 7)]
+    for n, s in pv:
+        names += [n + '/Adam:0', n + '/Adam_1:0']
+        arrays += [rng.randn(*s).astype(np.float32), rng.rand(*s).astype(np.float32)]
+    return pv, names, arrays
+
+
+@pytest.mark.parametrize('kind', ['nature_cnn', 'mlp_copy'])
+def test_reference_shaped_checkpoints_load_by_name_and_as_legacy_list(lib, kind):
+    from baselines_amd.ppo2.model import checkpoint_to_flat
+    if kind == 'nature_cnn':
+        rc, h = _layout(lib, network=_lib.NET_NATURE_CNN, ob_shape=(84, 84, 4), ob_dtype=_lib.OB_U8,
+                        pd_kind=_lib.PD_CATEGORICAL, nact=6)
+    else:
+        rc, h = _layout(lib, network=_lib.NET_MLP, ob_shape=(376,), ob_dtype=_lib.OB_F32, value_copy=1,
+                        pd_kind=_lib.PD_DIAG_GAUSSIAN, nact=17)
+    assert rc == 0
+    P = lib.mrl_model_num_params(h)
+    tensors = [(n, s, o, int(np.prod(s))) for n, s, o, _ in _tensors(lib, h)]
+    pv, names, arrays = _reference_shaped_checkpoint(kind, np.random.RandomState(0))
+    n = len(pv)
+    assert P == sum(int(np.prod(s)) for _, s in pv)
+    # the flat buffers a loader has to end up with: variables concatenated in creation order
+    want = {'params': np.concatenate([a.reshape(-1) for a in arrays[:n]]),
+            'adam_m': np.concatenate([arrays[n + 2 + 2 * i].reshape(-1) for i in range(n)]),
+            'adam_v': np.concatenate([arrays[n + 3 + 2 * i].reshape(-1) for i in range(n)])}
+
+    def flat(out, key):
+        f = np.full(P, np.nan, np.float32)
+        for off, a in out[key]:
+            f[off:off + a.size] = a
+        return f
+
+    for loaded in (dict(zip(names, arrays)), list(arrays)):          # tf_util.py:367-369 / :362-366
+        out = checkpoint_to_flat(loaded, tensors)
+        for key in want:
+            np.testing.assert_array_equal(flat(out, key), want[key])
+        assert out['beta_powers'] == (np.float32(0.9 ** 7), np.float32(0.999 ** 7))
+    # parameters only: a dict without optimizer state leaves the slots alone; a list of the n model variables too
+    for loaded in ({k: v for k, v in zip(names[:n], arrays[:n])}, list(arrays[:n])):
+        out = checkpoint_to_flat(loaded, tensors)
+        np.testing.assert_array_equal(flat(out, 'params'), want['params'])
+        assert out['adam_m'] == [] and out['adam_v'] == [] and out['beta_powers'] is None
+    with pytest.raises(AssertionError, match='number of variables loaded mismatches'):
+        checkpoint_to_flat(list(arrays[:n + 1]), tensors)
+    with pytest.raises(KeyError):
+        d = dict(zip(names, arrays))
+        del d[names[3]]
+        checkpoint_to_flat(d, tensors)
+    lib.mrl_model_destroy(h)

@@ -69,6 +69,25 @@ def test_seeded_init_matches_reference_stream(kind):
     np.testing.assert_array_equal(model.get_flat_params(), om.flat_params())
 
 
+@pytest.mark.parametrize('kind,net', [('atari', 'nature_cnn_nact6'), ('mujoco', 'mlp_copy_376_17')])
+def test_model_init_matches_the_reference_ortho_init_function(kind, net, golden_dir):
+    """`Model` init against tests/golden/ortho_init.npz = the REFERENCE's ortho_init (a2c/utils.py:20-35, exec'd from
+    its source by oracle/make_golden.py) called in TF variable-creation order on the stream of set_global_seeds(3)"""
+    g = np.load(os.path.join(golden_dir, 'ortho_init.npz'))
+    model, _ = _models(kind, 4, 4, 1, seed=3)
+    flat = model.get_flat_params()
+    ws = [t for t in model.dm.tensors if t['name'].endswith('/w')]
+    assert len(ws) == 6
+    for i, t in enumerate(ws):
+        w = flat[t['offset']:t['offset'] + t['size']]
+        np.testing.assert_allclose(w[::37], g['%s_%d_sample' % (net, i)], rtol=0, atol=2e-7, err_msg=t['name'])
+        np.testing.assert_allclose([w.astype(np.float64).sum(), np.abs(w.astype(np.float64)).sum()],
+                                   g['%s_%d_sums' % (net, i)], rtol=0, atol=2e-7 * w.size ** 0.5)
+    others = [t for t in model.dm.tensors if not t['name'].endswith('/w')]
+    for t in others:       # biases and logstd are zeros (a2c/utils.py:45,62; distributions.py:104)
+        assert not flat[t['offset']:t['offset'] + t['size']].any(), t['name']
+
+
 class _NoiseModel(object):
     """wraps our Model so that the Runner's act calls use a recorded noise stream (teacher forcing)"""
 
@@ -218,6 +237,18 @@ def test_model_train_reference_signature_and_save_load(tmp_path):
     np.testing.assert_array_equal(model3.get_flat_params(), model.get_flat_params())
     np.testing.assert_array_equal(model3.adam_v.cpu().numpy(), model.adam_v.cpu().numpy())
     assert model3.beta1_power == model.beta1_power
+    # the legacy LIST checkpoint (tf_util.py:362-366): GLOBAL_VARIABLES order = variables, beta powers, (m, v) per variable
+    names = [t['name'] for t in model.dm.tensors]
+    legacy = [d[n + ':0'] for n in names] + [d['beta1_power:0'], d['beta2_power:0']]
+    for n in names:
+        legacy += [d[n + '/Adam:0'], d[n + '/Adam_1:0']]
+    joblib.dump(legacy, path + '_legacy')
+    model4, _ = _models('cartpole', 8, 16, 1, seed=6)
+    model4.load(path + '_legacy')
+    np.testing.assert_array_equal(model4.get_flat_params(), model.get_flat_params())
+    np.testing.assert_array_equal(model4.adam_m.cpu().numpy(), model.adam_m.cpu().numpy())
+    np.testing.assert_array_equal(model4.adam_v.cpu().numpy(), model.adam_v.cpu().numpy())
+    assert model4.beta2_power == model.beta2_power
 
 
 def test_total_timesteps_zero_builds_model_only():
