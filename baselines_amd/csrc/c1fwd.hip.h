@@ -649,8 +649,16 @@ inline hipError_t launch_c1fwd3(const void* obs, const int32_t* srow, const floa
         default: break;
     }
 #endif
-    hipError_t e0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e0 != hipSuccess) return e0;
+    // one driver call per selected variant, not per launch (the kernel is picked at run time: remember which were raised)
+    static const void* raised[8] = {nullptr};
+    bool seen = false;
+    int slot = 0;
+    for (; slot < 8 && raised[slot]; ++slot) seen = seen || raised[slot] == (const void*)kern;
+    if (!seen) {
+        hipError_t e0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return e0;
+        if (slot < 8) raised[slot] = (const void*)kern;
+    }
     const size_t lds = (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * C1_IMG16;          // 163584
     const int grid = std::max(1, std::min(B, num_cus));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B);

@@ -774,7 +774,8 @@ inline bool lstm_nh_ok(int nh) { return nh >= 1 && nh <= 1024; }
 inline int& lstm_e1() { static int v = getenv("MRL_LSTM_E1") ? atoi(getenv("MRL_LSTM_E1")) : 1; return v; }     // mrl_set_option "lstm_e1"
 // one environment per workgroup: long scans whose groups of four environments would leave CUs idle
 inline bool lstm_use_e1(int nenv, int T, int nh, int num_cus) {
-    return lstm_e1() && (nh == 128 || nh == 64) && T >= 8 && (nenv + 3) / 4 < num_cus;
+    // the one-environment kernels index with unsigned 32-bit element offsets (row * 4nh): longer rollouts take the 4-env kernels
+    return lstm_e1() && (nh == 128 || nh == 64) && T >= 8 && (nenv + 3) / 4 < num_cus && (long)nenv * T * 4 * nh < (1L << 32);
 }
 inline hipError_t launch_lstm_fwd(const LstmFwdArgs& a, int nh, int num_cus, hipStream_t st) {
     constexpr int E = 4;

@@ -859,7 +859,9 @@ __global__ __launch_bounds__(256) void heads_train_kernel(HeadArgs a) {
                         float z0 = 0.f;
                         for (int j = 0; j < nv; ++j) z0 += expf(l[j] - mx);
                         const float logz = logf(z0);
-                        nlp += logz - (l[x[q]] - mx);
+                        // an out-of-range component is an all-zero one_hot row (distributions.py:214): that slice's cross
+                        // entropy is 0 and its gradient softmax - 0 (below); never an out-of-bounds read
+                        if ((unsigned)x[q] < (unsigned)nv) nlp += logz - (l[x[q]] - mx);
                         float Hq = 0.f;
                         for (int j = 0; j < nv; ++j) { const float a0 = l[j] - mx; Hq += (expf(a0) / z0) * (logz - a0); }
                         H += Hq;

@@ -220,12 +220,19 @@ def kernel_rooflines(prof, sites, alg_bytes=None, pmc=None):
     return out
 
 
+def profile_round_key(path):
+    """profiles/rNN<letters>_*.json -> (NN, letters): r10a sorts after r09z and after r9z"""
+    import re
+    m = re.match(r'r(\d+)([a-z]*)_', os.path.basename(path))
+    return (int(m.group(1)), m.group(2)) if m else (-1, os.path.basename(path))
+
+
 def load_pmc(nbatch_train):
     """newest committed profiles/*_pmc_hbm.json -- used only if it was collected from the sources that are running"""
     import glob
     if nbatch_train != 131072:
         return {}, None
-    cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')))
+    cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')), key=profile_round_key)
     if not cand:
         return {}, 'no profiles/*_pmc_hbm.json'
     with open(cand[-1]) as fh:
@@ -470,8 +477,7 @@ def apply_graph_trace(res, workload, total_envs, T):
         res['kernel_times_source'] = ('rocprofv3 --kernel-trace of a child run of the same workload (replayed epoch graphs), whole '
                                       'updates of its timed region; that run took %.3f ms per update' % info)
         res['traced_ms_per_step'] = info
-        tot = sum(v['ms'] for v in prof.values())
-        assert tot <= info * 1.001, ('kernel trace exceeds its own run', tot, info)
+        # a trace that exceeds its own run is reported by check_breakdown (`breakdown_check`), it never costs the JSON line
     else:
         # no trace: the eager update's shares, scaled onto the timed graph-replay step (its kernels take longer with an event
         # pair around each of them than inside the replayed graph)

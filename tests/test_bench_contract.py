@@ -4,6 +4,8 @@ import ast
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -61,17 +63,39 @@ def test_bench_defaults_to_one_gpu_and_a_short_run():
     assert 'oracle' in src and 'cpu_baseline' in src            # the only product-side file allowed to touch oracle/
 
 
-def test_committed_counter_traffic_belongs_to_the_committed_kernel_sources():
-    """bench.py attaches roofline.traffic only when profiles/*_pmc_hbm.json was collected from the sources that run: the newest committed
-    file must carry the hash of the kernel sources in the tree (a kernel edit without a new counter pass shows up here, on CPU)"""
+def test_counter_traffic_is_attached_only_for_the_kernel_sources_it_was_collected_from():
+    """bench.py attaches roofline.traffic only when the newest profiles/*_pmc_hbm.json (by round key, so r10 follows r9) was
+    collected from the kernel sources in the tree; after a kernel edit without a new counter pass it says "withheld" instead
+    of quoting stale counters -- either outcome is legal on CPU, a mismatch between the two is not"""
     import glob
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')))[-1]
-    assert json.load(open(newest))['source_sha16'] == bench.source_sha16(), newest
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04z_bench_atari4096.json')))
-    assert os.path.basename(newest) in d['roofline']['traffic_source']
+    names = ['profiles/r9z_pmc_hbm.json', 'profiles/r10a_pmc_hbm.json', 'profiles/r04z_pmc_hbm.json', 'profiles/r04x_pmc_hbm.json']
+    assert sorted(names, key=bench.profile_round_key)[-1] == 'profiles/r10a_pmc_hbm.json'
+    newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')), key=bench.profile_round_key)[-1]
+    per_launch, src = bench.load_pmc(131072)
+    if json.load(open(newest))['source_sha16'] == bench.source_sha16():
+        assert per_launch and src == 'profiles/' + os.path.basename(newest)
+    else:
+        assert per_launch == {} and 'traffic withheld' in src and os.path.basename(newest) in src
+    assert bench.load_pmc(8192) == ({}, None)          # counters exist for the full-size minibatch only
+
+
+def test_committed_bench_lines_carry_a_clean_breakdown_check():
+    """every committed bench line of the newest round: the per-kernel breakdown fits inside its step, for the headline and
+    for each other configuration (failures are recorded in `breakdown_check`, not raised, so they have to be looked at here)"""
+    import glob
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_atari4096.json')), key=bench.profile_round_key)
+    d = json.load(open(lines[-1]))
+    rows = [d] + [o for o in d.get('other_configs', []) if 'error' not in o]
+    checked = [r['breakdown_check'] for r in rows if 'breakdown_check' in r]
+    if not checked:
+        pytest.skip('%s predates the recorded breakdown check' % os.path.basename(lines[-1]))
+    assert all(c.startswith('ok') for c in checked), checked
 
 
 def test_lds_bank_conflict_model_reproduces_the_measured_ratios():
