@@ -179,6 +179,21 @@ def nature_cnn_alg_bytes(B):
     return {k: float(v) * B for k, v in per.items()}
 
 
+def lstm_alg_bytes(B, nin=512, nh=128):
+    """the recurrent row's GEMM sites outside the scans (a2c/utils.py:81-102: x @ wx for all steps at once, its data and weight
+    gradients, and h @ wh's weight gradient), fp32 operands once each; they run on the generic fp32-MFMA engine"""
+    g = 4 * nh
+    return {'lstm.fwd': 4.0 * B * (nin + g), 'lstm.dgrad': 4.0 * B * (g + nin), 'lstm.wgrad': 4.0 * B * (nin + g),
+            'lstm_h.wgrad': 4.0 * B * (nh + g)}
+
+
+def mlp_step_alg_bytes(B, P, ob_dim=376, nact=17):
+    """the fused MLP minibatch step (one launch = gather + both 2x64 networks forward + loss + backward): per sample the
+    observation row, its index, the four per-sample scalars and the action (SURVEY.md 8(d) K4+K5, fused: no activations or
+    pdparams reach HBM), plus the parameters read and the gradient written once"""
+    return {'mlp_step': float(B) * (4 * ob_dim + 8 + 16 + 4 * nact) + 8.0 * P}
+
+
 def kernel_rooflines(prof, sites, alg_bytes=None, pmc=None):
     """per launch site: the roofline that BINDS it.  A site with flops is priced on max(algorithmic bytes / HBM peak,
     algorithmic flops / peak of the matrix pipe it runs on); `bound` says which floor is the larger one, `achieved` /
@@ -199,7 +214,9 @@ def kernel_rooflines(prof, sites, alg_bytes=None, pmc=None):
             t_mfma, t_hbm = fl / (peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
             pipe = ('bf16 MFMA / %d exact products per multiply' % nprod) if nprod else 'fp32 MFMA'
             r = {'pipe': pipe, 'avg_ms': avg_s * 1e3, 'launches': v['count'], 'mfma_tflops': fl / avg_s / 1e12,
-                 'mfma_peak_tflops': peak, 'mfma_frac': t_mfma / avg_s, 'alg_bytes': nbytes,
+                 'mfma_peak_tflops': peak, 'mfma_frac': t_mfma / avg_s,
+                 # the contract figure of SURVEY.md 8(d): the same fp32-equivalent flops against the fp32 matrix pipe (157.3 TF)
+                 'frac_vs_fp32_mfma': fl / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 'alg_bytes': nbytes,
                  'hbm_gbs': nbytes / avg_s / 1e9, 'hbm_frac': t_hbm / avg_s}
             if t_hbm > t_mfma:
                 r.update({'bound': 'hbm', 'achieved': nbytes / avg_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -242,6 +259,96 @@ def load_pmc(nbatch_train):
     if have != want:
         return {}, '%s was collected from other kernel sources (%s, running %s): traffic withheld' % (name, have, want)
     return pm.get('per_launch', {}), name
+
+
+def dp_verify(model, ro, T, N, hp, world, rank, comm):
+    """Self-validation of the data-parallel gradient BEFORE the timed region (the >1-rank RCCL path has
+    never met a second GPU in the build environment, so the first multi-GPU run has to check itself).  One minibatch of the
+    shape the ranks time (same env-major indices on every rank), its gradient formed three ways:
+      plain      -- every rank computes its LOCAL gradient with the communicator detached, then one torch.distributed
+                    all-reduce(sum) of rank_weight * gradient (mpi_adam_optimizer.py:21,39);
+      overlapped -- the in-library path the timed steps use: mrl_model_grad with the communicator attached (two slices
+                    all-reduced on the communication stream from inside the backward pass, ordered by events);
+      recompute  -- the ranks' minibatches (gathered rows) are all-gathered, rank 0 runs each of them through the same
+                    kernels on ITS device with ITS parameters and adds the results up: no collective on the gradient at all.
+    A missing event wait, a wrong slice boundary or a rank that reduced a stale buffer shows as a difference between the
+    first two; data that is not what the other ranks' kernels saw (or parameters that differ) as a difference to the third.
+    -> dict for the JSON line; the caller fails the run above 1e-6 of the gradient's scale."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from baselines_amd import ops
+    dev = model.device
+    B, P, dm = model.nbatch_train, model.dm.P, model.dm
+    w = float(model.mpi_rank_weight)
+    idx_h = np.random.RandomState(11).permutation(N * T)[:B]              # identical on all ranks, like the reference's permutations
+    idx = torch.from_numpy(idx_h).to(dev)
+
+    def grad(obs, act, ret, val, nlp, index, t, n):
+        g = torch.empty(P, dtype=torch.float32, device=dev)
+        st = torch.empty(5, dtype=torch.float32, device=dev)
+        dm.grad(model.params, obs, act, ret, val, nlp, index, B, t, n, hp['cliprange'], hp['ent_coef'], 0.5, g, st)
+        return g
+
+    fields = (ro.obs, ro.actions, ro.returns, ro.values, ro.neglogpacs)
+    native = bool(model.native_dp)
+    if native:
+        dm.attach_comm(None)
+    local = grad(*fields, idx, T, N)
+    plain = local * w
+    dist.all_reduce(plain)
+    overl = None
+    if native:
+        dm.attach_comm(comm.native, w)
+        overl = grad(*fields, idx, T, N)
+    # the gathered minibatch of every rank on every rank (reference index i = e*T + t lives in storage row t*N + e)
+    rows = torch.from_numpy((idx_h % T) * N + idx_h // T).to(dev)
+    mine = [f.reshape((T * N,) + tuple(f.shape[2:]))[rows].contiguous() for f in fields]
+    everyones = []
+    for f in mine:
+        if dist.get_backend() == 'nccl':
+            buf = torch.empty((world,) + tuple(f.shape), dtype=f.dtype, device=dev)
+            dist.all_gather_into_tensor(buf, f)
+        else:                                   # gloo rehearsal on a box with fewer GPUs than ranks: gather through the host
+            parts = [torch.empty(f.shape, dtype=f.dtype) for _ in range(world)]
+            dist.all_gather(parts, f.cpu())
+            buf = torch.stack(parts).to(dev)
+        everyones.append(buf)
+    out = {'minibatch': B, 'ranks': world,
+           'ways': 'plain = local gradients (communicator detached) + torch.distributed all-reduce; overlapped = in-library '
+                   'two-slice all-reduce inside the backward pass; recompute = rank 0 runs every rank\'s gathered minibatch itself'}
+    res = torch.zeros(4, dtype=torch.float64, device=dev)                 # rank 0 fills it, everybody learns the verdict
+    if rank == 0:
+        if native:
+            dm.attach_comm(None)
+        single = torch.zeros(P, dtype=torch.float32, device=dev)
+        own_identical = None
+        for r in range(world):
+            g_r = grad(*[e[r] for e in everyones], None, 1, 1)
+            if r == 0:
+                own_identical = bool(torch.equal(g_r, local))
+            single += w * g_r                                             # bench ranks all carry weight 1 (mpi_rank_weight default)
+        if native:
+            dm.attach_comm(comm.native, w)
+        scale = float(plain.abs().max())
+        res[0] = scale
+        res[1] = float((single - plain).abs().max()) / scale
+        res[2] = float((overl - plain).abs().max()) / scale if overl is not None else -1.0
+        res[3] = (1.0 if own_identical else 0.0) + (2.0 if (overl is not None and torch.equal(overl, plain)) else 0.0)
+    dist.broadcast(res, 0)
+    r_ = [float(x) for x in res.cpu()]
+    out.update({'grad_scale': r_[0], 'recompute_vs_plain_max_abs_diff_over_scale': r_[1],
+                'overlapped_vs_plain_max_abs_diff_over_scale': (r_[2] if r_[2] >= 0 else None),
+                'overlapped_equals_plain': (r_[2] <= 1e-6 if r_[2] >= 0 else None),
+                'overlapped_bit_identical_to_plain': (bool(int(r_[3]) & 2) if r_[2] >= 0 else None),
+                'rank0_gathered_rows_reproduce_its_indexed_gradient_bitwise': bool(int(r_[3]) & 1),
+                'max_abs_diff_over_scale': max(r_[1], r_[2] if r_[2] >= 0 else 0.0)})
+    if not native:
+        out['note'] = 'in-library communicator not in use (%s): the overlapped path was not exercised' % (
+            getattr(comm, 'native_error', None) or dist.get_backend())
+    del everyones, mine
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, want_prof):
@@ -320,6 +427,13 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
         assert self_check['stats_max_abs_diff'] <= 1e-5 and self_check['grad_max_abs_diff_over_scale'] <= 1e-5, self_check
         del dm2, outs, g, st5
         torch.cuda.empty_cache()
+
+    dp_check = None
+    if world > 1 and workload == 'atari' and os.environ.get('MRL_BENCH_DP_VERIFY', '1') != '0':
+        ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95, out=ro.returns)
+        dp_check = dp_verify(model, ro, T, N, hp, world, rank, comm)
+        if not dp_check['max_abs_diff_over_scale'] <= 1e-6:
+            raise SystemExit('bench.py: data-parallel gradient self-check FAILED: %s' % json.dumps(dp_check))
 
     def update():
         """the PPO2 update (ppo2.py:142 GAE part + :154-166)"""
@@ -400,7 +514,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
                prof_steps=prof_steps, hp=hp, N=N, nbatch_train=nbatch_train, chunk=model.dm.chunk, graph_mode=graph_mode,
                model_tflops=flops_per_sample_visit * total_envs * T * hp['noptepochs'] * steps / dt / 1e12,
                native_dp=bool(getattr(model, 'native_dp', False)), device_state=device_state,
-               self_check=self_check, params_synced=params_synced)
+               self_check=self_check, params_synced=params_synced, dp_verify=dp_check)
     del runner, model, env, ro
     torch.cuda.empty_cache()
     return res
@@ -551,9 +665,16 @@ def dominant_roofline(res, sites, workload):
     prof = res['prof']
     if not prof:
         return None, {}
-    atari = workload == 'atari'          # per-site algorithmic bytes / pipes are tabulated for the feed-forward NatureCNN step
+    atari = workload == 'atari'          # counter traffic exists for the feed-forward NatureCNN step at the full-size minibatch
     pmc, pmc_src = load_pmc(res['nbatch_train']) if atari else ({}, None)
-    per = kernel_rooflines(prof, sites if atari else {}, nature_cnn_alg_bytes(res['nbatch_train']) if atari else None, pmc)
+    if workload in ('atari', 'atari_lstm'):
+        # the conv / fc1 sites of the recurrent row are the same engines on the same pipes; its LSTM GEMMs are fp32-MFMA sites
+        alg = nature_cnn_alg_bytes(res['nbatch_train'])
+        if workload == 'atari_lstm':
+            alg.update(lstm_alg_bytes(res['nbatch_train']))
+        per = kernel_rooflines(prof, sites, alg, pmc)
+    else:
+        per = kernel_rooflines(prof, {}, mlp_step_alg_bytes(res['nbatch_train'], res['P']), pmc)
     tot_ms = sum(v['ms'] for v in prof.values())
     dom = max(per, key=lambda k: prof[k]['ms'])
     roof = dict(per[dom])
@@ -684,6 +805,7 @@ def main():
             out['self_check'] = res['self_check']
         if world > 1:
             out['params_synced_across_ranks'] = res.get('params_synced')
+            out['dp_verify'] = res.get('dp_verify')
             out['config']['native_dp'] = res.get('native_dp')
         if res['graph_mode']:
             out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps)'

@@ -112,3 +112,43 @@ def test_lds_bank_conflict_model_reproduces_the_measured_ratios():
     assert abs(ratio(L.gemm_x6(False)) - 0.36) < 0.01 and abs(ratio(L.gemm_x6(False, 128, 128)) - 0.33) < 0.01
     assert ratio(L.gemm_x6(True)) == 0 and ratio(L.gemm_x6(True, 128, 128)) == 0
     assert abs(ratio(L.c1wgrad_half()) - 0.36) < 0.02
+
+
+def test_every_row_prices_its_sites_with_algorithmic_bytes_and_the_pipe_it_runs_on():
+    """the recurrent row's conv / fc1 sites are the SAME engines on the same pipe as the feed-forward row's
+    (its c2.dgrad must come out at the same fraction for the same time, not 2.7x higher on the fp32 peak), its LSTM GEMMs are
+    fp32-MFMA sites with real bytes, the MLP row's fused step has algorithmic bytes, and every MFMA-priced site also carries
+    the SURVEY 8(d) contract figure `frac_vs_fp32_mfma`.  bench.dominant_roofline on synthetic per-kernel times, no GPU."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    sites = {k: 6 for k in ('c2.fwd', 'c3.fwd', 'fc1.fwd', 'fc1.dgrad', 'c2.dgrad', 'c3.dgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad')}
+    sites.update({'c1.fwd': 3, 'c1.wgrad': 3})
+    B = 8192
+    flop = {'c2.dgrad': 2.0 * B * 81 * 64 * 512, 'c1.fwd': 2.0 * B * 400 * 32 * 256, 'lstm.fwd': 2.0 * B * 512 * 512}
+
+    def prof(extra=()):
+        p = {k: {'ms': ms * 16, 'count': 16, 'flops': flop[k] * 16, 'bytes': 0.0}
+             for k, ms in (('c2.dgrad', 0.31), ('c1.fwd', 0.18))}
+        for k, ms in extra:
+            p[k] = {'ms': ms * 16, 'count': 16, 'flops': flop.get(k, 0.0) * 16, 'bytes': 0.0}
+        return p
+
+    rows = {}
+    for wl, extra in (('atari', ()), ('atari_lstm', (('lstm.fwd', 0.065),))):
+        res = dict(prof=prof(extra), nbatch_train=B, prof_steps=1, P=1687719)
+        roof, per = bench.dominant_roofline(res, sites, wl)
+        rows[wl] = (roof, per)
+        for k, r in per.items():
+            assert r['alg_bytes'] > 0, (wl, k)
+            if r.get('pipe'):
+                assert abs(r['frac_vs_fp32_mfma'] - r['mfma_tflops'] / 157.3) < 1e-12
+    a, l = rows['atari'][0], rows['atari_lstm'][0]
+    assert a['kernel'] == l['kernel'] == 'c2.dgrad' and a['pipe'] == l['pipe'] and '6 exact products' in l['pipe']
+    assert abs(a['frac'] - l['frac']) < 1e-12 and a['alg_bytes'] == l['alg_bytes']
+    assert rows['atari_lstm'][1]['lstm.fwd']['pipe'] == 'fp32 MFMA'
+    assert rows['atari_lstm'][1]['c1.fwd']['bound'] == 'hbm'
+    res = dict(prof={'mlp_step': {'ms': 0.041 * 320, 'count': 320, 'flops': 248.6e3 * 4096 * 320, 'bytes': 0.0}},
+               nbatch_train=4096, prof_steps=1, P=57763)
+    roof, _ = bench.dominant_roofline(res, sites, 'mujoco')
+    assert roof['kernel'] == 'mlp_step' and roof['alg_bytes'] == 4096 * (1504 + 8 + 16 + 68) + 8 * 57763 and roof['pipe'] == 'fp32 MFMA'

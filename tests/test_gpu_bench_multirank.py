@@ -37,3 +37,32 @@ def test_bench_two_ranks_one_json_line_and_synced_parameters(num_envs):
     assert all(abs(x) < 1e6 and x == x for x in d['loss'])                   # finite
     assert d['params_synced_across_ranks'] is True
     assert 'gloo' in d['config']['collective']
+    # the data-parallel self-validation of the first multi-GPU run (bench.dp_verify), rehearsed over gloo: the all-reduced
+    # local gradients against rank 0 recomputing every rank's gathered minibatch on its own device
+    v = d['dp_verify']
+    assert v['ranks'] == 2 and v['minibatch'] == d['config']['nbatch_train_per_gpu']
+    assert v['max_abs_diff_over_scale'] <= 1e-6 and v['recompute_vs_plain_max_abs_diff_over_scale'] <= 1e-6
+    assert v['rank0_gathered_rows_reproduce_its_indexed_gradient_bitwise'] is True
+    assert v['overlapped_equals_plain'] is None and 'not exercised' in v['note']      # RCCL refuses two ranks on one device
+
+
+def test_bench_two_ranks_over_the_in_library_rccl_path_when_two_gpus_are_visible():
+    """The native path itself -- mrl_comm over RCCL, the two-slice all-reduce issued from inside the backward pass -- with 2
+    ranks on 2 GPUs: skipped on the one-GPU test box, runs wherever the suite meets a multi-GPU node.  bench.py's dp_verify
+    compares the overlapped gradient with the plain all-reduce and with a single-device recomputation (1e-6 of its scale)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 HIP devices (RCCL refuses two ranks on one device)')
+    env = dict(os.environ, MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MRL_BENCH_BACKEND', 'MRL_NATIVE_COMM'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--num-envs', '1024',
+           '--no-cpu-baseline', '--no-other-configs']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['params_synced_across_ranks'] is True
+    assert d['config']['native_dp'] is True and 'in-library RCCL' in d['config']['collective']
+    v = d['dp_verify']
+    assert v['overlapped_equals_plain'] is True and v['max_abs_diff_over_scale'] <= 1e-6
+    assert v['overlapped_bit_identical_to_plain'] is True          # two addends: the sum does not depend on the ring's order

@@ -238,3 +238,133 @@ def test_recurrent_bptt_over_128_steps_at_the_benched_shape_vs_oracle(name):
     dm.grad_rnn(params, r_obs, r_act, r_ret, r_val, r_nlp, r_m, d_s, nseq, dev(idx), B, T, N, 0.1, 0.01, 0.5, grads2, stats2)
     np.testing.assert_array_equal(stats2.cpu().numpy(), stats.cpu().numpy())
     np.testing.assert_array_equal(grads2.cpu().numpy(), grads.cpu().numpy())
+
+
+# ---- config 4's per-rank shape and config 3's whole update ---------------------------
+CNN_KW = dict(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6, value_network=None,
+              ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+
+
+def test_rank_shard_minibatch_backward_vs_oracle_every_entry():
+    """Config 4's PER-RANK shape (num_envs = 4096 over 8 GPUs = 512 envs per rank, 4 minibatches of 16384, chunk 16384 -- the
+    shape `bench.py --gpus 8` and the N = 512 row of `other_configs` time): `mrl_model_grad` gathering 16384 samples through
+    env-major indices out of a time-major rollout, every entry of every gradient tensor and the 5 statistics against the
+    fp64 oracle (ppo2/model.py:57-114, 136-139; common/models.py:15-26) at the bar of the full-size test (5e-6 of each
+    tensor's scale).  The engines size their persistent-workgroup grids and slab counts from B, so neither the B = 8192 nor
+    the B = 131072 test reaches this configuration."""
+    from baselines_amd import ops
+    from tests.test_gpu_large_batch import MARGIN, _sliced
+    B, S, clip = 16384, 8192, 0.1
+    T, N = 48, 512                                     # a 512-env shard; 24576 stored samples to screen 16384 out of
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    rng = np.random.RandomState(31)
+    np.random.seed(31)
+    om = OracleModel(**CNN_KW)
+    with torch.no_grad():
+        for k in om.names:
+            om.p[k] += torch.tensor(0.02 * rng.randn(*om.p[k].shape), dtype=torch.float32)
+    obs_tm = rng.randint(0, 256, (T, N, 84, 84, 4), dtype=np.uint8)           # storage order of the rollout buffer: [T][N]
+    flat = O.sf01(obs_tm)                                                      # the reference's env-major view, i = e*T + t
+    n = T * N
+    a_f, v_f, nlp_f = np.empty(n, np.int64), np.empty(n, np.float32), np.empty(n, np.float32)
+    for sl in _sliced(n, S):
+        a_f[sl], v_f[sl], _, nlp_f[sl] = om.step(flat[sl], rng.rand(sl.stop - sl.start, 6).astype(np.float32))
+    with torch.no_grad():
+        for k in om.names:
+            om.p[k] += torch.tensor(0.003 * rng.randn(*om.p[k].shape), dtype=torch.float32)
+    om64 = OracleModel(dtype=torch.float64, params=om.params_numpy(), **CNN_KW)
+    ret_f = (v_f + 0.5 * rng.randn(n)).astype(np.float32)
+    keep = np.nonzero(_min_abs_preact(om64, flat) > MARGIN)[0]
+    assert keep.size >= B, 'screening left %d of %d samples' % (keep.size, B)
+    idx = rng.permutation(keep)[:B]                                            # a minibatch: B env-major indices, shuffled
+
+    def tm(x):                                                                 # env-major flat -> time-major [T][N]
+        return np.ascontiguousarray(x.reshape(N, T).swapaxes(0, 1))
+
+    dm = ops.DeviceModel(chunk=B, **{k: CNN_KW[k] for k in ('network', 'ob_shape', 'ob_dtype', 'pd_kind', 'nact')})
+    assert dm.chunk == B
+    params = dev(om.flat_params().astype(np.float32))
+    d = dict(obs=dev(obs_tm), act=dev(tm(a_f).astype(np.int32)), ret=dev(tm(ret_f)), val=dev(tm(v_f)), nlp=dev(tm(nlp_f)))
+    grads = torch.empty(dm.P, dtype=torch.float32, device='cuda')
+    stats = torch.empty(5, dtype=torch.float32, device='cuda')
+    dm.grad(params, d['obs'], d['act'], d['ret'], d['val'], d['nlp'], dev(idx), B, T, N, clip, 0.01, 0.5, grads, stats)
+    g_d, s_d = grads.cpu().numpy().astype(np.float64), stats.cpu().numpy()
+    assert np.isfinite(g_d).all() and np.isfinite(s_d).all()
+
+    obs, rets, acts, vals, nlps = flat[idx], ret_f[idx], a_f[idx], v_f[idx], nlp_f[idx]
+    advs64, advs32 = om64._normalised_advs(rets, vals), om._normalised_advs(rets, vals)
+    g64, g32, s64 = np.zeros(dm.P), np.zeros(dm.P), np.zeros(5)
+    for sl in _sliced(B, S):                           # two slices with the advantage statistics of the WHOLE minibatch
+        st, fl = om64.compute_grads(clip, obs[sl], rets[sl], acts[sl], vals[sl], nlps[sl], advs=advs64[sl])
+        g64 += fl.numpy() / (B // S)
+        s64 += np.array(st) / (B // S)
+        _, fl32 = om.compute_grads(clip, obs[sl], rets[sl], acts[sl], vals[sl], nlps[sl], advs=advs32[sl])
+        g32 += fl32.numpy().astype(np.float64) / (B // S)
+    np.testing.assert_allclose(s_d, s64, rtol=1e-5, atol=1e-5)
+    assert s64[4] > 0.0                                # some samples are clipped
+    errs = per_tensor_errors(dm.tensors, g_d, g32, g64)
+    report(test='rank_shard_minibatch_backward', B=B, chunk=B, T=T, N=N,
+           stats_abs_diff_vs_fp64=[float(x) for x in np.abs(s_d - s64)], grad_errors_over_tensor_scale=errs)
+    scale = np.abs(g64).max()
+    for t in dm.tensors:
+        sl = slice(t['offset'], t['offset'] + t['size'])
+        tol = 5e-6 * max(np.abs(g64[sl]).max(), 1e-3 * scale)
+        assert np.abs(g_d[sl] - g64[sl]).max() <= tol, (t['name'], errs[t['name']])
+
+
+def test_config3_whole_update_vs_oracle_step_by_step():
+    """BASELINE.json config 3 exactly as `learn()` runs it (ppo2/ppo2.py:154-166, ppo2/defaults.py:15-22): nature_cnn,
+    num_envs = 256, nsteps = 128, 4 epochs x 4 minibatches of 8192 out of the rollout the device Runner stored -- 16
+    `Model.train_indexed` steps with permutations from the global NumPy stream, each followed by `OracleModel.train`
+    (fp32 and fp64; ppo2/model.py:133-158) on the same gathered samples.  north_star's bar: the 5 loss statistics of all
+    16 steps within 1e-5, parameters within 5e-6 of the fp64 trajectory after the optimizer steps (or within twice the
+    fp32 CPU restatement's own drift from it -- Adam's sign-like steps amplify round-off on cancellation-residue entries;
+    same yardstick as the config-2 test).  No ReLU-margin screening here: these are the samples the runner produced."""
+    from baselines_amd.common import set_global_seeds
+    from baselines_amd.common.policies import build_policy
+    from baselines_amd.common.vec_env.synthetic_vec_env import SyntheticVecEnv
+    from baselines_amd.ppo2 import Model, Runner
+    N, T, M, E = 256, 128, 4, 4
+    B = N * T // M
+    lr, clip = 2.5e-4, 0.1
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    env = SyntheticVecEnv('atari', N, seed=1003)
+    set_global_seeds(0)
+    policy = build_policy(env, 'cnn')
+    model = Model(policy=policy, ob_space=env.observation_space, ac_space=env.action_space, nbatch_act=N, nbatch_train=B,
+                  nsteps=T, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+    np.random.seed(0)
+    om = OracleModel(**CNN_KW)
+    np.testing.assert_array_equal(model.get_flat_params(), om.flat_params())
+    om64 = OracleModel(dtype=torch.float64, params=om.params_numpy(), **CNN_KW)
+    runner = Runner(env=env, model=model, nsteps=T, gamma=0.99, lam=0.95, return_host=False)
+    runner.run()
+    runner.run()                                       # second rollout: episodes have ended, dones are mixed in
+    ro = runner.rollout
+    f = {k: O.sf01(getattr(ro, k).cpu().numpy()) for k in ('obs', 'actions', 'returns', 'values', 'neglogpacs')}
+    worst_stats, drift_d, drift_o, clipfrac = 0.0, [], [], []
+    inds = np.arange(N * T)
+    step = 0
+    for epoch in range(E):
+        np.random.shuffle(inds)                        # ppo2.py:157-158
+        inds_dev = model.indices_to_device(inds)
+        for lo in range(0, N * T, B):
+            idx = inds[lo:lo + B]
+            st = model.train_indexed(lr, clip, ro, inds_dev[lo:lo + B]).cpu().numpy()
+            args = (lr, clip, f['obs'][idx], f['returns'][idx], None, f['actions'][idx], f['values'][idx], f['neglogpacs'][idx])
+            so, s64 = np.array(om.train(*args)), np.array(om64.train(*args))
+            np.testing.assert_allclose(st, so, rtol=1e-5, atol=1e-5, err_msg='step %d' % step)
+            np.testing.assert_allclose(st, s64, rtol=1e-5, atol=1e-5, err_msg='step %d (fp64)' % step)
+            worst_stats = max(worst_stats, float(np.abs(st - s64).max()))
+            p64 = om64.flat_params()
+            drift_d.append(float(np.abs(model.get_flat_params() - p64).max()))
+            drift_o.append(float(np.abs(om.flat_params() - p64).max()))
+            clipfrac.append(float(s64[4]))
+            step += 1
+    report(test='config3_whole_update', N=N, T=T, minibatch=B, steps_checked=step, worst_stat_abs_diff_vs_fp64=worst_stats,
+           max_param_abs_diff_vs_fp64_after_each_step=drift_d, fp32_oracle_max_param_abs_diff_vs_fp64_after_each_step=drift_o,
+           clipfrac_per_step=clipfrac)
+    assert step == E * M == 16 and model._train_calls == 16
+    assert max(clipfrac) > 0.0                         # the policy moved: ratios != 1, the clip is active in later epochs
+    for k in range(step):
+        assert drift_d[k] <= max(5e-6, 2.0 * drift_o[k]), (k, drift_d, drift_o)
