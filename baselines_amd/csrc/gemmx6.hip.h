@@ -31,16 +31,40 @@ namespace mrl {
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 constexpr int X6_BM = 128, X6_BN = 128, X6_BK = 32, X6_LDK = 40;
 
+// Class-major k order of a conv forward GEMM (option x6_frag; rf % stride == 0, C % 32 == 0).  k step s (32 channels of one
+// filter tap) is enumerated as (stride-parity class (py, px), 32-channel chunk kc, tap (a, c) of the class): ky = py + stride a,
+// kx = px + stride c.  The taps of one class read the SAME input pixels shifted by whole pixels of the class grid, so the
+// rf^2 / stride^2 k steps of a class re-read one ~43-58 KB footprint per tile back to back -- inside the XCD's 4 MB L2 for its 64
+// concurrent tiles -- instead of coming back to a pixel 8 k steps (and ~16 MB of other tiles' traffic) later: counters before
+// (profiles/r04z_pmc_hbm.json): conv2 forward fetched 16.8 GB for 6.7 GB of input, conv3 9.7 for 2.7, both at ~4 TB/s = HBM-bound
+// on their re-reads.  A dot product does not care in which order k runs; the weight planes are laid out in the same order.
+__host__ __device__ __forceinline__ void conv_kcls_decode(int s, int rf, int stride, int C, int& ky, int& kx, int& kc) {
+    const int T = rf / stride, cpc = C >> 5, per = T * T * cpc;
+    const int cls = s / per, r = s - cls * per;
+    kc = r / (T * T);
+    const int r2 = r - kc * (T * T), a = r2 / T, c = r2 - a * T;
+    ky = cls / stride + stride * a;
+    kx = cls % stride + stride * c;
+}
+// position of original k = (ky * rf + kx) * C + ch in the class-major order
+__host__ __device__ __forceinline__ long conv_kcls_encode(long k, int rf, int stride, int C) {
+    const int ch = (int)(k % C), t = (int)(k / C), ky = t / rf, kx = t - ky * rf;
+    const int T = rf / stride, cpc = C >> 5;
+    const int cls = (ky % stride) * stride + (kx % stride), a = ky / stride, c = kx / stride, kc = ch >> 5;
+    return ((long)(cls * cpc + kc) * T * T + a * T + c) * 32 + (ch & 31);
+}
 // out[plane][n][k] (bf16 bits) from src[R][Cn] fp32:  transpose ? (n, k) = (col, row) : (n, k) = (row, col)
 // kperm: k runs in the order of a plane tensor (planes.hip.h: perm32 inside each aligned block of 32)
+// kcls_rf > 0: k runs in the class-major order of a conv layer with that filter size / stride / input channels (conv_kcls_encode)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int Cn, int transpose,
-                                                           uint16_t* __restrict__ out, int kperm = 0) {
+                                                           uint16_t* __restrict__ out, int kperm = 0, int kcls_rf = 0,
+                                                           int kcls_stride = 1, int kcls_c = 32) {
     const long total = (long)R * Cn;
     const long Nn = transpose ? Cn : R, Kd = transpose ? R : Cn;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
         const long r = e / Cn, c = e - r * Cn;
         const long n = transpose ? c : r, k0 = transpose ? r : c;
-        const long k = kperm ? kperm32(k0) : k0;
+        const long k = kcls_rf ? conv_kcls_encode(k0, kcls_rf, kcls_stride, kcls_c) : kperm ? kperm32(k0) : k0;
         uint16_t b0, b1, b2;
         split1_bf16x3(src[e], b0, b1, b2);
         out[(0 * Nn + n) * Kd + k] = b0;
@@ -56,6 +80,7 @@ struct X6DenseA {            // A[M][lda] row-major
     __device__ __forceinline__ long koff(int k0) const { return k0; }
 };
 struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k = (ky, kx, c); X6_BK divides rf*C
+    int kcls = 0;            // 1: k steps in class-major order (above); the B planes must be laid out with the same order
     __device__ __forceinline__ long row_base(int m) const {
         const int ohw = OH * OW;
         int b = (int)d_ohw.div((uint32_t)m), r = m - b * ohw;
@@ -64,6 +89,11 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
         return ((img * H + oy * stride) * W + ox * stride) * C;
     }
     __device__ __forceinline__ long koff(int k0) const {
+        if (kcls) {
+            int ky, kx, kc;
+            conv_kcls_decode(k0 >> 5, rf, stride, C, ky, kx, kc);
+            return ((long)ky * W + kx) * C + kc * 32;
+        }
         const int ky = (int)d_rowk.div((uint32_t)k0);
         return (long)ky * W * C + (k0 - ky * rowk);
     }
@@ -397,10 +427,11 @@ inline bool gemm_x6_ok(const void* A, long lda, int K) {
 inline size_t gemm_x6_plane_bytes(long N, long K) { return (size_t)3 * N * K * sizeof(uint16_t); }
 
 inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool transpose, uint16_t* out, hipStream_t stream,
-                                      bool kperm = false) {
+                                      bool kperm = false, int kcls_rf = 0, int kcls_stride = 1, int kcls_c = 32) {
     const long total = (long)R * Cn;
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out, kperm ? 1 : 0);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out, kperm ? 1 : 0,
+                       kcls_rf, kcls_stride, kcls_c);
     return hipGetLastError();
 }
 

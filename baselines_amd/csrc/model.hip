@@ -26,6 +26,8 @@
 #ifdef MRL_X6_EXPERIMENTS
 #include "gemmx6s.hip.h"
 #endif
+#include "gemmx6r.hip.h"
+#include "convx6c.hip.h"
 #include "c1fwd.hip.h"
 #include "wgradx8.hip.h"
 #include "wgradtr.hip.h"
@@ -385,6 +387,13 @@ static int act_planes_mode() {
 }
 // wave-specialised (producer / consumer) form of the tiled split engines (gemmx6s.hip.h): measured NOT faster than the plain
 // form (two waves of one SIMD share its VALU issue and its matrix pipe: profiles/README.md), kept as an experiment knob
+// transposed-epilogue launches of the tiled split engine: split-at-the-fragment kernel (gemmx6r.hip.h, option x6_frag) or the
+// staged-planes kernel (gemmx6.hip.h); bit-identical results
+template <class AF, class EF>
+static hipError_t launch_x6_tr(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t st, long long* dbg) {
+    if (x6_frag() && !dbg && N % 32 == 0) return launch_gemm_x6r(af, Bp, ef, M, N, K, st);
+    return launch_gemm_x6_planes<false, true>(af, 0, Bp, ef, M, N, K, st, dbg);
+}
 static int x6_specialised() { return kExp ? get_option("x6_spec", "MRL_X6_SPEC", 0) : 0; }
 // phase-stamp / phase-omission knobs exist in experiment builds only
 static int dbg_option(const char* name, const char* env) { return kExp ? get_option(name, env, 0) : 0; }
@@ -397,6 +406,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -420,6 +430,8 @@ extern "C" int mrl_set_option(const char* name, int value) {
             if (!strcmp(name, "x6_dither")) x6_dither() = value;
             if (!strcmp(name, "x6_il")) x6_il() = value;
             if (!strcmp(name, "x6_pg")) x6_pg() = value;
+            if (!strcmp(name, "x6_frag")) x6_frag() = value;
+            if (!strcmp(name, "conv_x6c")) conv_x6c() = value;
             if (!strcmp(name, "lstm_e1")) lstm_e1() = value;
             if (!strcmp(name, "x6_dbg")) x6_xd() = value >= 100 ? value - 100 : 0;
             return 0;
@@ -1555,8 +1567,13 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     const bool trp = EXP && hp_out && hpwrote;   // the epilogue also leaves the plane tensor
                     const bool tr = (trp || tr_plain) && x6 == 2 && l.NF % 32 == 0 && l.act == ACT_RELU && !x6_specialised() &&
                                     (uintptr_t)bias % 16 == 0;
-                    hipError_t e = launch_split_planes(W, l.K, l.NF, true, planes, st, pa);
+                    // k steps in class-major order (gemmx6.hip.h conv_kcls_*): the split-at-the-fragment launches only, so that
+                    // x6_frag = 0 stays the round-4 engine for A/B runs
+                    const bool kcls = tr && !pa && x6_frag() && !(x6_frag() & 4) && l.rf % l.stride == 0 && l.C % 32 == 0 && l.NF % 32 == 0;
+                    hipError_t e = kcls ? launch_split_planes(W, l.K, l.NF, true, planes, st, false, l.rf, l.stride, l.C)
+                                        : launch_split_planes(W, l.K, l.NF, true, planes, st, pa);
                     if (e != hipSuccess) return (int)e;
+                    ca.kcls = kcls ? 1 : 0;
                     if (pa || tr) {
                         // pre-split operands: A staged from the plane tensor of the layer below, and / or the epilogue leaves
                         // the plane tensor of this layer's output for the layer above
@@ -1566,12 +1583,20 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                             TrBiasRelu tf{hout, l.NF, bias, nullptr, trp ? hp_out : nullptr, (long)npix * l.NF};
                             if (mbits) { tf.mask = mbits; if (mwrote) *mwrote = 1; }
                             if (trp) *hpwrote = 1;
+                            // NatureCNN's conv2 / conv3 at minibatch sizes: class-resident kernel (convx6c.hip.h) -- whole images per
+                            // tile, every input element loaded once, 4 / 2 barrier pairs per tile instead of 16 / 18
+                            if (!pa && !trp && conv_x6c() && B >= 1024 && l.NF == 64 && l.pad_t == 0 && l.pad_l == 0) {
+                                if (l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2)
+                                    return (int)launch_conv_x6c<20, 20, 32, 4, 2, 64, 3>(hprev, W, planes, tf, B, num_cus(), st);
+                                if (l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1)
+                                    return (int)launch_conv_x6c<9, 9, 64, 3, 1, 64, 5>(hprev, W, planes, tf, B, num_cus(), st);
+                            }
                             // MRL_X6_DBG = 10 + layer index: phase stamps of that conv layer's forward land behind the zero page
                             long long* dbgq = dbg_option("x6_dbg", "MRL_X6_DBG") == 10 + (int)(&l - &m->pi.L[0]) ? dbgbuf : nullptr;
                             if constexpr (EXP) {
                                 if (pa) return (int)launch_gemm_x6_planes<true, true>(ca, aps, planes, tf, npix, l.NF, l.K, st, dbgq);
                             }
-                            return (int)launch_gemm_x6_planes<false, true>(ca, 0, planes, tf, npix, l.NF, l.K, st, dbgq);
+                            return (int)launch_x6_tr(ca, planes, tf, npix, l.NF, l.K, st, dbgq);
                         }
                         if constexpr (EXP) {
                             EpiBiasAct efp{hout, l.NF, bias, l.act};
@@ -1662,7 +1687,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                         if (pa) return (int)launch_gemm_x6_planes<true, true>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
                                                                               (long)B * l.K, planes, tf, B, l.N, l.K, st, dbgq);
                     }
-                    return (int)launch_gemm_x6_planes<false, true>(X6DenseA{hprev, (long)l.K}, 0, planes, tf, B, l.N, l.K, st, dbgq);
+                    return (int)launch_x6_tr(X6DenseA{hprev, (long)l.K}, planes, tf, B, l.N, l.K, st, dbgq);
                 }
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
                 long long* dbgp = dbg_option("x6_dbg", "MRL_X6_DBG") == 1 ? dbgbuf : nullptr;
@@ -1997,7 +2022,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                         if constexpr (EXP) {
                             if (dz_p) { e = launch_gemm_x6_planes<true, true>(da, aps, nw.planes, tf, B, l.K, l.N, st); done = true; }
                         }
-                        if (!done) e = launch_gemm_x6_planes<false, true>(da, 0, nw.planes, tf, B, l.K, l.N, st);
+                        if (!done) e = launch_x6_tr(da, nw.planes, tf, B, l.K, l.N, st, nullptr);
                         if (e == hipSuccess && dx_p) nw.dzpvalid[i - 1] = 1;
                     } else {
                         if constexpr (EXP) e = launch_gemm_x6_planes<true, false>(da, aps, nw.planes, ef, B, l.K, l.N, st);

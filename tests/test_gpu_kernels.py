@@ -335,7 +335,7 @@ def test_engine_options_agree():
         return g.cpu().numpy(), st.cpu().numpy()
 
     names = ['u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'tr_epilogue',
-             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither']
+             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c']
     # builds with -DMRL_X6_EXPERIMENTS also carry the measured-and-dropped variants (plane tensors, separate load phase)
     experiments = True
     try:
@@ -349,6 +349,8 @@ def test_engine_options_agree():
     assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 / fc1 weight gradients: transpose-read kernels by default'
     assert defaults['c1_lds'] == 4, 'first conv layer forward: software-pipelined image-resident kernel by default'
     assert defaults['x6_dither'] == 3, 'tiled split engines: sign alternation of the staged rows and conflict-free staging order by default'
+    assert defaults['conv_x6c'] == 1, 'conv2 / conv3 forward at minibatch sizes: class-resident kernel by default'
+    assert defaults['x6_frag'] == 1, 'tiled split engines: operand split on the fragment path, between the MFMAs, by default'
     if experiments:
         assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
     try:
@@ -388,6 +390,14 @@ def test_engine_options_agree():
                  ('split engines, sign alternation without the conflict-free staging order', dict(defaults, x6_dither=1), 3e-6),
                  ('split engines, conflict-free staging order without the sign alternation', dict(defaults, x6_dither=2), 3e-6),
                  ('split engines, no sign alternation, row-major accumulators', dict(defaults, x6_dither=0, tr_epilogue=0), 3e-6),
+                 ('split engines, conv2 / conv3 forward on the tiled engine instead of the class-resident kernel', dict(defaults, conv_x6c=0), 3e-6),
+                 ('split engines, operand split in the staging pass (planes in LDS) instead of on the fragment path', dict(defaults, x6_frag=0, conv_x6c=0), 3e-6),
+                 ('split engines, split in the staging pass, no sign alternation', dict(defaults, x6_frag=0, x6_dither=2, conv_x6c=0), 3e-6),
+                 ('split engines, split on the fragment path, conv k steps in natural order', dict(defaults, x6_frag=5, conv_x6c=0), 3e-6),
+                 ('split engines, split on the fragment path, natural k order, no sign alternation', dict(defaults, x6_frag=5, x6_dither=2, conv_x6c=0), 3e-6),
+                 ('split engines, split on the fragment path, two register sets of operand loads', dict(defaults, x6_frag=2, conv_x6c=0), 3e-6),
+                 ('split engines, class-resident conv forward without the sign alternation', dict(defaults, x6_dither=2), 3e-6),
+                 ('split engines, tiled conv forward in class-major k order without the sign alternation', dict(defaults, x6_dither=2, conv_x6c=0), 3e-6),
                  ('split engines, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
                  ('split engines, first conv layer forward: lock-step phases instead of the software pipeline',
                   dict(defaults, c1_lds=2), 3e-6),
@@ -407,11 +417,26 @@ def test_engine_options_agree():
                       ('plane tensors of the pre-activation gradients only', dict(defaults, act_planes=2), 3e-6),
                       ('plane tensors of both', dict(defaults, act_planes=3), 3e-6),
                       ('transposed-accumulator epilogues incl. fc1 forward, planes of the last dz only', dict(defaults, act_planes=108), 3e-6)]
+        by_name = {}
         for name, opts, tol in cases:
             g1, s1 = grads(*cnn, B, opts, scr)
+            by_name[name] = (g1, s1)
             d = np.abs(g1 - g0)
             assert d.max() <= tol * scale + 1e-9, (name, d.max(), scale, int(d.argmax()))
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
+        # the split-at-the-fragment kernel (gemmx6r.hip.h) forms the same products as the staged-planes kernel and, with the conv
+        # layers' k steps in natural order (x6_frag = 5), adds them in the same order: gradient and statistics are then BIT-identical,
+        # with and without the sign alternation (the default's class-major k order changes the order of the sums only)
+        for a, b in (('split engines, split on the fragment path, conv k steps in natural order',
+                      'split engines, operand split in the staging pass (planes in LDS) instead of on the fragment path'),
+                     ('split engines, split on the fragment path, natural k order, no sign alternation',
+                      'split engines, split in the staging pass, no sign alternation'),
+                     # the class-resident kernel walks k in the class-major order of the tiled engine's default: the same sums (its tiles
+                     # are whole images, so WHICH rows the sign alternation negates differs -- compared without it)
+                     ('split engines, class-resident conv forward without the sign alternation',
+                      'split engines, tiled conv forward in class-major k order without the sign alternation')):
+            np.testing.assert_array_equal(by_name[a][0], by_name[b][0], err_msg=b)
+            np.testing.assert_array_equal(by_name[a][1], by_name[b][1], err_msg=b)
     finally:
         for o, v in defaults.items():
             L.set_option(o, v)
