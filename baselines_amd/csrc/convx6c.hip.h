@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void x6c_split_planes_kernel(const float* __re
     }
 }
 
-template <int H, int W, int C, int RF, int S, int NF, int G, class EF, int VPM>
+// DBG (timing experiments, wrong results except bit 1; builds with -DMRL_X6_EXPERIMENTS reach them through option conv_x6c = 1 + 2 * DBG):
+// 1 = staging loads in the last three units of a pass, 2 = B fragments loaded once per pass, 4 = no MFMAs, 8 = 3-instruction fake split, 16 = no epilogue
+template <int H, int W, int C, int RF, int S, int NF, int G, class EF, int VPM, int DBG>
 __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restrict__ x, const uint16_t* __restrict__ Bf, EF ef, int B,
                                                           int ntiles, int dither) {
     using Q = X6cGeom<H, W, C, RF, S, NF, G>;
@@ -77,15 +79,23 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
 
     // ---- tile-independent addresses
     // staging piece j of this thread: LDS row (tid >> 3) + 32 j, 16-byte chunk tid & 7; source = class-grid position of image b_l
-    int goff[Q::NP];                                   // element offset inside the tile's G images, class (0, 0), chunk kc = 0
+    // stride 1 with the class grid = the image (conv3): consecutive LDS rows are consecutive pixels, the offsets are linear in j (no registers)
+    constexpr bool LINEAR = S == 1 && Q::GH == H && Q::GW == W;
+    int goff[LINEAR ? 1 : Q::NP];                      // element offset inside the tile's G images, class (0, 0), chunk kc = 0
+    if constexpr (LINEAR) {
+        goff[0] = (tid >> 3) * C + (tid & 7) * 4;
+    } else {
 #pragma unroll
-    for (int j = 0; j < Q::NP; ++j) {
-        const int row = min((tid >> 3) + 32 * j, Q::ROWS - 1);
-        const int bl = row / (Q::GH * Q::GW), r = row - bl * (Q::GH * Q::GW), gy = r / Q::GW, gx = r - gy * Q::GW;
-        // grid positions past the image edge (conv2: none; a class whose last position would fall outside) are clamped: no tap reads them
-        const int iy = min(S * gy, H - S), ix = min(S * gx, W - S);
-        goff[j] = ((bl * H + iy) * W + ix) * C + (tid & 7) * 4;
+        for (int j = 0; j < Q::NP; ++j) {
+            const int row = min((tid >> 3) + 32 * j, Q::ROWS - 1);
+            const int bl = row / (Q::GH * Q::GW), r = row - bl * (Q::GH * Q::GW), gy = r / Q::GW, gx = r - gy * Q::GW;
+            goff[j] = ((bl * H + S * gy) * W + S * gx) * C + (tid & 7) * 4;
+        }
     }
+    auto piece_off = [&](int j) {                      // j is a compile-time constant at every call
+        if constexpr (LINEAR) return (j + 1) * 32 <= Q::ROWS ? goff[0] + j * 32 * C : min(goff[0] + j * 32 * C, (Q::ROWS - 1) * C + (tid & 7) * 4);
+        else return goff[j];
+    };
     uint8_t* const sw = x6c_lds + (tid >> 3) * Q::PITCH + (tid & 7) * 16;        // + j * 32 * PITCH
     // fragment reads: lane (i, h) of row block a_ = output row wave * 64 + a_ * 32 + i -> its class-grid row at tap (0, 0)
     int abase[2];
@@ -101,6 +111,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
     auto split_frag = [&](const x6r_f4& lo, const x6r_f4& hi, bf16x8 (&f)[3]) {
         u32x4v p0, p1, p2;
         uint32_t a, b, c;
+        if constexpr ((DBG & 8) != 0) {
+            p0 = u32x4v{__float_as_uint(lo.x) ^ sg_k, __float_as_uint(lo.z), __float_as_uint(hi.x), __float_as_uint(hi.z)};
+            p1 = u32x4v{__float_as_uint(lo.y), __float_as_uint(lo.w) ^ sg_k, __float_as_uint(hi.y), __float_as_uint(hi.w)};
+            p2 = p0 ^ p1;
+            f[0] = __builtin_bit_cast(bf16x8, p0); f[1] = __builtin_bit_cast(bf16x8, p1); f[2] = __builtin_bit_cast(bf16x8, p2);
+            return;
+        }
         split2_bf16x3_sg(lo.x, lo.y, sg_k, sg_s, a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
         split2_bf16x3_sg(lo.z, lo.w, sg_k, sg_s, a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
         split2_bf16x3_sg(hi.x, hi.y, sg_k, sg_s, a, b, c); p0[2] = a; p1[2] = b; p2[2] = c;
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
         {                                                                                                              \
             const int cls_ = (p_) / Q::CPC, kc_ = (p_) - cls_ * Q::CPC;                                                \
             const int po_ = ((cls_ / S) * W + (cls_ % S)) * C + kc_ * 32;                                              \
-            int o_ = goff[j_];                                                                                         \
+            int o_ = piece_off(j_);                                                                                         \
             if ((gv_) < G && o_ >= (gv_) * (H * W * C)) o_ -= (o_ / (H * W * C)) * (H * W * C);                        \
             ra[j_] = *reinterpret_cast<const x6r_f4*>((xt_) + po_ + o_);                                               \
         }
@@ -158,15 +175,28 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) fb[0][cb][pl] = *reinterpret_cast<const bf16x8*>(bq + (pl * 2 + cb) * 512);
             bf16x8 fa[2][3];
+            // raw fragments are read AHEAD units before their split (a ds_read consumed in the unit it is issued in stalls the wave's MFMA
+            // stream at its wait); two units where the registers allow it (conv3's 13 staged pieces leave no room: it would spill)
+            constexpr int AHEAD = Q::NP <= 10 ? 2 : 1;
+            x6r_f4 rlo[2], rhi[2];
+            auto raw_addr = [&](int u) {
+                const int tn = u >> 2, kn = (u >> 1) & 1, an = u & 1;
+                return x6c_lds + abase[an] + ((tn / Q::T) * Q::GW + (tn % Q::T)) * Q::PITCH + kn * 64;
+            };
             {
-                const uint8_t* s = x6c_lds + abase[0];
+                const uint8_t* s = raw_addr(0);
                 split_frag(*reinterpret_cast<const x6r_f4*>(s), *reinterpret_cast<const x6r_f4*>(s + 16), fa[0]);
+                if constexpr (AHEAD == 2) {
+                    const uint8_t* s1 = raw_addr(1);
+                    rlo[1] = *reinterpret_cast<const x6r_f4*>(s1);
+                    rhi[1] = *reinterpret_cast<const x6r_f4*>(s1 + 16);
+                }
             }
             constexpr int NU = Q::NTAP * 4;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int tap = u >> 2, kb = (u >> 1) & 1, a_ = u & 1;
-                if (a_ == 0 && u + 2 < NU) {           // next k block's B fragments -> the other register buffer
+                if (a_ == 0 && u + 2 < NU && !(DBG & 2)) {           // next k block's B fragments -> the other register buffer
                     const int g1 = (u >> 1) + 1;       // = tap * 2 + kb, next
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
@@ -174,27 +204,41 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
                         for (int cb = 0; cb < 2; ++cb)
                             fb[g1 & 1][cb][pl] = *reinterpret_cast<const bf16x8*>(bq + ((g1 * 3 + pl) * 2 + cb) * 512);
                 }
-                if (u < Q::NP) X6C_LOAD1(xp, gvp, pn, u)        // next pass's operand loads, one per unit
-                x6r_f4 lo, hi;
-                if (u + 1 < NU) {
-                    const int tn = (u + 1) >> 2, kn = ((u + 1) >> 1) & 1, an = (u + 1) & 1;
-                    const uint8_t* s = x6c_lds + abase[an] + ((tn / Q::T) * Q::GW + (tn % Q::T)) * Q::PITCH + kn * 64;
-                    lo = *reinterpret_cast<const x6r_f4*>(s);
-                    hi = *reinterpret_cast<const x6r_f4*>(s + 16);
+                // next pass's operand loads.  The memory counter retires in order: a wait for B fragments also waits for every
+                // staging load issued before them, so staging loads spread over the phase (LATE = 0: one per unit) put HBM latency
+                // in front of every k block; LATE = 1 issues them in the last three units, behind the pass's last B-fragment request
+                if constexpr (DBG & 1) {
+                    constexpr int PER = (Q::NP + 2) / 3;
+                    if (u >= NU - 3) {
+#pragma unroll
+                        for (int j = (u - (NU - 3)) * PER; j < (u - (NU - 3) + 1) * PER; ++j)
+                            if (j < Q::NP) X6C_LOAD1(xp, gvp, pn, j)
+                    }
+                } else {
+                    if (u < Q::NP) X6C_LOAD1(xp, gvp, pn, u)
+                }
+                if (u + AHEAD < NU) {
+                    const uint8_t* s = raw_addr(u + AHEAD);
+                    rlo[(u + AHEAD) & 1] = *reinterpret_cast<const x6r_f4*>(s);
+                    rhi[(u + AHEAD) & 1] = *reinterpret_cast<const x6r_f4*>(s + 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int g0 = u >> 1;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {          // small terms first, as the tiled engines
-                    acc[a_][b] = mma(fa[u & 1][2], fb[g0 & 1][b][0], acc[a_][b]);
-                    acc[a_][b] = mma(fa[u & 1][1], fb[g0 & 1][b][1], acc[a_][b]);
-                    acc[a_][b] = mma(fa[u & 1][0], fb[g0 & 1][b][2], acc[a_][b]);
-                    acc[a_][b] = mma(fa[u & 1][1], fb[g0 & 1][b][0], acc[a_][b]);
-                    acc[a_][b] = mma(fa[u & 1][0], fb[g0 & 1][b][1], acc[a_][b]);
-                    acc[a_][b] = mma(fa[u & 1][0], fb[g0 & 1][b][0], acc[a_][b]);
+                    if constexpr ((DBG & 4) != 0) {
+                        acc[a_][b][0] += (float)fa[u & 1][2][0] + (float)fb[g0 & 1][b][0][1] + (float)fa[u & 1][1][2] + (float)fa[u & 1][0][3];
+                        continue;
+                    }
+                    acc[a_][b] = mma(fa[u & 1][2], fb[(DBG & 2) ? 0 : (g0 & 1)][b][0], acc[a_][b]);
+                    acc[a_][b] = mma(fa[u & 1][1], fb[(DBG & 2) ? 0 : (g0 & 1)][b][1], acc[a_][b]);
+                    acc[a_][b] = mma(fa[u & 1][0], fb[(DBG & 2) ? 0 : (g0 & 1)][b][2], acc[a_][b]);
+                    acc[a_][b] = mma(fa[u & 1][1], fb[(DBG & 2) ? 0 : (g0 & 1)][b][0], acc[a_][b]);
+                    acc[a_][b] = mma(fa[u & 1][0], fb[(DBG & 2) ? 0 : (g0 & 1)][b][1], acc[a_][b]);
+                    acc[a_][b] = mma(fa[u & 1][0], fb[(DBG & 2) ? 0 : (g0 & 1)][b][0], acc[a_][b]);
                 }
                 if (u + 1 < NU) {
-                    split_frag(lo, hi, fa[(u + 1) & 1]);
+                    split_frag(rlo[(u + 1) & 1], rhi[(u + 1) & 1], fa[(u + 1) & 1]);
 #pragma unroll
                     for (int q = 0; q < 12; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -222,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
             for (int b = 0; b < 2; ++b) {
                 const int ml = wave * 64 + a * 32 + i;
                 const bool valid = ml < gv * Q::NPIX;
-                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? ((long)b0 * Q::NPIX + ml) * ef.ld + b * 32 : 0L, h, valid, sg_s);
+                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? ((long)b0 * Q::NPIX + ml) * ef.ld + b * 32 : 0L, h,
+                                  valid && (!(DBG & 16) || acc[a][b][0] == 12345.678f), sg_s);
             }
     }
 }
@@ -238,12 +283,25 @@ inline hipError_t launch_conv_x6c(const float* x, const float* w, uint16_t* plan
     using Q = X6cGeom<H, W, C, RF, S, NF, G>;
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL((x6c_split_planes_kernel<H, W, C, RF, S, NF, G>), dim3(64), dim3(256), 0, stream, w, planes);
-    auto kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5>;
-    static bool raised = false;
-    if (!raised) {
+    auto kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 0>;
+    int slot = 0;
+#ifdef MRL_X6_EXPERIMENTS
+    switch (conv_x6c() >> 1) {
+        case 1: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 1>; slot = 1; break;
+        case 2: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 2>; slot = 2; break;
+        case 4: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 4>; slot = 3; break;
+        case 8: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 8>; slot = 4; break;
+        case 16: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 16>; slot = 5; break;
+        case 6: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 6>; slot = 6; break;
+        case 10: kern = conv_x6c_kernel<H, W, C, RF, S, NF, G, EF, 5, 10>; slot = 7; break;
+        default: break;
+    }
+#endif
+    static bool raised[8] = {false};
+    if (!raised[slot]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised[slot] = true;
     }
     const int ntiles = (B + G - 1) / G;
     const int grid = std::max(1, std::min(ntiles, 2 * num_cus));

@@ -391,7 +391,8 @@ static int act_planes_mode() {
 // staged-planes kernel (gemmx6.hip.h); bit-identical results
 template <class AF, class EF>
 static hipError_t launch_x6_tr(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t st, long long* dbg) {
-    if (x6_frag() && !dbg && N % 32 == 0) return launch_gemm_x6r(af, Bp, ef, M, N, K, st);
+    // (N <= 64: the 32 x 128 wave tiles of the fc layer measured slower -- fc1.fwd 1.94 -> 2.17 ms, fc1.dgrad 2.39 -> 2.52 -- unless bit 3 asks)
+    if (x6_frag() && !dbg && N % 32 == 0 && (N <= 64 || (x6_frag() & 8))) return launch_gemm_x6r(af, Bp, ef, M, N, K, st);
     return launch_gemm_x6_planes<false, true>(af, 0, Bp, ef, M, N, K, st, dbg);
 }
 static int x6_specialised() { return kExp ? get_option("x6_spec", "MRL_X6_SPEC", 0) : 0; }
@@ -406,7 +407,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -432,6 +433,7 @@ extern "C" int mrl_set_option(const char* name, int value) {
             if (!strcmp(name, "x6_pg")) x6_pg() = value;
             if (!strcmp(name, "x6_frag")) x6_frag() = value;
             if (!strcmp(name, "conv_x6c")) conv_x6c() = value;
+            if (!strcmp(name, "wgrad_pipe")) wgrad_tr_pipe() = value;
             if (!strcmp(name, "lstm_e1")) lstm_e1() = value;
             if (!strcmp(name, "x6_dbg")) x6_xd() = value >= 100 ? value - 100 : 0;
             return 0;

@@ -78,7 +78,13 @@ struct WgTrCfg {
 // Wave -> tiles.  The K / 32 m tiles are numbered t = (ky * CB + cb) * RF + kx (CB = C / 32 channel blocks); a wave owns TM
 // consecutive ones -- TM taps kx .. kx + TM - 1 of ONE kernel row and ONE channel block, so their LDS addresses differ by
 // immediates (one pixel stride each) -- and TN consecutive n tiles.
-template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD, int DBG = 0>
+// PIPE (round 5, option wgrad_tr = 1): the split arithmetic of image b+1 runs BETWEEN the MFMAs of image b's later chunks and its
+// planes wait in registers for the barrier (only the LDS stores are left between the barriers).  All waves of the one workgroup
+// per CU walk their phases together, so a split phase of its own keeps the matrix pipe idle for its whole length (fake-split
+// bound: -17 % of the kernel); placed instruction by instruction behind MFMAs most of it hides (profiles/r05b_interleave_ubench.txt:
+// 1 wave per SIMD, 48 MFMAs + 320 VALU: 5.5 ms as two blocks, 3.7 ms interleaved).  Round 3 tried the same split as ONE block in
+// the middle of the MFMA phase -- slower; the difference is the placement.  Same products, same order: bit-identical.
+template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD, int DBG = 0, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B,
                                                               float* __restrict__ part, int dither) {
     using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
@@ -177,18 +183,74 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
         }
     };
 
+    // PIPE: the planes of the next image, split ahead of the barrier.  (u32x4v = {plane 0 | 1 | 2}[q] as {xy, zw} pairs)
+    uint32_t px[PIPE ? G::NXV : 1][6], pd[PIPE ? G::NDV : 1][6];
+    bool split_live = true;                            // false while the (already split) last image of this workgroup is multiplied
+    auto split_x = [&](int q) {
+        split2_bf16x3(rx[q].x, rx[q].y, px[q][0], px[q][2], px[q][4]);
+        split2_bf16x3(rx[q].z, rx[q].w, px[q][1], px[q][3], px[q][5]);
+    };
+    auto split_d = [&](int q) {
+        split2_bf16x3_sg(rd[q].x, rd[q].y, sg_k, sg_s, pd[q][0], pd[q][2], pd[q][4]);
+        split2_bf16x3_sg(rd[q].z, rd[q].w, sg_k, sg_s, pd[q][1], pd[q][3], pd[q][5]);
+        if (split_live && tid + q * G::NT < G::DZV) { bias4.x += rd[q].x; bias4.y += rd[q].y; bias4.z += rd[q].z; bias4.w += rd[q].w; }
+    };
+    auto write_planes = [&]() {
+#pragma unroll
+        for (int q = 0; q < G::NXV; ++q)
+            if (tid + q * G::NT < G::XV) {
+                uint8_t* d = xs + xw0 + q * (G::NT / XQ) * G::XPS;
+                *reinterpret_cast<uint2*>(d) = make_uint2(px[q][0], px[q][1]);
+                *reinterpret_cast<uint2*>(d + C * 2) = make_uint2(px[q][2], px[q][3]);
+                *reinterpret_cast<uint2*>(d + C * 4) = make_uint2(px[q][4], px[q][5]);
+            }
+#pragma unroll
+        for (int q = 0; q < G::NDV; ++q)
+            if (tid + q * G::NT < G::DZV) {
+                uint8_t* d = ds + dw0 + q * (G::NT / DQ) * G::DPS;
+                *reinterpret_cast<uint2*>(d) = make_uint2(pd[q][0], pd[q][1]);
+                *reinterpret_cast<uint2*>(d + NF * 2) = make_uint2(pd[q][2], pd[q][3]);
+                *reinterpret_cast<uint2*>(d + NF * 4) = make_uint2(pd[q][4], pd[q][5]);
+            }
+    };
+    // the split of the next image is spread over the LAST SPLIT_CH chunks of the MFMA phase (its loads were issued at the phase's
+    // start and have that long to arrive): pieces [lo, hi) of the NXV + NDV staged float4s go behind chunk q's MFMAs
+    constexpr int NPIECE = G::NXV + G::NDV;
+    constexpr int SPLIT_CH = G::NCH >= 4 ? G::NCH - 2 : G::NCH - 1;
+    constexpr int MF_CH = TM * TN * kSplitProducts;                 // MFMAs per chunk and wave
+
     int b = blockIdx.x;
     if (b < B) issue_loads(b);
+    if constexpr (PIPE) {
+        if (b < B) {                                       // the first image: split in the open
+#pragma unroll
+            for (int q = 0; q < G::NXV; ++q) split_x(q);
+#pragma unroll
+            for (int q = 0; q < G::NDV; ++q) split_d(q);
+        }
+    }
     for (; b < B; b += gridDim.x) {
         __syncthreads();                                   // the previous image's fragment reads are done
-        if (!(DBG & 1) || b == (int)blockIdx.x) write_stage();      // DBG 1 (timing experiment): stage the first image only
+        if constexpr (PIPE) write_planes();
+        else if (!(DBG & 1) || b == (int)blockIdx.x) write_stage();      // DBG 1 (timing experiment): stage the first image only
         const int bn = b + gridDim.x;
         if (bn < B) issue_loads(bn);                       // in flight during the MFMA phase
+        split_live = bn < B;
         __syncthreads();
         // ---- MFMA phase: NCH chunks of 16 pixels
         if (DBG & 2) continue;                             // DBG 2 (timing experiment): no MFMA phase
 #pragma unroll
         for (int q = 0; q < G::NCH; ++q) {
+            if constexpr (PIPE) {
+                // (the workgroup's last image: the split runs on stale registers and is never written)
+                constexpr int q0 = G::NCH - SPLIT_CH;
+                if (q >= q0) {
+                    const int lo = (q - q0) * NPIECE / SPLIT_CH, hi = (q - q0 + 1) * NPIECE / SPLIT_CH;
+#pragma unroll
+                    for (int e = 0; e < NPIECE; ++e)
+                        if (e >= lo && e < hi) { if (e < G::NXV) split_x(e); else split_d(e - G::NXV); }
+                }
+            }
             bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
@@ -221,6 +283,20 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[c][1], acc[a][c], 0, 0, 0);
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[c][0], acc[a][c], 0, 0, 0);
                 }
+            if constexpr (PIPE) {
+                constexpr int q0 = G::NCH - SPLIT_CH;
+                if (q >= q0) {
+                    // this chunk's fragment reads first, then one MFMA : VPM split instructions (30 + moves per piece)
+                    constexpr int VPM = (NPIECE * 34 / SPLIT_CH + MF_CH - 1) / MF_CH;
+                    __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * 3 * 2, 0);
+#pragma unroll
+                    for (int m = 0; m < MF_CH; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -256,15 +332,18 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tr_kernel(const float* __res
     }
 }
 
+inline int& wgrad_tr_pipe() { static int p = getenv("MRL_WGRAD_PIPE") ? atoi(getenv("MRL_WGRAD_PIPE")) : 1; return p; }   // mrl_set_option "wgrad_pipe"
 template <int H, int W, int C, int RF, int STRIDE, int NF, int WAVES, int TM, int TN, int XPAD, int DPAD, int DBG = 0>
 inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float* part, int nblocks, hipStream_t stream) {
     using G = WgTrCfg<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD>;
-    auto kern = wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD, DBG>;
-    static bool raised = false;
-    if (!raised) {
+    const bool pipe = DBG == 0 && wgrad_tr_pipe() != 0;
+    auto kern = pipe ? wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD, DBG, DBG == 0>
+                     : wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD, DBG, false>;
+    static bool raised[2] = {false, false};
+    if (!raised[pipe]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised[pipe] = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part, x6_dither() & 1);
     return hipGetLastError();

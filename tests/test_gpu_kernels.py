@@ -335,7 +335,7 @@ def test_engine_options_agree():
         return g.cpu().numpy(), st.cpu().numpy()
 
     names = ['u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'tr_epilogue',
-             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c']
+             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c', 'wgrad_pipe']
     # builds with -DMRL_X6_EXPERIMENTS also carry the measured-and-dropped variants (plane tensors, separate load phase)
     experiments = True
     try:
@@ -349,6 +349,7 @@ def test_engine_options_agree():
     assert defaults['wgrad_tr'] == 1, 'conv2 / conv3 / fc1 weight gradients: transpose-read kernels by default'
     assert defaults['c1_lds'] == 4, 'first conv layer forward: software-pipelined image-resident kernel by default'
     assert defaults['x6_dither'] == 3, 'tiled split engines: sign alternation of the staged rows and conflict-free staging order by default'
+    assert defaults['wgrad_pipe'] == 1, 'conv2 / conv3 weight gradients: next image split between the MFMAs of the current one by default'
     assert defaults['conv_x6c'] == 1, 'conv2 / conv3 forward at minibatch sizes: class-resident kernel by default'
     assert defaults['x6_frag'] == 1, 'tiled split engines: operand split on the fragment path, between the MFMAs, by default'
     if experiments:
@@ -396,6 +397,7 @@ def test_engine_options_agree():
                  ('split engines, split on the fragment path, conv k steps in natural order', dict(defaults, x6_frag=5, conv_x6c=0), 3e-6),
                  ('split engines, split on the fragment path, natural k order, no sign alternation', dict(defaults, x6_frag=5, x6_dither=2, conv_x6c=0), 3e-6),
                  ('split engines, split on the fragment path, two register sets of operand loads', dict(defaults, x6_frag=2, conv_x6c=0), 3e-6),
+                 ('split engines, conv weight gradients with a split phase of its own (no software pipeline)', dict(defaults, wgrad_pipe=0), 3e-6),
                  ('split engines, class-resident conv forward without the sign alternation', dict(defaults, x6_dither=2), 3e-6),
                  ('split engines, tiled conv forward in class-major k order without the sign alternation', dict(defaults, x6_dither=2, conv_x6c=0), 3e-6),
                  ('split engines, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
@@ -434,7 +436,9 @@ def test_engine_options_agree():
                      # the class-resident kernel walks k in the class-major order of the tiled engine's default: the same sums (its tiles
                      # are whole images, so WHICH rows the sign alternation negates differs -- compared without it)
                      ('split engines, class-resident conv forward without the sign alternation',
-                      'split engines, tiled conv forward in class-major k order without the sign alternation')):
+                      'split engines, tiled conv forward in class-major k order without the sign alternation'),
+                     # the pipelined weight gradients split the same values and multiply in the same order
+                     ('split engines (default)', 'split engines, conv weight gradients with a split phase of its own (no software pipeline)')):
             np.testing.assert_array_equal(by_name[a][0], by_name[b][0], err_msg=b)
             np.testing.assert_array_equal(by_name[a][1], by_name[b][1], err_msg=b)
     finally:
