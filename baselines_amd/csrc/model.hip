@@ -1293,6 +1293,81 @@ __global__ __launch_bounds__(256) void heads_act_kernel(HeadArgs a) {
     }
 }
 
+// ---- wave-per-sample act heads for the NatureCNN head shape (Categorical <= 8 actions, value head on the same 512-wide latent) ----
+// The tile kernel above walks 32 samples per workgroup through LDS scalar loops: at the act batch of a 512-env shard that is 16
+// workgroups and 57 us per env step (profiles/r05k_rollout_trace_n512.txt), 12 % of the rollout.  Here a wave owns a sample: lane l
+// holds latent elements [8 l, 8 l + 8) and its slice of Wpi / Wvf in registers, the nact + 1 dot products are butterfly-reduced
+// (same form as heads_train_wave_kernel, so act and train see the same logits for the same parameters), lane 0 samples
+// (Gumbel-max, policies.py:52; distributions.py:199-201) and writes action / value / neglogp.
+template <int KPL>
+__global__ __launch_bounds__(256) void heads_act_wave_kernel(HeadArgs a) {
+    constexpr int NA = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nact = a.nact, nlat = a.nlat;
+    float W[KPL][NA], Wv[KPL];
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+        const int k = lane * KPL + kk;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) W[kk][j] = j < nact ? a.Wpi[k * nact + j] : 0.f;
+        Wv[kk] = a.Wvf[k];
+    }
+    const int nwaves = gridDim.x * 4;
+    for (int s = blockIdx.x * 4 + wave; s < a.Bc; s += nwaves) {
+        float x[KPL];
+        const float4* src = reinterpret_cast<const float4*>(a.lat + (long)s * nlat + lane * KPL);
+#pragma unroll
+        for (int q = 0; q < KPL / 4; ++q) {
+            const float4 v4 = src[q];
+            x[q * 4 + 0] = v4.x; x[q * 4 + 1] = v4.y; x[q * 4 + 2] = v4.z; x[q * 4 + 3] = v4.w;
+        }
+        float pi[NA], v = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) t = fmaf(x[kk], W[kk][j], t);
+            pi[j] = t;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPL; ++kk) v = fmaf(x[kk], Wv[kk], v);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                if (j < nact) pi[j] += __shfl_xor(pi[j], off);
+            v += __shfl_xor(v, off);
+        }
+        if (lane == 0) {
+            const long b = a.row0 + s;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) if (j < nact) pi[j] += a.bpi[j];
+            if (a.values_out) a.values_out[b] = v + a.bvf[0];
+            if (a.pdparam_out) {
+#pragma unroll
+                for (int j = 0; j < NA; ++j) if (j < nact) a.pdparam_out[b * nact + j] = pi[j];
+            }
+            if (a.actions_out) {
+                const float* nz = a.noise + b * nact;
+                int best = 0;                              // argmax(logits - log(-log(u))), first max wins (tf.argmax)
+                float bv = pi[0] - logf(-logf(nz[0])), mx = pi[0], pbest = pi[0];
+#pragma unroll
+                for (int j = 1; j < NA; ++j)
+                    if (j < nact) {
+                        const float c = pi[j] - logf(-logf(nz[j]));
+                        if (c > bv) { bv = c; best = j; pbest = pi[j]; }
+                        mx = fmaxf(mx, pi[j]);
+                    }
+                float z0 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) if (j < nact) z0 += expf(pi[j] - mx);
+                static_cast<int32_t*>(a.actions_out)[b] = best;
+                a.neglogp_out[b] = logf(z0) - (pbest - mx);
+            }
+        }
+    }
+}
+
 // ============================================================================================
 // layer normalisation of mlp(layer_norm=True) --- common/models.py:97-98: tf.contrib.layers.layer_norm(h, center=True,
 // scale=True): moments over the features of a row (biased variance), y = (z - mean) * rsqrt(var + 1e-12) * gamma + beta,
@@ -1572,7 +1647,12 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                     // k steps in class-major order (gemmx6.hip.h conv_kcls_*): the split-at-the-fragment launches only, so that
                     // x6_frag = 0 stays the round-4 engine for A/B runs
                     const bool kcls = tr && !pa && x6_frag() && !(x6_frag() & 4) && l.rf % l.stride == 0 && l.C % 32 == 0 && l.NF % 32 == 0;
-                    hipError_t e = kcls ? launch_split_planes(W, l.K, l.NF, true, planes, st, false, l.rf, l.stride, l.C)
+                    // (the class-resident kernel lays out its own fragment-ordered weight planes)
+                    const bool x6c = tr && !pa && !trp && conv_x6c() && B >= 96 && l.NF == 64 && l.pad_t == 0 && l.pad_l == 0 &&
+                                     ((l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2) ||
+                                      (l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1));
+                    hipError_t e = x6c ? hipSuccess
+                                 : kcls ? launch_split_planes(W, l.K, l.NF, true, planes, st, false, l.rf, l.stride, l.C)
                                         : launch_split_planes(W, l.K, l.NF, true, planes, st, pa);
                     if (e != hipSuccess) return (int)e;
                     ca.kcls = kcls ? 1 : 0;
@@ -1587,7 +1667,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                             if (trp) *hpwrote = 1;
                             // NatureCNN's conv2 / conv3 at minibatch sizes: class-resident kernel (convx6c.hip.h) -- whole images per
                             // tile, every input element loaded once, 4 / 2 barrier pairs per tile instead of 16 / 18
-                            if (!pa && !trp && conv_x6c() && B >= 1024 && l.NF == 64 && l.pad_t == 0 && l.pad_l == 0) {
+                            if (x6c) {
                                 if (l.H == 20 && l.W == 20 && l.C == 32 && l.rf == 4 && l.stride == 2)
                                     return (int)launch_conv_x6c<20, 20, 32, 4, 2, 64, 3>(hprev, W, planes, tf, B, num_cus(), st);
                                 if (l.H == 9 && l.W == 9 && l.C == 64 && l.rf == 3 && l.stride == 1)
@@ -1646,8 +1726,10 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
         // adds the bias and applies the activation.
         const RowKC af0{first ? (const float*)in.obs : hprev, l.K, B, l.K, is_vec(first ? in.obs : (const void*)hprev, l.K),
                         first ? in.srow : nullptr};
-        if (part && B <= 64 && l.K >= 1024 && !tuned(l, "fwd")) {
-            const int ntile = (l.N + 31) / 32;
+        // Round 5: also the act batches of an env shard (B = 256 .. 1023 rows of fc1: 16 tiles walking K = 3136 took 286 us of a
+        // 483 us env step, profiles/r05k_rollout_trace_n512.txt); the tiled split engine takes over from B = 1024.
+        if (part && B < 1024 && l.K >= 1024 && !tuned(l, "fwd")) {
+            const int ntile = ((B + 127) / 128) * ((l.N + 31) / 32);
             int ns = std::max(1, std::min(512 / ntile, l.K / 128));
             const int ksplit = ((l.K + ns - 1) / ns + 31) / 32 * 32;
             ns = (l.K + ksplit - 1) / ksplit;
@@ -2243,7 +2325,7 @@ static int model_act_impl(const mrl_model* m, const float* params, const void* o
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int Bc = std::min(chunk, n - c0);
         In in{(const char*)obs + (size_t)c0 * ob_bytes, nullptr};
-        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
+        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st, ws.part, ws.part_floats);       // (split-K fc layers at act batch sizes)
         if (rc) return rc;
         if (m->pi.lstm) {      // one step of Bc independent sequences (policies.py:77-96 with S, M fed; act model nsteps = 1)
             const int ss = 2 * m->pi.nh;
@@ -2270,7 +2352,12 @@ static int model_act_impl(const mrl_model* m, const float* params, const void* o
             if (e != hipSuccess) return (int)e;
         }
         ProfScope ps("heads_act", 0.0, (double)Bc * (4.0 * a.nlat + (a.shared ? 0 : 4.0 * a.nlatv) + 16.0), st);
-        hipLaunchKernelGGL(heads_act_kernel, dim3(std::min(ntiles, HEAD_MAXBLK)), dim3(256), lds, st, a);
+        const bool wave_ok = a.has_pi_head && a.shared && a.pd_kind == MRL_PD_CATEGORICAL && a.nact <= 8 && a.nlat == 512 &&
+                             (uintptr_t)a.lat % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 1);
+        if (wave_ok)       // one wave per sample, up to 8 samples per wave
+            hipLaunchKernelGGL(heads_act_wave_kernel<8>, dim3(std::max(1, std::min((Bc + 3) / 4, 2048))), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(heads_act_kernel, dim3(std::min(ntiles, HEAD_MAXBLK)), dim3(256), lds, st, a);
         MRL_LAUNCH_CHECK();
     }
     return 0;
