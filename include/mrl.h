@@ -424,10 +424,18 @@ int mrl_tune_set(const char* label, int variant);
  *                  engine.  4, 3 and 2 are bit-identical (same products, same order of accumulation).
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
- *   "x6_frag"     [MRL_X6_FRAG, 1]  tiled split engine, forward / fc data-gradient launches: the streamed operand is staged into LDS as
- *                  raw fp32 and split into its three bf16 planes on the FRAGMENT path, between the MFMAs of the wave that owns the
- *                  rows (gemmx6r.hip.h) -- the split arithmetic hides behind the matrix instructions instead of forming a
- *                  barrier-delimited phase of its own; 0 = split while staging (gemmx6.hip.h).  Bit-identical.
+ *   "conv_x6c"    [MRL_CONV_X6C, 1]  conv2 / conv3 forward of NatureCNN from 96 images up on the class-resident kernel
+ *                  (convx6c.hip.h): a tile is whole images, the input pixels of one stride-parity class are staged once as raw
+ *                  fp32 and serve all taps of the class (every input element loaded once, 4 / 2 barrier pairs per tile instead of
+ *                  16 / 18), operand split on the fragment path between the MFMAs, weight fragments as coalesced 1 KB loads;
+ *                  0 = tiled engine.  Same products, k walked in class-major order.
+ *   "x6_frag"     [MRL_X6_FRAG, 1]  tiled split engine, 64-filter conv forward launches (the batches "conv_x6c" does not take): the
+ *                  streamed operand is staged into LDS as raw fp32 and split into its three bf16 planes on the FRAGMENT path,
+ *                  between the MFMAs of the wave that owns the rows (gemmx6r.hip.h), k walked in class-major order;
+ *                  0 = split while staging, natural k order (gemmx6.hip.h, the round-4 engine).
+ *   "wgrad_pipe"  [MRL_WGRAD_PIPE, 1]  conv2 / conv3 weight gradients (wgrad_tr): the next image's operand split runs between the
+ *                  MFMAs of the current image and its planes wait in registers for the barrier; 0 = a split phase of its own.
+ *                  Bit-identical.
  *   "x6_dither"   [MRL_X6_DITHER, 3]  two bits.  Bit 0: the tiled split engines (forward and data-gradient GEMMs) stage every other
  *                  group of 8 rows of their streamed operand with its sign flipped and undo that in the epilogue (no extra instructions): the small
  *                  bias toward -inf that v_mfma_f32_32x32x16_bf16 has for products far below its accumulator then alternates
