@@ -28,8 +28,8 @@ LABELS = {
 # (".top8" lines of scripts/rocpd_pmc.py, launch order); (kernel substring, which of the alternating layers, of how many)
 TOP = {
     'c1.fwd': ('c1fwd3_kernel', 0, 1),
-    'c2.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::TrBiasRelu', 0, 2),
-    'c3.fwd': ('gemm_x6_kernel<mrl::X6ConvA, mrl::TrBiasRelu', 1, 2),
+    'c2.fwd': ('conv_x6c_kernel<20, 20, 32', 0, 1),          # round 5: class-resident conv forward (convx6c.hip.h)
+    'c3.fwd': ('conv_x6c_kernel<9, 9, 64', 0, 1),
     'fc1.fwd': ('gemm_x6_kernel<mrl::X6DenseA, mrl::TrBiasRelu', 0, 1),
 }
 
