@@ -792,7 +792,11 @@ def main():
                        'envs_per_gpu': res['N'], 'nbatch_train_per_gpu': res['nbatch_train'], 'chunk': res['chunk'],
                        'arithmetic_mode': arith_short, 'arithmetic': arith_text,
                        'parallelism': 'dp%d (envs sharded, 1 all-reduce of the flat gradient per minibatch step)' % world,
-                       'world_size_observed': observed_world, 'collective': collective},
+                       'world_size_observed': observed_world, 'collective': collective,
+                       # north_star's "Adam fused into the gradient kernel" (SURVEY row n1): measured and declined, DESIGN.md 3.6 / 8
+                       'adam': 'separate launch, measured: clip + Adam is ONE 28*P-byte pass right behind the gradient reduction; a '
+                               'last-arriving-workgroup tail inside the gradient kernel needs a grid-wide release/acquire across 8 '
+                               'non-coherent L2s (~3.5 us) -- more than the 1.5-1.9 us kernel boundary it would replace'},
             'model_tflops': res['model_tflops'],
             # power-limited: the sampled shader clock sits well below the 2.4 GHz the nominal peaks are quoted at
             'device_state': res.get('device_state'),
