@@ -30,7 +30,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
     assert r['traffic'] is None or r['traffic'] > 0
-XX
+    assert (r['traffic'] is None or (r['traffic_source'].startswith('profiles/r') and r['traffic_source'].endswith('_pmc_hbm.json'))) and d['dtype'] == 'f32'
+    # round 5: counter traffic of all GEMM sites over their algorithmic bytes (was 1.49 with the tiled conv forward's re-reads)
+    assert r['traffic'] is None or r['all_gemm_sites_traffic_over_algorithmic'] <= 1.35
+    assert 'separate launch, measured' in d['config']['adam']
     assert r['bound'] == 'mfma' and abs(r['frac'] - r['mfma_frac']) < 1e-12 and 0 < r['hbm_frac'] < r['frac']
     # the headline runs the split engines: six exact bf16 products per fp32 multiply, nearest-rounded planes
     assert d['config']['arithmetic_mode'] == 'bf16x6-rn-split'
