@@ -426,8 +426,36 @@ inline bool gemm_x6_ok(const void* A, long lda, int K) {
 }
 inline size_t gemm_x6_plane_bytes(long N, long K) { return (size_t)3 * N * K * sizeof(uint16_t); }
 
+// transpose form through an LDS tile (round 5): out[plane][n][k] from src[k][n] -- the element-wise kernel above writes 2-byte
+// pieces K * 2 bytes apart (fc1's 3136 x 512 weights: 28-35 us per call, twice per minibatch step and once per act step); here a
+// workgroup reads a 32 (k) x 64 (n) tile with coalesced rows and writes 16-byte pieces of 8 consecutive k per (plane, n).
+__global__ __launch_bounds__(256) void split_planes_tr_kernel(const float* __restrict__ src, int K, int N, uint16_t* __restrict__ out) {
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int ntn = N / 64, tk = blockIdx.x / ntn, tn = blockIdx.x - tk * ntn;
+    const int k0 = tk * 32, n0 = tn * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = (tid >> 6) + 4 * j, n = tid & 63;
+        tile[k][n] = src[(long)(k0 + k) * N + n0 + n];
+    }
+    __syncthreads();
+    const int n = tid >> 2, kc = (tid & 3) * 8;
+    uint32_t p[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        split2_bf16x3(tile[kc + 2 * q][n], tile[kc + 2 * q + 1][n], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4v*>(out + ((long)pl * N + n0 + n) * K + k0 + kc) = u32x4v{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+}
+
 inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool transpose, uint16_t* out, hipStream_t stream,
                                       bool kperm = false, int kcls_rf = 0, int kcls_stride = 1, int kcls_c = 32) {
+    if (transpose && !kperm && !kcls_rf && R % 32 == 0 && Cn % 64 == 0 && (uintptr_t)out % 16 == 0) {
+        hipLaunchKernelGGL(split_planes_tr_kernel, dim3((unsigned)((R / 32) * (Cn / 64))), dim3(256), 0, stream, src, R, Cn, out);
+        return hipGetLastError();
+    }
     const long total = (long)R * Cn;
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out, kperm ? 1 : 0,

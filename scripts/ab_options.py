@@ -52,7 +52,7 @@ def measure(tag):
     _lib.prof_enable(False)
     r = _lib.prof_report()
     tot = sum(v['ms'] for v in r.values()) / 2
-    keys = ['c1.fwd', 'c2.fwd', 'c3.fwd', 'fc1.fwd', 'fc1.dgrad', 'c3.dgrad', 'c2.dgrad', 'c1.wgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad']
+    keys = ['c1.fwd', 'c2.fwd', 'c3.fwd', 'fc1.fwd', 'fc1.dgrad', 'c3.dgrad', 'c2.dgrad', 'c1.wgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad', 'heads_loss']
     print('%-22s epoch %.2f ms | ' % (tag, tot) + ' '.join('%s %.2f' % (k, r[k]['ms'] / r[k]['count']) for k in keys), flush=True)
 
 

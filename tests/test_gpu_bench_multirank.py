@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_two_ranks_one_json_line_and_synced_parameters(num_envs):
     """num_envs=1024: 512 envs per rank -> 16384-sample minibatches, i.e. every rank runs the engines of the benched shapes
     (tiled split engines need B >= 1024)"""
-    env = dict(os.environ, MRL_BENCH_BACKEND='gloo', MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, MRL_BENCH_BACKEND='gloo', MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0', MRL_BENCH_DP_STRICT='1')
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--num-envs', str(num_envs),
@@ -40,7 +40,7 @@ def test_bench_two_ranks_one_json_line_and_synced_parameters(num_envs):
     # the data-parallel self-validation of the first multi-GPU run (bench.dp_verify), rehearsed over gloo: the all-reduced
     # local gradients against rank 0 recomputing every rank's gathered minibatch on its own device
     v = d['dp_verify']
-    assert v['ranks'] == 2 and v['minibatch'] == d['config']['nbatch_train_per_gpu']
+    assert v['ok'] is True and v['ranks'] == 2 and v['minibatch'] == d['config']['nbatch_train_per_gpu']
     assert v['max_abs_diff_over_scale'] <= 1e-6 and v['recompute_vs_plain_max_abs_diff_over_scale'] <= 1e-6
     assert v['rank0_gathered_rows_reproduce_its_indexed_gradient_bitwise'] is True
     assert v['overlapped_equals_plain'] is None and 'not exercised' in v['note']      # RCCL refuses two ranks on one device
@@ -53,7 +53,7 @@ def test_bench_two_ranks_over_the_in_library_rccl_path_when_two_gpus_are_visible
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 HIP devices (RCCL refuses two ranks on one device)')
-    env = dict(os.environ, MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, MRL_BENCH_SMI='0', HSA_ENABLE_IPC_MODE_LEGACY='0', MRL_BENCH_DP_STRICT='1')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MRL_BENCH_BACKEND', 'MRL_NATIVE_COMM'):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--num-envs', '1024',
@@ -64,5 +64,5 @@ def test_bench_two_ranks_over_the_in_library_rccl_path_when_two_gpus_are_visible
     assert d['n_gpus'] == 2 and d['params_synced_across_ranks'] is True
     assert d['config']['native_dp'] is True and 'in-library RCCL' in d['config']['collective']
     v = d['dp_verify']
-    assert v['overlapped_equals_plain'] is True and v['max_abs_diff_over_scale'] <= 1e-6
+    assert v['ok'] is True and v['overlapped_equals_plain'] is True and v['max_abs_diff_over_scale'] <= 1e-6
     assert v['overlapped_bit_identical_to_plain'] is True          # two addends: the sum does not depend on the ring's order
