@@ -211,14 +211,83 @@ __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew,
     }
 }
 
+// One environment per LANE (round 5): a wave owns 64 consecutive environments, every load / store of a time step is one coalesced row
+// segment, the operands of GAE_LU steps are requested before the chain walks them, and nothing goes through LDS.  Same operations
+// in the same order per environment as gae_kernel above (bit-identical; the goldens of the reference's Runner.run hold for both);
+// only the carry -> carry part of a step (one f64 multiply, one f64 add) is on the dependent chain, delta is formed beside it.
+// 19 -> ~7 us at T = 128, N = 4096: all 64 lanes of 64 waves walk chains instead of 16 lanes of 256 workgroups.
+constexpr int GAE_LU = 8;
+__global__ __launch_bounds__(64) void gae_lane_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                      const uint8_t* __restrict__ done, const float* __restrict__ last_val,
+                                                      const uint8_t* __restrict__ last_done, float gamma_f, double gamma_lam,
+                                                      float* __restrict__ adv_out, float* __restrict__ ret_out, int T, int N) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= N) return;
+    double carry = 0.0;
+    float v1 = last_val[e];                     // V[t + 1]
+    float m1 = last_done[e] ? 0.f : 1.f;        // 1 - done[t + 1]
+    int t = T - 1;
+    float rn[GAE_LU], vn[GAE_LU];               // the NEXT block's operands, requested before this block's chain is walked
+    uint8_t dn[GAE_LU];
+    auto request = [&](int tb) {
+#pragma unroll
+        for (int u = 0; u < GAE_LU; ++u) {
+            const long o = (long)(tb - u) * N + e;
+            rn[u] = rew[o]; vn[u] = val[o]; dn[u] = done[o];
+        }
+    };
+    if (t >= GAE_LU - 1) request(t);
+    for (; t >= GAE_LU - 1; t -= GAE_LU) {
+        float r_[GAE_LU], v_[GAE_LU];
+        uint8_t d_[GAE_LU];
+#pragma unroll
+        for (int u = 0; u < GAE_LU; ++u) { r_[u] = rn[u]; v_[u] = vn[u]; d_[u] = dn[u]; }
+        if (t - GAE_LU >= GAE_LU - 1) request(t - GAE_LU);
+#pragma unroll
+        for (int u = 0; u < GAE_LU; ++u) {
+            const double nnt = (double)m1;
+            const float gv = __fmul_rn(gamma_f, v1);
+            const double delta = __dsub_rn(__dadd_rn((double)r_[u], __dmul_rn((double)gv, nnt)), (double)v_[u]);
+            carry = __dadd_rn(delta, __dmul_rn(__dmul_rn(gamma_lam, nnt), carry));
+            const float a = (float)carry;
+            const long o = (long)(t - u) * N + e;
+            if (adv_out) adv_out[o] = a;
+            ret_out[o] = __fadd_rn(a, v_[u]);
+            v1 = v_[u];
+            m1 = d_[u] ? 0.f : 1.f;             // done[t] gates step t - 1
+        }
+    }
+    for (; t >= 0; --t) {
+        const long o = (long)t * N + e;
+        const float r = rew[o], v = val[o];
+        const uint8_t d = done[o];
+        const double nnt = (double)m1;
+        const float gv = __fmul_rn(gamma_f, v1);
+        const double delta = __dsub_rn(__dadd_rn((double)r, __dmul_rn((double)gv, nnt)), (double)v);
+        carry = __dadd_rn(delta, __dmul_rn(__dmul_rn(gamma_lam, nnt), carry));
+        const float a = (float)carry;
+        if (adv_out) adv_out[o] = a;
+        ret_out[o] = __fadd_rn(a, v);
+        v1 = v;
+        m1 = d ? 0.f : 1.f;
+    }
+}
+
 extern "C" int mrl_gae(const float* rew, const float* val, const uint8_t* done, const float* last_val,
                        const uint8_t* last_done, double gamma, double lam, float* adv_out, float* ret_out,
                        int T, int N, void* stream) {
     if (T <= 0 || N <= 0 || !rew || !val || !done || !last_val || !last_done || !ret_out) return MRL_EINVAL;
-    dim3 grid((N + GAE_E - 1) / GAE_E);
     ProfScope ps("gae", 0.0, 17.0 * T * N + 9.0 * N, (hipStream_t)stream);
-    hipLaunchKernelGGL(gae_kernel, grid, dim3(256), 0, (hipStream_t)stream, rew, val, done, last_val, last_done,
-                       (float)gamma, gamma * lam, adv_out, ret_out, T, N);
+    static const int lane_form = getenv("MRL_GAE_LANE") ? atoi(getenv("MRL_GAE_LANE")) : 1;      // 0: the LDS-staged kernel (A/B; bit-identical)
+    // a lane per environment needs a wave's worth of environments; smaller vector envs keep the 16-per-workgroup form
+    if (lane_form && N >= 64) {
+        hipLaunchKernelGGL(gae_lane_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew, val, done, last_val, last_done,
+                           (float)gamma, gamma * lam, adv_out, ret_out, T, N);
+    } else {
+        dim3 grid((N + GAE_E - 1) / GAE_E);
+        hipLaunchKernelGGL(gae_kernel, grid, dim3(256), 0, (hipStream_t)stream, rew, val, done, last_val, last_done,
+                           (float)gamma, gamma * lam, adv_out, ret_out, T, N);
+    }
     MRL_LAUNCH_CHECK();
     return 0;
 }
