@@ -531,7 +531,7 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
 
 
 TRACE_LABELS = (('mlp_step_kernel', 'mlp_step'), ('mlp_tail_kernel', 'mlp_tail'), ('reduce_slabs_kernel', 'reduce_slabs'),
-                ('adam_kernel', 'clip+adam'), ('mlp_advstat_kernel', 'advstat'), ('gae_kernel', 'gae'))
+                ('adam_kernel', 'clip+adam'), ('mlp_advstat_kernel', 'advstat'), ('gae_kernel', 'gae'), ('gae_lane_kernel', 'gae'))
 
 
 def graph_kernel_trace(workload, num_envs, nsteps):
@@ -561,7 +561,7 @@ def graph_kernel_trace(workload, num_envs, nsteps):
         if not dbs:
             return None, 'no rocpd database written'
         rows = sqlite3.connect(dbs[0]).execute('select name, start, end from kernels order by start').fetchall()
-        gae = [i for i, r in enumerate(rows) if 'gae_kernel' in r[0]]
+        gae = [i for i, r in enumerate(rows) if 'gae_kernel' in r[0] or 'gae_lane_kernel' in r[0]]      # one per update: the window markers
         if len(gae) < 3:
             return None, 'fewer than 3 updates in the trace'
         lo, hi = gae[-1 - child['steps']], gae[-1]          # the child's timed updates: whole updates, gae kernel to gae kernel
