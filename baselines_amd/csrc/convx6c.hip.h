@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
             for (int j = 0; j < Q::NP; ++j) X6C_LOAD1(xt, gv, 0, j)
         }
         for (int pass = 0; pass < Q::NPASS; ++pass) {
+            // the pass's first B fragments do not depend on the tile in LDS: requested ahead of the staging barriers
+            const uint16_t* bq = bl_ptr + (long)pass * Q::NTAP * 2 * 6 * 512;
+            bf16x8 fb[2][2][3];                        // [buffer][cb][pl]
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) fb[0][cb][pl] = *reinterpret_cast<const bf16x8*>(bq + (pl * 2 + cb) * 512);
             __syncthreads();                           // the previous pass's fragment reads are done
 #pragma unroll
             for (int j = 0; j < Q::NP; ++j)
@@ -168,12 +175,6 @@ __global__ __launch_bounds__(256, 2) void conv_x6c_kernel(const float* __restric
             __builtin_amdgcn_s_setprio(1);
             // units u = (tap, kb, a_): 12 MFMAs each; the raw fragment of unit u+1 is read and split between the MFMAs of unit u,
             // the B fragments of k block (tap, kb) + 1 are requested while (tap, kb) multiplies, one staging load per unit
-            const uint16_t* bq = bl_ptr + (long)pass * Q::NTAP * 2 * 6 * 512;
-            bf16x8 fb[2][2][3];                        // [buffer][cb][pl]
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) fb[0][cb][pl] = *reinterpret_cast<const bf16x8*>(bq + (pl * 2 + cb) * 512);
             bf16x8 fa[2][3];
             // raw fragments are read AHEAD units before their split (a ds_read consumed in the unit it is issued in stalls the wave's MFMA
             // stream at its wait); two units where the registers allow it (conv3's 13 staged pieces leave no room: it would spill)
