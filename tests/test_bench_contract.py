@@ -43,6 +43,15 @@ def test_committed_bench_line_has_the_contract_fields():
     assert kr['c1.fwd']['bound'] == 'hbm' and kr['c1.fwd']['peak'] == 8000.0 and abs(kr['c1.fwd']['mfma_peak_tflops'] - 2516.6 / 3) < 1e-3
     assert d['self_check']['stats_max_abs_diff'] <= 1e-5 and d['self_check']['grad_max_abs_diff_over_scale'] <= 1e-5
     assert {o['workload'].split()[0] for o in d['other_configs']} == {'ppo2', 'deepq'} and len(d['other_configs']) == 5
+    # no row prices a kernel with zero algorithmic bytes, and the recurrent row's conv sites are priced like the
+    # feed-forward row's (same engines, same pipe): its dominant kernel's fraction within 3 % of the N = 256 cnn row's
+    rows = {o['workload']: o['roofline'] for o in d['other_configs'] if o.get('roofline')}
+    for name, rf in list(rows.items()) + [('headline', r)]:
+        assert rf.get('bound') and rf.get('alg_bytes', 1.0) > 0, name
+    cnn256 = next(v for k, v in rows.items() if ' cnn num_envs=256' in k)
+    lstm256 = next(v for k, v in rows.items() if 'cnn_lstm' in k)
+    assert cnn256['kernel'] == lstm256['kernel'] and abs(cnn256['frac'] / lstm256['frac'] - 1.0) < 0.03
+    assert 'frac_vs_fp32_mfma' in r and 'frac_vs_fp32_mfma' in lstm256
     c = d['cpu_baseline']
     assert c['host_cpu_count'] >= c['cores'] and c['host_cpu_model']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
