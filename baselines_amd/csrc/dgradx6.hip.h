@@ -103,6 +103,12 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     auto stage_row = [&](int r) { return rowperm ? ((r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)) : r; };
     const int arow = stage_row(tid >> 3);
     if (dbg & 1) { hmask = nullptr; mbits = nullptr; }     // timing experiments (MRL_DGX6_DBG): 1 = no mask loads,
+    // operand registers of the next k tile live ACROSS tiles (round 5): the last k step of a tile requests the first k tile of the
+    // workgroup's next tile instead of re-reading its own (each tile used to start by waiting out a full memory latency)
+    float4 ra0[PA ? 1 : NA];
+    u32x4v rp0[PA ? 3 * NAP : 1];
+    u32x4v rb0[3 * NQ];
+    int t_pref = -1;                                       // >= 0: that k tile of the upcoming tile is already in flight
     for (long slot = blockIdx.x >> 3; slot < tiles_per_xcd; slot += slots_per_xcd) {      // 2 = no stores, 4 = no main loop
     const long lt = (long)xcd * tiles_per_xcd + slot;
     if (lt >= total_tiles) break;
@@ -154,9 +160,6 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
         while (t < G::NKT && !kvalid(t)) ++t;
         return t;
     };
-    float4 ra0[PA ? 1 : NA];
-    u32x4v rp0[PA ? 3 * NAP : 1];
-    u32x4v rb0[3 * NQ];
     auto fetch = [&](float4 (&ra)[PA ? 1 : NA], u32x4v (&rp)[PA ? 3 * NAP : 1], u32x4v (&rb)[3 * NQ], int tt) {      // tt: a VALID k tile
         const int tap = tt / G::KT_PER_TAP, kin = (tt - tap * G::KT_PER_TAP) * X6_BK;
         const int a = tap / TAPS, b2 = tap - a * TAPS;
@@ -241,16 +244,43 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     };
     uint16_t* L0 = x6s;
     int t = (dbg & 4) ? G::NKT : next_valid(0);
-    if (t < G::NKT) fetch(ra0, rp0, rb0, t);
+    if (t < G::NKT && t_pref != t) fetch(ra0, rp0, rb0, t);
+    t_pref = -1;
     while (t < G::NKT) {
         __syncthreads();                       // previous tile's fragment reads are done
         swrite(ra0, rp0, rb0, L0);
         __syncthreads();
         const int tn = next_valid(t + 1);
+        int tf = tn < G::NKT ? tn : t;         // what this step's loads fetch (past the end of the last tile: a re-read, never consumed)
+        // (measured: conv2's 128 x 128 tiles 4.98 -> 4.65 ms; conv3's 256 x 64 tiles, 18 k steps per tile, 3.04 -> 3.13 with 6 spilled registers: off there)
+        if constexpr (!PA && NTN == 1 && WM == 2) {
+            if (tn >= G::NKT) {                // last k step of the tile: its loads fetch the next tile's first valid k tile
+                const long slot2 = slot + slots_per_xcd, lt2 = (long)xcd * tiles_per_xcd + slot2;
+                if (slot2 < tiles_per_xcd && lt2 < total_tiles) {
+                    const int pos2 = (int)(lt2 % G::NPOS), bt2 = (int)(lt2 / G::NPOS);
+                    const int yy2 = pos2 / G::WX, xx2 = pos2 - yy2 * G::WX;
+                    int t2 = 0;
+                    while (t2 < G::NKT) {
+                        const int tap = t2 / G::KT_PER_TAP, a = tap / TAPS, b2 = tap - a * TAPS;
+                        if ((unsigned)(yy2 - a) < (unsigned)OH && (unsigned)(xx2 - b2) < (unsigned)OW) break;
+                        ++t2;
+                    }
+                    if (t2 < G::NKT) {
+                        // (the current tile's row pointers are dead from here on: every k tile of it has been requested)
+#pragma unroll
+                        for (int p = 0; p < NA; ++p) {
+                            const int b = min(bt2 * BM + p * 32 + arow, B - 1);
+                            ap[p] = dz + ((long)(b * OH + yy2) * OW + xx2) * NF + (tid & 7) * 4;
+                        }
+                        tf = t2;
+                        t_pref = t2;
+                    }
+                }
+            }
+        }
         if constexpr (IL) {
             constexpr int NL = (PA ? 3 * NAP : NA) + 3 * NQ;
             static_assert(2 * NL <= 32, "two MFMAs per load inside the first half of the block");
-            const int tf = tn < G::NKT ? tn : t;
             __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             fetch(ra0, rp0, rb0, tf);
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
             t = tn;
             continue;
         }
-        fetch(ra0, rp0, rb0, tn < G::NKT ? tn : t);  // next valid tile in flight during the MFMA block (past the end: re-read, never consumed)
+        fetch(ra0, rp0, rb0, tf);                    // next valid tile (or the next TILE's first one) in flight during the MFMA block
         __builtin_amdgcn_sched_barrier(0);
         if (prio) __builtin_amdgcn_s_setprio(1);     // the MFMA stream outranks the co-resident workgroup's staging VALU
         mfma_block(L0);
