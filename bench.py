@@ -318,23 +318,31 @@ def dp_verify(model, ro, T, N, hp, world, rank, comm):
            'ways': 'plain = local gradients (communicator detached) + torch.distributed all-reduce; overlapped = in-library '
                    'two-slice all-reduce inside the backward pass; recompute = rank 0 runs every rank\'s gathered minibatch itself'}
     res = torch.zeros(4, dtype=torch.float64, device=dev)                 # rank 0 fills it, everybody learns the verdict
+    rank0_error = None
     if rank == 0:
-        if native:
-            dm.attach_comm(None)
-        single = torch.zeros(P, dtype=torch.float32, device=dev)
-        own_identical = None
-        for r in range(world):
-            g_r = grad(*[e[r] for e in everyones], None, 1, 1)
-            if r == 0:
-                own_identical = bool(torch.equal(g_r, local))
-            single += w * g_r                                             # bench ranks all carry weight 1 (mpi_rank_weight default)
-        if native:
-            dm.attach_comm(comm.native, w)
-        scale = float(plain.abs().max())
-        res[0] = scale
-        res[1] = float((single - plain).abs().max()) / scale
-        res[2] = float((overl - plain).abs().max()) / scale if overl is not None else -1.0
-        res[3] = (1.0 if own_identical else 0.0) + (2.0 if (overl is not None and torch.equal(overl, plain)) else 0.0)
+        # the only asymmetric part of the check: whatever goes wrong here must still reach the broadcast below, or the other
+        # ranks would wait in it until the collective timeout
+        try:
+            if native:
+                dm.attach_comm(None)
+            single = torch.zeros(P, dtype=torch.float32, device=dev)
+            own_identical = None
+            for r in range(world):
+                g_r = grad(*[e[r] for e in everyones], None, 1, 1)
+                if r == 0:
+                    own_identical = bool(torch.equal(g_r, local))
+                single += w * g_r                                         # bench ranks all carry weight 1 (mpi_rank_weight default)
+            scale = float(plain.abs().max())
+            res[0] = scale
+            res[1] = float((single - plain).abs().max()) / scale
+            res[2] = float((overl - plain).abs().max()) / scale if overl is not None else -1.0
+            res[3] = (1.0 if own_identical else 0.0) + (2.0 if (overl is not None and torch.equal(overl, plain)) else 0.0)
+        except Exception as exc:
+            rank0_error = repr(exc)
+            res = torch.tensor([0.0, 1e30, 1e30 if native else -1.0, 0.0], dtype=torch.float64, device=dev)    # finite: the line stays JSON
+        finally:
+            if native:
+                dm.attach_comm(comm.native, w)
     dist.broadcast(res, 0)
     r_ = [float(x) for x in res.cpu()]
     out.update({'grad_scale': r_[0], 'recompute_vs_plain_max_abs_diff_over_scale': r_[1],
@@ -343,6 +351,8 @@ def dp_verify(model, ro, T, N, hp, world, rank, comm):
                 'overlapped_bit_identical_to_plain': (bool(int(r_[3]) & 2) if r_[2] >= 0 else None),
                 'rank0_gathered_rows_reproduce_its_indexed_gradient_bitwise': bool(int(r_[3]) & 1),
                 'max_abs_diff_over_scale': max(r_[1], r_[2] if r_[2] >= 0 else 0.0)})
+    if rank0_error:
+        out['rank0_error'] = rank0_error
     if not native:
         out['note'] = 'in-library communicator not in use (%s): the overlapped path was not exercised' % (
             getattr(comm, 'native_error', None) or dist.get_backend())
