@@ -450,10 +450,20 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
             dp_check['ok'] = bool(dp_check['max_abs_diff_over_scale'] <= 1e-6)
         except Exception as exc:                      # reported, never silently dropped
             dp_check = {'ok': False, 'error': repr(exc)}
+            if model.native_dp:                       # the check detaches the communicator in places: leave it as the timed region expects
+                model.dm.attach_comm(comm.native, float(model.mpi_rank_weight))
         if not dp_check['ok']:
             sys.stderr.write('bench.py: data-parallel gradient self-check FAILED: %s\n' % json.dumps(dp_check))
             if os.environ.get('MRL_BENCH_DP_STRICT', '0') == '1':
                 raise SystemExit(3)
+            # the overlapped in-library all-reduce disagreed while the plain one matches rank 0's recomputation: time the plain path
+            # (same verdict on every rank -- it was broadcast -- so every rank takes this branch or none does)
+            if (model.native_dp and dp_check.get('overlapped_equals_plain') is False
+                    and dp_check.get('recompute_vs_plain_max_abs_diff_over_scale', 1.0) <= 1e-6):
+                model.dm.attach_comm(None)
+                model.native_dp = False
+                dp_check['fallback'] = ('overlapped path rejected: the timed region all-reduces with torch.distributed after the '
+                                        'backward pass (Model._apply_gradients)')
 
     def update():
         """the PPO2 update (ppo2.py:142 GAE part + :154-166)"""
@@ -831,6 +841,9 @@ def main():
             out['params_synced_across_ranks'] = res.get('params_synced')
             out['dp_verify'] = res.get('dp_verify')
             out['config']['native_dp'] = res.get('native_dp')
+            if (res.get('dp_verify') or {}).get('fallback'):
+                out['config']['collective'] = ('torch.distributed all_reduce (%s), after the backward pass [in-library overlapped path '
+                                               'rejected by dp_verify]' % backend)
         if res['graph_mode']:
             out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps)'
             out['kernel_times_source'] = res.get('kernel_times_source')
