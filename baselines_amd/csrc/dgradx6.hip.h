@@ -62,6 +62,16 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
     }
 }
 
+// destination of block (a_, b_) of this lane in the transposed epilogue: element offset off_, validity ok_, first channel c0_
+#define DGX6_EPI_ADDR(a_, b_, off_, ok_, c0_)                                                                  \
+    const int cb_ = n0 + (wn * 2 + (b_)) * 32;                                                                 \
+    const int cls_ = cb_ / C, c0_ = cb_ - cls_ * C;                                                            \
+    const int py_ = cls_ / S, px_ = cls_ - py_ * S;                                                            \
+    const int iy_ = yy * S + py_, ix_ = xx * S + px_;                                                          \
+    const int bimg_ = b0 + (wm * 2 + (a_)) * 32 + i;                                                           \
+    const bool ok_ = cb_ < G::N && iy_ < H && ix_ < W && bimg_ < B;                                            \
+    const long off_ = ok_ ? (long)bimg_ * (H * W * C) + ((long)iy_ * W + ix_) * C + c0_ : 0L;
+
 // PA: dz comes as a plane tensor (dzp = plane 0, dz_ps elements between planes; Bp laid out with kperm): staging without
 //     split arithmetic.  TR: MFMA operands swapped, a lane owns one image and 16 channels of a destination pixel: the
 //     epilogue reads ONE mask word per 32 channels and writes fp32 + the plane tensor of dx with 16-byte stores
@@ -243,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
         }
     };
     uint16_t* L0 = x6s;
+    // TR + bit masks: the four mask words of the epilogue are requested during the tile's last k step (they used to be the first thing
+    // the epilogue waited for)
+    uint32_t mw00 = 0, mw01 = 0, mw10 = 0, mw11 = 0;
+    bool mw_done = false;
     int t = (dbg & 4) ? G::NKT : next_valid(0);
     if (t < G::NKT && t_pref != t) fetch(ra0, rp0, rb0, t);
     t_pref = -1;
@@ -276,6 +290,15 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
                         t_pref = t2;
                     }
                 }
+            }
+        }
+        if constexpr (TR) {
+            if (tn >= G::NKT && mbits && !(dbg & 2)) {
+                { DGX6_EPI_ADDR(0, 0, o_, k_, c_) mw00 = k_ ? mbits[o_ >> 5] : 0u; (void)c_; }
+                { DGX6_EPI_ADDR(0, 1, o_, k_, c_) mw01 = k_ ? mbits[o_ >> 5] : 0u; (void)c_; }
+                { DGX6_EPI_ADDR(1, 0, o_, k_, c_) mw10 = k_ ? mbits[o_ >> 5] : 0u; (void)c_; }
+                { DGX6_EPI_ADDR(1, 1, o_, k_, c_) mw11 = k_ ? mbits[o_ >> 5] : 0u; (void)c_; }
+                mw_done = true;
             }
         }
         if constexpr (IL) {
@@ -317,27 +340,40 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     // epilogue: column (class, c) of row (image, position) -> its destination pixel, masked by act'(h) of the layer below
     if constexpr (TR) {
         // transposed accumulators: lane (i, h) owns image b0 + .. + i and channels 8g + 4h + j of one destination pixel
-        const TrMaskRelu ef{dx, 0, hmask, mbits, dxp, dx_ps};
-        TrAux aux[2][2];
-        long oo[2][2];
-        bool vv[2][2];
+        const float sgn = (!PA && (dither & 1) && (i & 8)) ? -1.f : 1.f;
+        if (mbits) {
+            // bit-mask path: one mask word per block -- in flight since the last k step (mw_done), or requested here; no fp32 mask values
+            const TrMaskRelu ef{dx, 0, nullptr, mbits, dxp, dx_ps};
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int cb = n0 + (wn * 2 + b) * 32;
-                const int cls = cb / C, c0 = cb - cls * C;
-                const int py = cls / S, px = cls - py * S;
-                const int iy = yy * S + py, ix = xx * S + px;
-                const int bimg = b0 + (wm * 2 + a) * 32 + i;
-                vv[a][b] = cb < G::N && iy < H && ix < W && bimg < B && (!(dbg & 2) || acc[a][b][0] == 12345.678f);   // dbg 2: no epilogue memory traffic
-                oo[a][b] = vv[a][b] ? (long)bimg * (H * W * C) + ((long)iy * W + ix) * C + c0 : 0L;
-                aux[a][b] = ef.load_aux(oo[a][b], c0, h, vv[a][b]);
-            }
+                for (int b = 0; b < 2; ++b) {
+                    DGX6_EPI_ADDR(a, b, o_, k_, c_)
+                    (void)c_;
+                    const bool kk_ = k_ && (!(dbg & 2) || acc[a][b][0] == 12345.678f);   // dbg 2: no epilogue memory traffic
+                    TrAux x;
+                    x.w = mw_done ? (a ? (b ? mw11 : mw10) : (b ? mw01 : mw00)) : (kk_ ? mbits[o_ >> 5] : 0u);
+                    tr_block_epilogue(ef, acc[a][b], x, kk_ ? o_ : 0L, h, kk_, sgn);
+                }
+        } else {
+            const TrMaskRelu ef{dx, 0, hmask, mbits, dxp, dx_ps};
+            TrAux aux[2][2];
+            long oo[2][2];
+            bool vv[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b], (!PA && (dither & 1) && (i & 8)) ? -1.f : 1.f);
+                for (int b = 0; b < 2; ++b) {
+                    DGX6_EPI_ADDR(a, b, o_, k_, c_)
+                    vv[a][b] = k_ && (!(dbg & 2) || acc[a][b][0] == 12345.678f);   // dbg 2: no epilogue memory traffic
+                    oo[a][b] = vv[a][b] ? o_ : 0L;
+                    aux[a][b] = ef.load_aux(oo[a][b], c_, h, vv[a][b]);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) tr_block_epilogue(ef, acc[a][b], aux[a][b], oo[a][b], h, vv[a][b], sgn);
+        }
     } else {
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!PA && (dither & 1)) {                   // registers with r & 4 hold the images 8..15, 24..31 that were staged negated

@@ -402,7 +402,7 @@ struct OptionDef { const char* name; const char* env; int dflt; };
 static const OptionDef kOptions[] = {
     // ---- product options (include/mrl.h)
     {"u8_bf16x3", "MRL_U8_BF16X3", 1}, {"f32_bf16x6", "MRL_F32_BF16X6", 2}, {"mlp_fused", "MRL_MLP_FUSED", 1},
-    {"heads_wave", "MRL_HEADS_WAVE", 1}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 1},
+    {"heads_wave", "MRL_HEADS_WAVE", 2}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 1},
     {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 4},
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
@@ -1158,6 +1158,199 @@ __global__ __launch_bounds__(256) void heads_train_wave_kernel(HeadArgs a) {
         for (int q = 0; q < KPL / 4; ++q) dst[q] = make_float4(g[q * 4], g[q * 4 + 1], g[q * 4 + 2], g[q * 4 + 3]);
     }
     // ---- combine the 4 waves of the block in fixed order -> one partial slab per block (layout of heads_train_kernel)
+    float* mine = smem + (long)wave * a.HP;
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+        const int k = lane * KPL + kk;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (j < nact) mine[k * nact + j] = gW[kk][j];
+        mine[nlat * nact + nact + k] = gWv[kk];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (j < nact) mine[nlat * nact + j] = gb[j];
+        mine[nlat * nact + nact + nlat] = gbv;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sst[wave][j] = st[j];
+    }
+    __syncthreads();
+    for (int e = tid; e < a.HP; e += 256)
+        a.hpart[(long)blockIdx.x * a.HP + e] = ((smem[e] + smem[a.HP + e]) + smem[2 * a.HP + e]) + smem[3 * a.HP + e];
+    if (tid < 5) a.spart[blockIdx.x * 5 + tid] = ((sst[0][tid] + sst[1][tid]) + sst[2][tid]) + sst[3][tid];
+}
+
+// ---- two samples per wave-step (round 5, `heads_wave` = 2): same per-sample arithmetic, same summation orders -- bit-identical to
+// heads_train_wave_kernel -- but a wave-step takes the wave's next TWO samples (b and b + nwaves: the same samples, in the same order,
+// the one-sample kernel gives this wave).  The first butterfly step leaves sample A's partial sums in lanes 0..31 and sample B's in
+// lanes 32..63, so the remaining five steps reduce both samples at once and the per-sample loss algebra -- which every lane of the
+// one-sample kernel evaluates redundantly -- is evaluated ONCE for both (lane half = sample).  The per-sample scalars every lane needs
+// afterwards (dpi, dv, the five statistics) come back as wave-uniform values (v_readlane of lane 0 / lane 32) and multiply as scalar
+// operands.  Two independent dependency chains per wave also hide each other's latencies (the kernel runs two waves per SIMD).
+template <int KPL, int NA>
+__global__ __launch_bounds__(256) void heads_train_wave2_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][HP] head-gradient partials
+    __shared__ double sst[4][5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool hiB = lane >= 32;                                     // this lane evaluates sample B's algebra
+    const int nact = a.nact, nlat = a.nlat;
+    float W[KPL][NA], Wv[KPL], gW[KPL][NA], gWv[KPL], gb[NA], gbv = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+        const int k = lane * KPL + kk;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            W[kk][j] = j < nact ? a.Wpi[k * nact + j] : 0.f;
+            gW[kk][j] = 0.f;
+        }
+        Wv[kk] = a.Wvf[k];
+        gWv[kk] = 0.f;
+    }
+    float bpi[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { bpi[j] = j < nact ? a.bpi[j] : 0.f; gb[j] = 0.f; }
+    const float bv = a.bvf[0];
+    double st[5] = {0, 0, 0, 0, 0};
+    const float mean = a.advstat[0], sd = a.advstat[1] + 1e-8f;
+    const float eps = a.cliprange;
+    const float ce = a.ent_coef * a.invB;
+    const int nwaves = gridDim.x * 4;
+    auto bcast = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+    for (int b = blockIdx.x * 4 + wave; b < a.Bc; b += 2 * nwaves) {
+        const bool hasB = b + nwaves < a.Bc;                         // wave-uniform
+        const int b2 = hasB ? b + nwaves : b;
+        float xA[KPL], xB[KPL];
+        {
+            const float4* sA = reinterpret_cast<const float4*>(a.lat + (long)b * nlat + lane * KPL);
+            const float4* sB = reinterpret_cast<const float4*>(a.lat + (long)b2 * nlat + lane * KPL);
+#pragma unroll
+            for (int q = 0; q < KPL / 4; ++q) {
+                const float4 u = sA[q], w = sB[q];
+                xA[q * 4 + 0] = u.x; xA[q * 4 + 1] = u.y; xA[q * 4 + 2] = u.z; xA[q * 4 + 3] = u.w;
+                xB[q * 4 + 0] = w.x; xB[q * 4 + 1] = w.y; xB[q * 4 + 2] = w.z; xB[q * 4 + 3] = w.w;
+            }
+        }
+        const int bm = hiB ? b2 : b;                                 // the sample this lane's algebra belongs to
+        const long r = a.idx ? envmajor_to_row(a.idx[bm], a.T, a.N) : a.row0 + bm;
+        const float R = a.returns[r], oldv = a.values[r], oldnlp = a.neglogp[r];
+        const int act = static_cast<const int32_t*>(a.actions)[r];
+        float pi[NA], v;
+        {
+            float pA[NA], pB[NA], vA = 0.f, vB = 0.f;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                float t = 0.f, u = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KPL; ++kk) { t = fmaf(xA[kk], W[kk][j], t); u = fmaf(xB[kk], W[kk][j], u); }
+                pA[j] = t; pB[j] = u;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) { vA = fmaf(xA[kk], Wv[kk], vA); vB = fmaf(xB[kk], Wv[kk], vB); }
+            // butterfly step 32 for both samples: lane l < 32 ends with A_l + A_{l+32}, lane l >= 32 with B_l + B_{l-32} -- the sums the
+            // one-sample kernel's first step forms (own + partner, fp addition commutes)
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                if (j < nact) pi[j] = (hiB ? pB[j] : pA[j]) + __shfl_xor(hiB ? pA[j] : pB[j], 32);
+                else pi[j] = 0.f;
+            v = (hiB ? vB : vA) + __shfl_xor(hiB ? vA : vB, 32);
+        }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                if (j < nact) pi[j] += __shfl_xor(pi[j], off);
+            v += __shfl_xor(v, off);
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) pi[j] += bpi[j];
+        v += bv;
+        // ---- per-sample loss algebra (formulas and evaluation order of heads_train_wave_kernel), once per lane half
+        const float adv = ((R - oldv) - mean) / sd;
+        float mx = pi[0];
+#pragma unroll
+        for (int j = 1; j < NA; ++j) if (j < nact) mx = fmaxf(mx, pi[j]);
+        float z0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) if (j < nact) z0 += expf(pi[j] - mx);
+        const float logz = logf(z0);
+        float pact = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) if (j == act) pact = pi[j];
+        const float nlp = logz - (pact - mx);
+        float H = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (j < nact) {
+                const float a0 = pi[j] - mx;
+                H += (expf(a0) / z0) * (logz - a0);
+            }
+        const float ratio = expf(oldnlp - nlp);
+        const float pg1 = -adv * ratio;
+        const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+        const float pg2 = -adv * rc;
+        const float dr = (pg1 >= pg2) ? -adv : ((ratio >= 1.f - eps && ratio <= 1.f + eps) ? -adv : 0.f);
+        const float dnlp = dr * (-ratio) * a.invB;
+        float dpi[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            dpi[j] = 0.f;
+            if (j < nact) {
+                const float a0 = pi[j] - mx;
+                const float p = expf(a0) / z0;
+                const float logp = a0 - logz;
+                dpi[j] = dnlp * (p - (j == act ? 1.f : 0.f)) + ce * p * (logp + H);
+            }
+        }
+        const float dvc = fminf(fmaxf(v - oldv, -eps), eps);
+        const float vclip = oldv + dvc;
+        const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+        const float dl = (l1 >= l2) ? (v - R) : ((v - oldv >= -eps && v - oldv <= eps) ? (vclip - R) : 0.f);
+        const float dv = a.vf_coef * a.invB * dl;
+        const float s0 = fmaxf(pg1, pg2), s1 = fmaxf(l1, l2), s3 = (nlp - oldnlp) * (nlp - oldnlp);
+        const float s4 = (fabsf(ratio - 1.f) > eps) ? 1.f : 0.f;
+        // ---- statistics in the one-sample kernel's order: sample A, then sample B
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !hasB) continue;
+            const int src = half * 32;
+            st[0] += (double)bcast(s0, src);
+            st[1] += 0.5 * (double)bcast(s1, src);
+            st[2] += (double)bcast(H, src);
+            st[3] += 0.5 * (double)bcast(s3, src);
+            st[4] += (double)bcast(s4, src);
+        }
+        // ---- dz of the latent layer (masked by act') and this lane's slice of the head gradients: sample A, then sample B
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !hasB) continue;
+            const int src = half * 32;
+            float d[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) d[j] = bcast(dpi[j], src);
+            const float dvs = bcast(dv, src);
+            float g[KPL];
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) {
+                const float xk = half ? xB[kk] : xA[kk];
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) t = fmaf(d[j], W[kk][j], t);
+                t = fmaf(dvs, Wv[kk], t);
+                g[kk] = t * act_bwd_from_out(xk, a.lat_act);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) gW[kk][j] = fmaf(xk, d[j], gW[kk][j]);
+                gWv[kk] = fmaf(xk, dvs, gWv[kk]);
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) gb[j] += d[j];
+            gbv += dvs;
+            float4* dst = reinterpret_cast<float4*>(a.dz_pi + (long)(half ? b2 : b) * nlat + lane * KPL);
+#pragma unroll
+            for (int q = 0; q < KPL / 4; ++q) dst[q] = make_float4(g[q * 4], g[q * 4 + 1], g[q * 4 + 2], g[q * 4 + 3]);
+        }
+    }
+    // ---- combine the 4 waves of the block in fixed order -> one partial slab per block (as heads_train_wave_kernel)
     float* mine = smem + (long)wave * a.HP;
 #pragma unroll
     for (int kk = 0; kk < KPL; ++kk) {
@@ -2353,7 +2546,7 @@ static int model_act_impl(const mrl_model* m, const float* params, const void* o
         }
         ProfScope ps("heads_act", 0.0, (double)Bc * (4.0 * a.nlat + (a.shared ? 0 : 4.0 * a.nlatv) + 16.0), st);
         const bool wave_ok = a.has_pi_head && a.shared && a.pd_kind == MRL_PD_CATEGORICAL && a.nact <= 8 && a.nlat == 512 &&
-                             (uintptr_t)a.lat % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 1);
+                             (uintptr_t)a.lat % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 2);
         if (wave_ok)       // one wave per sample, up to 8 samples per wave
             hipLaunchKernelGGL(heads_act_wave_kernel<8>, dim3(std::max(1, std::min((Bc + 3) / 4, 2048))), dim3(256), 0, st, a);
         else
@@ -2554,7 +2747,7 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         // wave-per-sample kernel for the NatureCNN head shape (Categorical <= 8 actions, shared 512-wide latent)
         const bool wave_ok = a.has_pi_head && a.shared && a.pd_kind == MRL_PD_CATEGORICAL && a.nact <= 8 && a.nlat == 512 &&
                              m->HP == a.nlat * a.nact + a.nact + a.nlat + 1 && (uintptr_t)a.lat % 16 == 0 &&
-                             (uintptr_t)a.dz_pi % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 1);
+                             (uintptr_t)a.dz_pi % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 2);
         if (wave_ok) nblk = std::min((Bc + 31) / 32, HEAD_MAXBLK);       // >= 8 samples per wave
         {
             // algorithmic traffic: latent in, dz out, per-sample rollout scalars
@@ -2568,7 +2761,18 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
                     if (e != hipSuccess) return (int)e;
                     raised = true;
                 }
-                hipLaunchKernelGGL(heads_train_wave_kernel<8>, dim3(nblk), dim3(256), wl, st, a);
+                if (a.nact <= 6 && get_option("heads_wave", "MRL_HEADS_WAVE", 2) >= 2) {
+                    static bool raised2 = false;
+                    if (!raised2 && wl > 64 * 1024) {
+                        hipError_t e = hipFuncSetAttribute((const void*)heads_train_wave2_kernel<8, 6>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        if (e != hipSuccess) return (int)e;
+                        raised2 = true;
+                    }
+                    hipLaunchKernelGGL((heads_train_wave2_kernel<8, 6>), dim3(nblk), dim3(256), wl, st, a);
+                } else {
+                    hipLaunchKernelGGL(heads_train_wave_kernel<8>, dim3(nblk), dim3(256), wl, st, a);
+                }
             } else {
                 hipLaunchKernelGGL(heads_train_kernel, dim3(nblk), dim3(256), lds, st, a);
             }

@@ -451,7 +451,8 @@ int mrl_tune_set(const char* label, int variant);
  *   "mlp_waves"   [MRL_MLP_WAVES, 8]  waves per workgroup of that kernel (8 | 4)
  *   "mlp_slice"   [MRL_MLP_SLICE, 1]  separate policy / value nets: one workgroup per (32-sample tile, net) instead of one per
  *                  tile -- half the serial chain per workgroup, 256 instead of 128 workgroups for a 4096-sample minibatch
- *   "heads_wave"  [MRL_HEADS_WAVE, 1]  wave-per-sample loss / head-gradient kernel for the NatureCNN head shape; 0 = generic
+ *   "heads_wave"  [MRL_HEADS_WAVE, 2]  loss / head-gradient kernel for the NatureCNN head shape: 2 = two samples per wave-step (lane half =
+ *                  sample for the loss algebra; <= 6 actions, else as 1), 1 = one sample per wave-step (bit-identical), 0 = generic tile kernel
  * Builds with -DMRL_X6_EXPERIMENTS (MRL_BUILD_DEFINES, csrc/build.py) add the measured-and-dropped variants that
  * profiles/README.md and scripts/ab_options.py refer to ("act_planes", "x6_il", "x6_spec", "*_dbg", ...); they are not part of
  * the product library.  Returns MRL_EINVAL for unknown names.  mrl_get_option reports the value in effect. */

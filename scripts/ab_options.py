@@ -53,6 +53,9 @@ def measure(tag):
     r = _lib.prof_report()
     tot = sum(v['ms'] for v in r.values()) / 2
     keys = ['c1.fwd', 'c2.fwd', 'c3.fwd', 'fc1.fwd', 'fc1.dgrad', 'c3.dgrad', 'c2.dgrad', 'c1.wgrad', 'c2.wgrad', 'c3.wgrad', 'fc1.wgrad', 'heads_loss']
+    import hashlib
+    sha = hashlib.sha1(grads.cpu().numpy().tobytes() + stats.cpu().numpy().tobytes()).hexdigest()[:12]     # same bits <=> same digest (builds / options)
+    print('%-22s grad+stats sha1 %s' % (tag, sha))
     print('%-22s epoch %.2f ms | ' % (tag, tot) + ' '.join('%s %.2f' % (k, r[k]['ms'] / r[k]['count']) for k in keys), flush=True)
 
 

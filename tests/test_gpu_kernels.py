@@ -335,7 +335,7 @@ def test_engine_options_agree():
         return g.cpu().numpy(), st.cpu().numpy()
 
     names = ['u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'tr_epilogue',
-             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c', 'wgrad_pipe']
+             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c', 'wgrad_pipe', 'heads_wave']
     # builds with -DMRL_X6_EXPERIMENTS also carry the measured-and-dropped variants (plane tensors, separate load phase)
     experiments = True
     try:
@@ -352,6 +352,7 @@ def test_engine_options_agree():
     assert defaults['wgrad_pipe'] == 1, 'conv2 / conv3 weight gradients: next image split between the MFMAs of the current one by default'
     assert defaults['conv_x6c'] == 1, 'conv2 / conv3 forward at minibatch sizes: class-resident kernel by default'
     assert defaults['x6_frag'] == 1, 'tiled split engines: operand split on the fragment path, between the MFMAs, by default'
+    assert defaults['heads_wave'] == 2, 'loss / head gradients of the NatureCNN head shape: two samples per wave-step by default'
     if experiments:
         assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
     try:
@@ -373,6 +374,17 @@ def test_engine_options_agree():
             scale = np.abs(g0).max()
             assert np.abs(g1 - g0).max() <= 2e-6 * scale + 1e-9, (opt, np.abs(g1 - g0).max(), scale)
             np.testing.assert_allclose(s1, s0, rtol=1e-5, atol=1e-6)
+        # the two-samples-per-wave-step loss kernel evaluates the same formulas on the same sums in the same orders as the one-sample
+        # kernel: gradient and statistics BIT-identical, for odd batch sizes and waves whose last step holds one sample as well
+        for B in (161, 165, 168, 33, 97):
+            scr_s = (om_s, None, {k: v[:B] for k, v in mb_s.items()})
+            g2, s2 = grads(*cnn, B, dict(defaults, heads_wave=2), scr_s)
+            g1, s1 = grads(*cnn, B, dict(defaults, heads_wave=1), scr_s)
+            np.testing.assert_array_equal(g2, g1, err_msg='heads_wave B=%d' % B)
+            np.testing.assert_array_equal(s2, s1, err_msg='heads_wave B=%d' % B)
+            g0, s0 = grads(*cnn, B, dict(defaults, heads_wave=0), scr_s)             # generic tile kernel
+            assert np.abs(g2 - g0).max() <= 2e-6 * np.abs(g0).max() + 1e-9
+            np.testing.assert_allclose(s2, s0, rtol=1e-5, atol=1e-6)
         # ---- B = 1152 (tiled split engines everywhere they apply), screened minibatch: every entry
         B = 1152
         scr = _problem(B, 21)
@@ -398,6 +410,7 @@ def test_engine_options_agree():
                  ('split engines, split on the fragment path, natural k order, no sign alternation', dict(defaults, x6_frag=5, x6_dither=2, conv_x6c=0), 3e-6),
                  ('split engines, split on the fragment path, two register sets of operand loads', dict(defaults, x6_frag=2, conv_x6c=0), 3e-6),
                  ('split engines, conv weight gradients with a split phase of its own (no software pipeline)', dict(defaults, wgrad_pipe=0), 3e-6),
+                 ('split engines, loss / head gradients one sample per wave-step', dict(defaults, heads_wave=1), 3e-6),
                  ('split engines, class-resident conv forward without the sign alternation', dict(defaults, x6_dither=2), 3e-6),
                  ('split engines, tiled conv forward in class-major k order without the sign alternation', dict(defaults, x6_dither=2, conv_x6c=0), 3e-6),
                  ('split engines, first conv layer on the gather engine instead of the image-resident one', dict(defaults, c1_lds=0), 3e-6),
@@ -438,7 +451,8 @@ def test_engine_options_agree():
                      ('split engines, class-resident conv forward without the sign alternation',
                       'split engines, tiled conv forward in class-major k order without the sign alternation'),
                      # the pipelined weight gradients split the same values and multiply in the same order
-                     ('split engines (default)', 'split engines, conv weight gradients with a split phase of its own (no software pipeline)')):
+                     ('split engines (default)', 'split engines, conv weight gradients with a split phase of its own (no software pipeline)'),
+                     ('split engines (default)', 'split engines, loss / head gradients one sample per wave-step')):
             np.testing.assert_array_equal(by_name[a][0], by_name[b][0], err_msg=b)
             np.testing.assert_array_equal(by_name[a][1], by_name[b][1], err_msg=b)
     finally:
