@@ -850,13 +850,28 @@ def main():
         }
         if res.get('self_check'):
             out['self_check'] = res['self_check']
+            # a compact copy inside `config`: the driver's record keeps `config` and `roofline` whole and only the NAMES of other keys
+            sc = res['self_check']
+            out['config']['self_check'] = {k: sc[k] for k in ('stats_max_abs_diff', 'grad_max_abs_diff_over_scale',
+                                                              'entries_above_1e-5_of_scale', 'unexplained_entries') if k in sc}
+        if res.get('device_state'):
+            out['config']['device_state'] = {k: res['device_state'].get(k) for k in ('sclk_mhz_median', 'socket_power_w_median')
+                                             if k in res['device_state']}
         if world > 1:
             out['params_synced_across_ranks'] = res.get('params_synced')
             out['dp_verify'] = res.get('dp_verify')
             out['config']['native_dp'] = res.get('native_dp')
-            if (res.get('dp_verify') or {}).get('fallback'):
+            dpv = res.get('dp_verify') or {}
+            if dpv.get('fallback'):
                 out['config']['collective'] = ('torch.distributed all_reduce (%s), after the backward pass [in-library overlapped path '
-                                               'rejected by dp_verify]' % backend)
+                                               'REJECTED by dp_verify]' % backend)
+            # impossible to misread: which collective the timed region ran and whether the gradient it
+            # produced was verified, at the top level next to `value` and inside `config`
+            out['collective'] = ('torch.distributed (overlapped path REJECTED)' if dpv.get('fallback') else
+                                 'in-library RCCL, overlapped with the backward pass' if res.get('native_dp') else
+                                 'torch.distributed (%s), after the backward pass' % backend)
+            out['dp_verify_ok'] = bool(dpv.get('ok')) if dpv else None
+            out['config']['dp_verify_ok'] = out['dp_verify_ok']
         if res['graph_mode']:
             out['config']['launch'] = 'one replayed hipGraph per epoch (32 minibatch steps)'
             out['kernel_times_source'] = res.get('kernel_times_source')

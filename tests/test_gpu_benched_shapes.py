@@ -379,3 +379,32 @@ def test_config3_whole_update_vs_oracle_step_by_step():
     assert max(clipfrac) > 0.0                         # the policy moved: ratios != 1, the clip is active in later epochs
     for k in range(step):
         assert drift_d[k] <= max(5e-6, 2.0 * drift_o[k]), (k, drift_d, drift_o)
+
+
+def test_config3_update_teacher_forced():
+    """Per-step EVALUATION error of the device update, separated from trajectory drift.
+    Before each of the 16 minibatch steps of a config-3 update the device parameters AND Adam slots are overwritten with the
+    fp64 teacher's, rounded to fp32 (the teacher continues from the same rounded state: tests/_teacher_forced.py), so every
+    step starts from bit-identical state and what is compared is one step's own arithmetic (ppo2/model.py:57-91 loss,
+    :97-114 clip + Adam, :133-158 train).  Bars, with NO allowance for the fp32 restatement's own error: the 5 statistics
+    within 5e-7 * (1 + |s|) of fp64, the post-step parameters within 1e-6.  Measured (profiles/r06a_teacher_forced_modes.txt):
+    statistics <= 4.4e-8 * (1 + |s|) -- one ulp of the fp32 word they are returned in; the fp32 CPU restatement: 5.8e-8 --,
+    parameters <= 4.8e-7 at the first step (m = v = 0: Adam's step is g / (|g| + eps), sensitivity 1 / eps = 1e5 to an entry's
+    gradient) and <= 2.3e-7 afterwards (the restatement: 2.0e-7 / 1.6e-7).  The free-running test above therefore measures
+    trajectory drift, not evaluation error."""
+    from tests import _teacher_forced as TF
+    model, ro = TF.make_model_and_rollout()
+    traj = TF.teacher_trajectory(model, ro)
+    res = TF.device_teacher_forced(model, ro, traj)
+    er = TF.errors(traj, res)
+    assert len(er) == 16
+    report(test='config3_update_teacher_forced', steps=len(er),
+           stat_err_over_1_plus_abs_per_step=[e['stat_err'].tolist() for e in er],
+           fp32_oracle_stat_err_over_1_plus_abs_per_step=[e['stat_err_fp32'].tolist() for e in er],
+           max_param_abs_diff_vs_fp64_after_each_step=[e['param_err'] for e in er],
+           fp32_oracle_max_param_abs_diff_vs_fp64_after_each_step=[e['param_err_fp32'] for e in er],
+           clipfrac_per_step=[float(r['s64'][4]) for r in traj])
+    assert max(float(r['s64'][4]) for r in traj) > 0.0            # the policy moved: the clip is active in later epochs
+    for k, e in enumerate(er):
+        assert (e['stat_err'] <= 5e-7).all(), ('step %d' % k, e['stat_err'].tolist(), res[k]['stats'].tolist(), traj[k]['s64'].tolist())
+        assert e['param_err'] <= 1e-6, ('step %d' % k, e['param_err'], e['param_err_fp32'])
