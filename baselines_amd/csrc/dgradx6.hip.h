@@ -26,6 +26,8 @@
 
 namespace mrl {
 
+inline int& dgrad_x6_pipe() { static int p = 1; return p; }      // mrl_set_option "dgrad_x6" = 2: dgrad_x6p_kernel (round 6)
+
 template <int H, int W, int C, int RF, int S, int NF>
 struct DgX6Geom {
     static constexpr int OH = (H - RF) / S + 1, OW = (W - RF) / S + 1;
@@ -423,6 +425,263 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6_kernel(const float* __restric
     }
 }
 
+// ---- round 6: the product form with its output stores OFF the critical path ------------------------------------------------
+// What the ISA of dgrad_x6_kernel showed (profiles/README.md, round 6): vmcnt counts loads and stores in ONE in-order counter, and the
+// compiler's wait insertion merges states at loop headers conservatively.  The tile loop's header was reached from the kernel entry
+// (operands of the first k tile in flight) and from the back edge (the same loads, then 16 epilogue stores per lane) -- so the first
+// use of a prefetched operand waited with the entry path's count, i.e. for the stores as well; the runtime choice between the fp32
+// activation and the bit mask of the layer below added copies of never-loaded registers behind an `s_waitcnt vmcnt(0)` right at the
+// loop top.  Every tile therefore began by waiting out the write round trip of the previous tile's 64 KB (phase omission had said
+// "stores: 1.4 of 4.6 ms" without saying why).  This kernel is the product configuration only (transposed epilogue, bit-mask act',
+// loads between the MFMAs, no plane tensors, whole tiles: B % BM == 0, every class pixel inside the input) with the control flow
+// shaped so that the wait counts are exact:
+//   * no runtime variants -> no merge points with differing memory events; epilogue stores are unconditional;
+//   * the state at the tile loop's header is the same on both edges: the kernel entry issues the first operand loads and then a
+//     DUMMY epilogue (zeros to the first tile's own destinations, overwritten by its real epilogue -- same wave, same addresses,
+//     in order), so "operand loads, then 16 stores" is what the header sees from either side and the first k step waits with
+//     vmcnt(16 + n) instead of vmcnt(n);
+//   * the first k step of a tile is peeled: its waits are the tile-header counts, the steady-state steps keep their own;
+//   * the last k step ALWAYS issues ten operand loads (the next tile's first k tile, or a harmless re-read at the very end).
+// The stores of tile T now drain while the first k step of tile T+1 multiplies; the second step's wait is the first that needs them.
+// Same loads, same staging, same MFMA order, same epilogue arithmetic: bit-identical to dgrad_x6_kernel<.., TR, IL>.
+template <int H, int W, int C, int RF, int S, int NF, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void dgrad_x6p_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ Bp,
+                                                        const uint32_t* __restrict__ mbits, float* __restrict__ dx, int B,
+                                                        long tiles_per_xcd, long total_tiles, int slots_per_xcd, int dither) {
+    using G = DgX6Geom<H, W, C, RF, S, NF>;
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = WM * 64, BN = WN * 64;
+    static_assert(G::N == BN, "one column tile: the weight-plane pointers are tile-independent");
+    static_assert(C % 32 == 0 && H % S == 0 && W % S == 0, "every (class, position) is a pixel of the input: unconditional stores");
+    static_assert(G::KT_PER_TAP >= 2, "a tile has at least two k steps: the peeled first step is never the last");
+    constexpr int NA = BM / 32, NQ = BN / 64;
+    constexpr int OH = G::OH, OW = G::OW, TAPS = G::TAPS;
+    extern __shared__ __attribute__((aligned(16))) uint16_t x6s[];
+    const int xcd = blockIdx.x & 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const bool sg_odd = (dither & 1) && (__builtin_amdgcn_readfirstlane(tid >> 6) & 1);
+    const uint32_t sg_k = sg_odd ? 0x80008000u : 0x8000u;
+    const float sg_s = sg_odd ? -1.f : 1.f;
+    const bool rowperm = (dither & 2) != 0;
+    auto stage_row = [&](int r) { return rowperm ? ((r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)) : r; };
+    const int arow = stage_row(tid >> 3);
+    const float sgn = ((dither & 1) && (i & 8)) ? -1.f : 1.f;
+    long slot = blockIdx.x >> 3;
+    if (slot >= tiles_per_xcd || (long)xcd * tiles_per_xcd + slot >= total_tiles) return;
+
+    auto first_valid = [&](int yy, int xx, int t) {      // first k tile >= t whose tap reads inside the dz map at (yy, xx)
+        while (t < G::NKT) {
+            const int tap = t / G::KT_PER_TAP, a = tap / TAPS, b2 = tap - a * TAPS;
+            if ((unsigned)(yy - a) < (unsigned)OH && (unsigned)(xx - b2) < (unsigned)OW) break;
+            ++t;
+        }
+        return t;
+    };
+    const float* ap[NA];
+    auto set_rows = [&](int b0, int yy, int xx) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) ap[p] = dz + ((long)((b0 + p * 32 + arow) * OH + yy) * OW + xx) * NF + (tid & 7) * 4;
+    };
+    const uint16_t* bp[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = q * 256 + tid;
+        bp[q] = Bp + (long)stage_row(c >> 2) * G::K + (c & 3) * 8;
+    }
+    constexpr long bplane = (long)G::N * G::K;
+    float4 ra0[NA];
+    u32x4v rb0[3 * NQ];
+    auto fetch = [&](int tt) {                           // tt: a VALID k tile of the tile `ap` points at
+        const int tap = tt / G::KT_PER_TAP, kin = (tt - tap * G::KT_PER_TAP) * X6_BK;
+        const int a = tap / TAPS, b2 = tap - a * TAPS;
+        const long ko = (long)kin - (long)(a * OW + b2) * NF;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) ra0[p] = *reinterpret_cast<const float4*>(ap[p] + ko);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rb0[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + tt * X6_BK);
+    };
+    uint16_t* const As = x6s;
+    uint16_t* const Bs = As + 3 * BM * X6_LDK;
+    auto swrite = [&]() {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            uint32_t a0x, a1x, a2x, a0y, a1y, a2y;
+            split2_bf16x3_sg(ra0[p].x, ra0[p].y, sg_k, sg_s, a0x, a1x, a2x);
+            split2_bf16x3_sg(ra0[p].z, ra0[p].w, sg_k, sg_s, a0y, a1y, a2y);
+            uint16_t* d = As + (p * 32 + arow) * X6_LDK + (tid & 7) * 4;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a0x, a0y);
+            *reinterpret_cast<uint2*>(d + BM * X6_LDK) = make_uint2(a1x, a1y);
+            *reinterpret_cast<uint2*>(d + 2 * BM * X6_LDK) = make_uint2(a2x, a2y);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = q * 256 + tid;
+                *reinterpret_cast<u32x4v*>(Bs + (pl * BN + stage_row(c >> 2)) * X6_LDK + (c & 3) * 8) = rb0[pl * NQ + q];
+            }
+    };
+    f32x16 acc[2][2];
+    auto mfma_block = [&]() {                            // transposed: D^T = B A^T
+#pragma unroll
+        for (int kb = 0; kb < X6_BK / 16; ++kb) {
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + (wm * 2 + a) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[b][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * 2 + b) * 32 + i) * X6_LDK + kb * 16 + 8 * h);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {            // small terms first
+                    if (kCross21) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][1], fa[a][2], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][2], fa[a][1], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][0], fa[a][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][1], fa[a][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][2], fa[a][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][0], fa[a][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][1], fa[a][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][0], fa[a][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+    // one k step: loads of k tile `tf` issued between the MFMAs of the staged one (schedule of dgrad_x6_kernel<.., IL>)
+    auto step = [&](int tf) {
+        constexpr int NL = NA + 3 * NQ;
+        static_assert(2 * NL <= 24, "two MFMAs per load inside the first half of the block");
+        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(tf);
+        mfma_block();
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        if constexpr (WM == 2 && WN == 2) {              // 128 x 128 tiles: the second k half's fragment reads 8 MFMAs early
+            __builtin_amdgcn_sched_group_barrier(0x008, 24 - 2 * NL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 32 - 2 * NL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // element offset of block (a, b) of this lane's image at class position (yy, xx) of tile b0
+    auto epi_off = [&](int a, int b, int b0, int yy, int xx) {
+        const int cb = (wn * 2 + b) * 32;
+        const int cls = cb / C, c0 = cb - cls * C;
+        const int py = cls / S, px = cls - py * S;
+        const int iy = yy * S + py, ix = xx * S + px;
+        const int bimg = b0 + (wm * 2 + a) * 32 + i;
+        return (long)bimg * (H * W * C) + ((long)iy * W + ix) * C + c0;
+    };
+
+    long lt = (long)xcd * tiles_per_xcd + slot;
+    int pos = (int)(lt % G::NPOS), b0 = (int)(lt / G::NPOS) * BM;
+    int yy = pos / G::WX, xx = pos - yy * G::WX;
+    set_rows(b0, yy, xx);
+    int t = first_valid(yy, xx, 0);
+    fetch(t);
+    {   // dummy epilogue (see the header comment): the memory events of a real one, zeros to this tile's own destinations
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float* d = dx + epi_off(a, b, b0, yy, xx) + 4 * h + 8 * (i & 3) - (long)(i & 3) * (H * W * C);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) *reinterpret_cast<float4*>(d + (long)s2 * (H * W * C)) = z4;
+            }
+    }
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        // ---- first k step (peeled; never the last)
+        __syncthreads();                       // the previous tile's fragment reads are done
+        swrite();
+        __syncthreads();
+        t = first_valid(yy, xx, t + 1);
+        step(t);
+        // ---- remaining k steps; the last one requests the mask words of this tile's epilogue and the next tile's first operands
+        uint32_t mw[2][2];
+        bool more;
+        int yy2 = yy, xx2 = xx, b02 = b0;
+        for (;;) {
+            __syncthreads();
+            swrite();
+            __syncthreads();
+            const int tn = first_valid(yy, xx, t + 1);
+            int tf = tn;
+            const bool last = tn >= G::NKT;
+            if (last) {
+                const long slot2 = slot + slots_per_xcd, lt2 = (long)xcd * tiles_per_xcd + slot2;
+                more = slot2 < tiles_per_xcd && lt2 < total_tiles;
+                tf = t;                        // nothing follows: a re-read of this k tile, never consumed
+                if (more) {
+                    const int pos2 = (int)(lt2 % G::NPOS);
+                    b02 = (int)(lt2 / G::NPOS) * BM;
+                    yy2 = pos2 / G::WX; xx2 = pos2 - yy2 * G::WX;
+                    set_rows(b02, yy2, xx2);   // (this tile's row pointers are dead: every k tile of it has been requested)
+                    tf = first_valid(yy2, xx2, 0);
+                    slot = slot2;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) mw[a][b] = mbits[epi_off(a, b, b0, yy, xx) >> 5];
+            }
+            step(tf);
+            if (last) { t = tf; break; }
+            t = tn;
+        }
+        // ---- epilogue: lane (i, h) owns image i of its block and the channels 8g + 4h + j of one destination pixel
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                // whole-line stores (planes.hip.h, quad_transpose4): after the exchange this lane holds chunk 2 m + h of the images
+                // i0 + s of its quad (m = i & 3, i0 = i - m); instruction s writes image i0 + s
+                float* d = dx + epi_off(a, b, b0, yy, xx) + 4 * h + 8 * (i & 3) - (long)(i & 3) * (H * W * C);
+                const uint32_t w = mw[a][b];
+                float4 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cin = 8 * g + 4 * h;
+                    v[g].x = acc[a][b][4 * g] * (((w >> cin) & 1u) ? sgn : 0.f);
+                    v[g].y = acc[a][b][4 * g + 1] * (((w >> (cin + 1)) & 1u) ? sgn : 0.f);
+                    v[g].z = acc[a][b][4 * g + 2] * (((w >> (cin + 2)) & 1u) ? sgn : 0.f);
+                    v[g].w = acc[a][b][4 * g + 3] * (((w >> (cin + 3)) & 1u) ? sgn : 0.f);
+                }
+                quad_transpose4(v, lane);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) *reinterpret_cast<float4*>(d + (long)s2 * (H * W * C)) = v[s2];
+            }
+        if (!more) break;
+        yy = yy2; xx = xx2; b0 = b02;
+    }
+}
+
 template <int H, int W, int C, int RF, int S, int NF>
 inline size_t dgrad_x6_plane_bytes() {
     using G = DgX6Geom<H, W, C, RF, S, NF>;
@@ -463,6 +722,22 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
                            (long)B * H * W * C, x6_dither());
         return hipGetLastError();
     };
+    if constexpr (C % 32 == 0 && NTN == 1 && H % S == 0 && W % S == 0) {
+        // round 6: the product configuration with exact wait counts around the epilogue stores (dgrad_x6 = 2, the default)
+        if (tr && !pa && mbits && !dxp && !dbg && x6_il() && B % BM == 0 && dgrad_x6_pipe()) {
+            static bool raised = false;
+            auto kern = dgrad_x6p_kernel<H, W, C, RF, S, NF, WM, WN>;
+            if (!raised) {
+                hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (er != hipSuccess) return er;
+                raised = true;
+            }
+            const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, mbits, dx, B,
+                               per_xcd, total, slots, x6_dither());
+            return hipGetLastError();
+        }
+    }
     if constexpr (C % 32 == 0) {
         if constexpr (EXP) {
             if (pa && tr) return launch(dgrad_x6_kernel<H, W, C, RF, S, NF, WM, WN, true, true, true>);

@@ -402,7 +402,7 @@ struct OptionDef { const char* name; const char* env; int dflt; };
 static const OptionDef kOptions[] = {
     // ---- product options (include/mrl.h)
     {"u8_bf16x3", "MRL_U8_BF16X3", 1}, {"f32_bf16x6", "MRL_F32_BF16X6", 2}, {"mlp_fused", "MRL_MLP_FUSED", 1},
-    {"heads_wave", "MRL_HEADS_WAVE", 2}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 1},
+    {"heads_wave", "MRL_HEADS_WAVE", 2}, {"dgrad_async", "MRL_DGRAD_ASYNC", 1}, {"dgrad_x6", "MRL_DGRAD_X6", 2},
     {"fused_norm", "MRL_FUSED_NORM", 1}, {"relu_bits", "MRL_RELU_BITS", 1}, {"c1_lds", "MRL_C1_LDS", 4},
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
@@ -2220,7 +2220,8 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 const int lk = ldsdgrad_kind(l, dz);
                 const bool overridden = tune_table().find(std::string(l.name) + ".dgrad") != tune_table().end();
                 int dv = pick_variant(l.name, "dgrad", Md, l.C, false);
-                if (lk && !overridden && nw.planes && f32_split_mode() && get_option("dgrad_x6", "MRL_DGRAD_X6", 1)) {
+                if (lk && !overridden && nw.planes && f32_split_mode() && get_option("dgrad_x6", "MRL_DGRAD_X6", 2)) {
+                    dgrad_x6_pipe() = get_option("dgrad_x6", "MRL_DGRAD_X6", 2) >= 2;
                     // position-major tiles on the split-bf16 pipe (dgradx6.hip.h): only useful MACs, all parity classes in one GEMM
                     char label[40];
                     if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);

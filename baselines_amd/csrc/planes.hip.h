@@ -95,6 +95,37 @@ struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of th
     }
 };
 
+// ---- whole-line stores out of the transposed layout (round 6) -------------------------------------------------------------
+// In the transposed layout lane (i, h) holds, for ITS row i, the four 16-byte chunks q = 2 g + h (g < 4) of a 128-byte group of 32
+// columns; store instruction g of the plain epilogue therefore touches 32 rows x 32 bytes: 32 cache lines per instruction, each line
+// completed by four instructions.  The CU's vector-memory path works per touched LINE (a timing experiment that only changed the
+// addresses -- 8 whole lines per instruction, wrong placement -- took c2.dgrad from 4.77 to 4.27 ms; profiles/README.md, round 6),
+// so the four lanes of a quad (rows i0 .. i0+3, same h) exchange their chunks first: a 4 x 4 transpose of 16-byte items over the
+// quad's lanes with DPP quad permutes (no LDS).  Afterwards lane (i0 + m, h) holds chunk q = 2 m + h of the rows i0 + s, s < 4, and
+// store instruction s writes row i0 + s: per instruction 8 rows x 8 chunks = 8 whole 128-byte lines.  Same values to the same
+// addresses.
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
+}
+// x[g] of quad lane m  ->  x[s] = what quad lane s held in x[m]   (per component; odd1 = m & 1, odd2 = m & 2)
+__device__ __forceinline__ void quad_transpose4(float& x0, float& x1, float& x2, float& x3, bool odd1, bool odd2) {
+    float r;
+    r = dpp_quad_xor1(odd1 ? x0 : x1); x0 = odd1 ? r : x0; x1 = odd1 ? x1 : r;
+    r = dpp_quad_xor1(odd1 ? x2 : x3); x2 = odd1 ? r : x2; x3 = odd1 ? x3 : r;
+    r = dpp_quad_xor2(odd2 ? x0 : x2); x0 = odd2 ? r : x0; x2 = odd2 ? x2 : r;
+    r = dpp_quad_xor2(odd2 ? x1 : x3); x1 = odd2 ? r : x1; x3 = odd2 ? x3 : r;
+}
+__device__ __forceinline__ void quad_transpose4(float4 (&v)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+    quad_transpose4(v[0].x, v[1].x, v[2].x, v[3].x, o1, o2);
+    quad_transpose4(v[0].y, v[1].y, v[2].y, v[3].y, o1, o2);
+    quad_transpose4(v[0].z, v[1].z, v[2].z, v[3].z, o1, o2);
+    quad_transpose4(v[0].w, v[1].w, v[2].w, v[3].w, o1, o2);
+}
+
 // One 32 x 32 accumulator in the transposed layout: lane (i, h) owns row i and the columns 8g + 4h + j = acc[4g + j] of
 // the 32-column block whose first element has offset o (a multiple of 32) in the output tensor.  Writes the fp32 values
 // (ef.out), the plane tensor (ef.hp) and the ReLU bit mask (ef.mask: one word per block, bit = column).  All 64 lanes

@@ -405,8 +405,11 @@ int mrl_tune_set(const char* label, int variant);
  *                  0 = row-major accumulators, ballot mask words
  *   "relu_bits"   [MRL_RELU_BITS, 1]  conv forward epilogues also write a 1-bit-per-element ReLU mask that the data gradients
  *                  read instead of the fp32 activations; 0 = fp32 activations
- *   "dgrad_x6"    [MRL_DGRAD_X6, 1]  conv data gradients on the position-major tiled split engine; 0 = LDS-resident fp32-MFMA
- *                  engine ("dgrad_async" [MRL_DGRAD_ASYNC, 1]: its LDS-DMA staging form for conv2)
+ *   "dgrad_x6"    [MRL_DGRAD_X6, 2]  conv data gradients on the position-major tiled split engine: 2 = the product configuration
+ *                  (transposed epilogue, bit-mask act', whole tiles) as a kernel of its own whose control flow gives the compiler
+ *                  exact vmcnt counts, so that a tile's output stores drain while the next tile multiplies (dgrad_x6p_kernel,
+ *                  round 6); 1 = the generic kernel for every case (round 5; what partial tiles still take); bit-identical.
+ *                  0 = LDS-resident fp32-MFMA engine ("dgrad_async" [MRL_DGRAD_ASYNC, 1]: its LDS-DMA staging form for conv2)
  *   "wgrad_tr"    [MRL_WGRAD_TR, 1]  weight gradients of conv2 / conv3 / fc1 on the split-arithmetic transpose-read kernels
  *                  (wgradtr.hip.h: operands staged in their natural layout, split once, fragments fetched with LDS transpose
  *                  reads; needs f32_bf16x6 != 0); 0 = "wgrad_x8" / fp32-MFMA engines

@@ -352,6 +352,7 @@ def test_engine_options_agree():
     assert defaults['wgrad_pipe'] == 1, 'conv2 / conv3 weight gradients: next image split between the MFMAs of the current one by default'
     assert defaults['conv_x6c'] == 1, 'conv2 / conv3 forward at minibatch sizes: class-resident kernel by default'
     assert defaults['x6_frag'] == 1, 'tiled split engines: operand split on the fragment path, between the MFMAs, by default'
+    assert defaults['dgrad_x6'] == 2, 'conv data gradients: position-major kernel with exact wait counts around its stores by default'
     assert defaults['heads_wave'] == 2, 'loss / head gradients of the NatureCNN head shape: two samples per wave-step by default'
     if experiments:
         assert defaults['act_planes'] == 76 and defaults['x6_il'] == 1
@@ -396,6 +397,7 @@ def test_engine_options_agree():
         scale = np.abs(g0).max()
         cases = [('split engines (default)', dict(defaults), 3e-6),
                  ('split engines, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
+                 ('split engines, data gradients with the generic position-major kernel (round 5)', dict(defaults, dgrad_x6=1), 3e-6),
                  ('split engines, act\' from the fp32 activations instead of the ReLU bit masks', dict(defaults, relu_bits=0), 3e-6),
                  ('split engines, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
                  ('split engines, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
@@ -452,9 +454,18 @@ def test_engine_options_agree():
                       'split engines, tiled conv forward in class-major k order without the sign alternation'),
                      # the pipelined weight gradients split the same values and multiply in the same order
                      ('split engines (default)', 'split engines, conv weight gradients with a split phase of its own (no software pipeline)'),
-                     ('split engines (default)', 'split engines, loss / head gradients one sample per wave-step')):
+                     ('split engines (default)', 'split engines, loss / head gradients one sample per wave-step'),
+                     # dgrad_x6p_kernel (round 6: exact wait counts around the epilogue stores) is the same arithmetic in the same order
+                     ('split engines (default)', 'split engines, data gradients with the generic position-major kernel (round 5)')):
             np.testing.assert_array_equal(by_name[a][0], by_name[b][0], err_msg=b)
             np.testing.assert_array_equal(by_name[a][1], by_name[b][1], err_msg=b)
+        # ... also where conv3's 256-image tiles divide the batch (1152 % 256 != 0 sends conv3 to the generic kernel above), on
+        # several tiles per workgroup, and on a batch neither tile size divides (both layers on the generic kernel)
+        for B2 in (1280, 5120, 200):
+            ga, sa = grads(*cnn, B2, dict(defaults), None)
+            gb, sb = grads(*cnn, B2, dict(defaults, dgrad_x6=1), None)
+            np.testing.assert_array_equal(ga, gb, err_msg='dgrad_x6 = 2 vs 1 at B = %d' % B2)
+            np.testing.assert_array_equal(sa, sb, err_msg='dgrad_x6 = 2 vs 1 at B = %d' % B2)
     finally:
         for o, v in defaults.items():
             L.set_option(o, v)
