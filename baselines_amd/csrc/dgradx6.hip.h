@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void dgx6_split_planes_kernel(const float* __r
         const float v = (ky < RF && kx < RF) ? w[((long)(ky * RF + kx) * C + c) * NF + n] : 0.f;
         uint16_t q0, q1, q2;
         split1_bf16x3(v, q0, q1, q2);
-        const int eo = kperm ? col * G::K + tap * NF + (int)kperm32(n) : e;      // k in the order of a plane tensor (planes.hip.h)
+        // kperm 1: k in the order of a plane tensor (planes.hip.h); 2: k-tile-major [k / 32][col][k % 32] -- a k tile of ALL columns is
+        // contiguous, so the 16 rows x 64 bytes a wave's staging load covers are 8 whole cache lines instead of 16 half lines
+        const int eo = kperm == 2 ? (k / X6_BK) * (G::N * X6_BK) + col * X6_BK + (k % X6_BK)
+                     : kperm ? col * G::K + tap * NF + (int)kperm32(n) : e;
         out[0 * total + eo] = q0;
         out[1 * total + eo] = q1;
         out[2 * total + eo] = q2;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6p_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = q * 256 + tid;
-        bp[q] = Bp + (long)stage_row(c >> 2) * G::K + (c & 3) * 8;
+        bp[q] = Bp + (long)stage_row(c >> 2) * X6_BK + (c & 3) * 8;       // k-tile-major planes (dgx6_split_planes_kernel, kperm = 2)
     }
     constexpr long bplane = (long)G::N * G::K;
     float4 ra0[NA];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_x6p_kernel(const float* __restri
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rb0[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + tt * X6_BK);
+            for (int q = 0; q < NQ; ++q) rb0[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + (long)tt * (G::N * X6_BK));
     };
     uint16_t* const As = x6s;
     uint16_t* const Bs = As + 3 * BM * X6_LDK;
@@ -700,8 +703,11 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NTN = (G::N + BN - 1) / BN;
     const bool pa = dzp && x8 && !dbg, tr = (dxp || tr_plain) && x8 && !(dbg & 1) && C % 32 == 0 && (act == ACT_RELU || (!hmask && !mbits));
+    bool pipe = false;
+    if constexpr (C % 32 == 0 && NTN == 1 && H % S == 0 && W % S == 0)
+        pipe = tr && !pa && mbits && !dxp && !dbg && x6_il() && B % BM == 0 && dgrad_x6_pipe();
     hipLaunchKernelGGL((dgx6_split_planes_kernel<H, W, C, RF, S, NF>), dim3((G::N * G::K + 255) / 256), dim3(256), 0, stream,
-                       w, planes, pa ? 1 : 0);
+                       w, planes, pipe ? 2 : pa ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int btiles = (B + BM - 1) / BM;
@@ -724,7 +730,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
     };
     if constexpr (C % 32 == 0 && NTN == 1 && H % S == 0 && W % S == 0) {
         // round 6: the product configuration with exact wait counts around the epilogue stores (dgrad_x6 = 2, the default)
-        if (tr && !pa && mbits && !dxp && !dbg && x6_il() && B % BM == 0 && dgrad_x6_pipe()) {
+        if (pipe) {
             static bool raised = false;
             auto kern = dgrad_x6p_kernel<H, W, C, RF, S, NF, WM, WN>;
             if (!raised) {
