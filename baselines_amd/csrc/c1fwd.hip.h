@@ -451,16 +451,29 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
         if constexpr (EPI) {
 #pragma unroll
             for (int u = 0; u < NU; ++u)
-                ob[u] = TR ? out + ((ppix0 + pixl[u]) * C1_NF + 4 * h) : out + ((ppix0 + (t0 + u) * 32 + 4 * h) * C1_NF + i);
+                ob[u] = TR ? out + ((ppix0 + pixl[u] - (i & 3)) * C1_NF + 8 * (i & 3) + 4 * h) : out + ((ppix0 + (t0 + u) * 32 + 4 * h) * C1_NF + i);
         }
         // TR epilogue piece e (0 .. 8 NU - 1) of the previous image: tile e >> 3, channel group g = (e & 7) >> 1 (channels
         // 8g + 4h .. +3); even pieces: its 16-byte store; odd pieces: its mask bits (bit = channel; v >= 0 after the ReLU)
         // The four 16-byte stores of a tile complete 32 whole 128-byte lines between them: issued close together (every SS-th
         // gap) they merge on the way to memory; spread evenly over the phase the same stores cost 0.3 ms more per launch.
-        auto epi_tr_store = [&](int u, int g) {
+        // round 6: WHOLE-LINE stores.  Lane (i, h) holds the chunks 2g + h of ITS pixel; piece j of the exchange (epi_tr_xpose) transposes
+        // component j of the four chunks over the lanes of a quad (planes.hip.h, quad_transpose4), after which the lane holds chunk
+        // 2 (i & 3) + h of the quad's pixels i0 + s in registers 4s .. 4s+3, and store s writes pixel i0 + s: 8 pixels x 128 bytes per
+        // instruction instead of 32 pixels x 32 bytes (the CU's vector-memory path works per touched line).  The mask bits are taken
+        // BEFORE the exchange (they belong to the lane's own pixel).
+        auto epi_tr_xpose = [&](int u, int j) {
+            if constexpr (EPI && TR)
+            {
+                float x0 = pend[u][j], x1 = pend[u][4 + j], x2 = pend[u][8 + j], x3 = pend[u][12 + j];
+                quad_transpose4(x0, x1, x2, x3, (i & 1) != 0, (i & 2) != 0);
+                pend[u][j] = x0; pend[u][4 + j] = x1; pend[u][8 + j] = x2; pend[u][12 + j] = x3;
+            }
+        };
+        auto epi_tr_store = [&](int u, int sq) {
             if constexpr (EPI && TR) {
                 if (!(DBG & 1))
-                    *reinterpret_cast<float4*>(ob[u] + 8 * g) = make_float4(pend[u][4 * g], pend[u][4 * g + 1], pend[u][4 * g + 2], pend[u][4 * g + 3]);
+                    *reinterpret_cast<float4*>(ob[u] + sq * C1_NF) = make_float4(pend[u][4 * sq], pend[u][4 * sq + 1], pend[u][4 * sq + 2], pend[u][4 * sq + 3]);
             }
         };
         auto epi_tr_mask = [&](int u, int g) {
@@ -521,8 +534,10 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
                     if constexpr (TR) {
                         constexpr int SS = C1_TR_STORE_STRIDE;
                         const int gu = gap % 48, u = gap / 48;                        // 48 gaps per tile
-                        if (gu % SS == 0 && gu / SS < 4) epi_tr_store(u, gu / SS);
-                        if (gu >= 24 && gu % 6 == 0) epi_tr_mask(u, (gu - 24) / 6);
+                        // gaps 0 .. 6: mask bits; 8 .. 20: the exchange, one component per four gaps; from 24: the four stores
+                        if (gu < 8 && gu % 2 == 0) epi_tr_mask(u, gu / 2);
+                        if (gu >= 8 && gu < 24 && gu % 4 == 0) epi_tr_xpose(u, (gu - 8) / 4);
+                        if (gu >= 24 && (gu - 24) % SS == 0 && (gu - 24) / SS < 4) epi_tr_store(u, (gu - 24) / SS);
                     }
                     else if (gap % 3 == 0) epi_row(gap / 3);                          // 32 (16) rows over 96 (48) gaps
                     if (gap % 3 == 1 && gap / 3 < 2 * NLD && !(DBG & 8) && !((DBG & 32) && TWO)) stage_half(nxt, gap / 6, (gap / 3) & 1);   // gaps 1, 4, .. 22: 8 half chunks
@@ -588,14 +603,21 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
-            float* ob = out + ((ppix0 + pixl[u]) * C1_NF + 4 * h);
+            float* ob = out + ((ppix0 + pixl[u] - (i & 3)) * C1_NF + 8 * (i & 3) + 4 * h);
             uint32_t bits = 0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<float4*>(ob + 8 * g) = make_float4(pend[u][4 * g], pend[u][4 * g + 1], pend[u][4 * g + 2], pend[u][4 * g + 3]);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bits |= min(__float_as_uint(pend[u][4 * g + j]), 1u) << (8 * g + 4 * h + j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0 = pend[u][j], x1 = pend[u][4 + j], x2 = pend[u][8 + j], x3 = pend[u][12 + j];
+                quad_transpose4(x0, x1, x2, x3, (i & 1) != 0, (i & 2) != 0);
+                pend[u][j] = x0; pend[u][4 + j] = x1; pend[u][8 + j] = x2; pend[u][12 + j] = x3;
             }
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq)
+                *reinterpret_cast<float4*>(ob + sq * C1_NF) = make_float4(pend[u][4 * sq], pend[u][4 * sq + 1], pend[u][4 * sq + 2], pend[u][4 * sq + 3]);
             if constexpr (MASK) {
                 const uint32_t other = (uint32_t)__shfl_xor((int)bits, 32);
                 if (h == 0) mask[ppix0 + pixl[u]] = bits | other;

@@ -56,9 +56,12 @@ __host__ __device__ __forceinline__ long conv_kcls_encode(long k, int rf, int st
 // out[plane][n][k] (bf16 bits) from src[R][Cn] fp32:  transpose ? (n, k) = (col, row) : (n, k) = (row, col)
 // kperm: k runs in the order of a plane tensor (planes.hip.h: perm32 inside each aligned block of 32)
 // kcls_rf > 0: k runs in the class-major order of a conv layer with that filter size / stride / input channels (conv_kcls_encode)
+// ktm (round 6): k-tile-major planes [plane][k / 32][n][k % 32] -- one k tile of ALL rows is contiguous, so the 16 rows x 64 bytes a
+// wave's staging load covers are 8 whole cache lines instead of 16 half lines 2 K bytes apart (the CU's vector-memory path works per
+// touched line: c2.dgrad 4.35 -> 4.13 ms with the same change, profiles/README.md round 6)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int Cn, int transpose,
                                                            uint16_t* __restrict__ out, int kperm = 0, int kcls_rf = 0,
-                                                           int kcls_stride = 1, int kcls_c = 32) {
+                                                           int kcls_stride = 1, int kcls_c = 32, int ktm = 0) {
     const long total = (long)R * Cn;
     const long Nn = transpose ? Cn : R, Kd = transpose ? R : Cn;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
@@ -67,9 +70,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const long k = kcls_rf ? conv_kcls_encode(k0, kcls_rf, kcls_stride, kcls_c) : kperm ? kperm32(k0) : k0;
         uint16_t b0, b1, b2;
         split1_bf16x3(src[e], b0, b1, b2);
-        out[(0 * Nn + n) * Kd + k] = b0;
-        out[(1 * Nn + n) * Kd + k] = b1;
-        out[(2 * Nn + n) * Kd + k] = b2;
+        const long eo = ktm ? (k / X6_BK) * (Nn * X6_BK) + n * X6_BK + (k % X6_BK) : n * Kd + k;
+        out[0 * Nn * Kd + eo] = b0;
+        out[1 * Nn * Kd + eo] = b1;
+        out[2 * Nn * Kd + eo] = b2;
     }
 }
 
@@ -183,9 +187,10 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = q * 256 + tid;
-        bp[q] = Bp + (long)min(n0 + stage_row(c >> 2), N - 1) * K + (c & 3) * 8;
+        bp[q] = Bp + (long)min(n0 + stage_row(c >> 2), N - 1) * ((dither & 8) ? X6_BK : K) + (c & 3) * 8;      // dither & 8: k-tile-major planes
     }
     const long bplane = (long)N * K;
+    const long bkt = (dither & 8) ? (long)N * X6_BK : (long)X6_BK;                                                 // distance between k tiles
     const int ntile = K / X6_BK;
     float4 ra0[PA ? 1 : NA];
     u32x4v rp0[PA ? 3 * NAP : 1];
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + k0);
+            for (int q = 0; q < NQ; ++q) rb[pl * NQ + q] = *reinterpret_cast<const u32x4v*>(bp[q] + pl * bplane + (k0 / X6_BK) * bkt);
     };
     auto swrite = [&](const float4 (&ra)[PA ? 1 : NA], const u32x4v (&rp)[PA ? 3 * NAP : 1], const u32x4v (&rb)[3 * NQ], uint16_t* As) {
         uint16_t* Bs = As + 3 * BM * X6_LDK;
@@ -429,7 +434,7 @@ inline size_t gemm_x6_plane_bytes(long N, long K) { return (size_t)3 * N * K * s
 // transpose form through an LDS tile (round 5): out[plane][n][k] from src[k][n] -- the element-wise kernel above writes 2-byte
 // pieces K * 2 bytes apart (fc1's 3136 x 512 weights: 28-35 us per call, twice per minibatch step and once per act step); here a
 // workgroup reads a 32 (k) x 64 (n) tile with coalesced rows and writes 16-byte pieces of 8 consecutive k per (plane, n).
-__global__ __launch_bounds__(256) void split_planes_tr_kernel(const float* __restrict__ src, int K, int N, uint16_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void split_planes_tr_kernel(const float* __restrict__ src, int K, int N, uint16_t* __restrict__ out, int ktm) {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
     const int ntn = N / 64, tk = blockIdx.x / ntn, tn = blockIdx.x - tk * ntn;
@@ -447,19 +452,21 @@ __global__ __launch_bounds__(256) void split_planes_tr_kernel(const float* __res
         split2_bf16x3(tile[kc + 2 * q][n], tile[kc + 2 * q + 1][n], p[0][q], p[1][q], p[2][q]);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
-        *reinterpret_cast<u32x4v*>(out + ((long)pl * N + n0 + n) * K + k0 + kc) = u32x4v{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+        *reinterpret_cast<u32x4v*>(out + (ktm ? (long)pl * N * K + (long)tk * (N * 32) + (long)(n0 + n) * 32 + kc : ((long)pl * N + n0 + n) * K + k0 + kc)) =
+            u32x4v{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
 }
 
 inline hipError_t launch_split_planes(const float* src, int R, int Cn, bool transpose, uint16_t* out, hipStream_t stream,
-                                      bool kperm = false, int kcls_rf = 0, int kcls_stride = 1, int kcls_c = 32) {
+                                      bool kperm = false, int kcls_rf = 0, int kcls_stride = 1, int kcls_c = 32, bool ktm = false) {
+    if (ktm && (kperm || kcls_rf || (transpose ? R : Cn) % X6_BK != 0)) return hipErrorInvalidValue;
     if (transpose && !kperm && !kcls_rf && R % 32 == 0 && Cn % 64 == 0 && (uintptr_t)out % 16 == 0) {
-        hipLaunchKernelGGL(split_planes_tr_kernel, dim3((unsigned)((R / 32) * (Cn / 64))), dim3(256), 0, stream, src, R, Cn, out);
+        hipLaunchKernelGGL(split_planes_tr_kernel, dim3((unsigned)((R / 32) * (Cn / 64))), dim3(256), 0, stream, src, R, Cn, out, ktm ? 1 : 0);
         return hipGetLastError();
     }
     const long total = (long)R * Cn;
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, R, Cn, transpose ? 1 : 0, out, kperm ? 1 : 0,
-                       kcls_rf, kcls_stride, kcls_c);
+                       kcls_rf, kcls_stride, kcls_c, ktm ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -467,7 +474,7 @@ inline int& x6_pg() { static int p = getenv("MRL_X6_PG") ? atoi(getenv("MRL_X6_P
 inline int& x6_il() { static int p = getenv("MRL_X6_IL") ? atoi(getenv("MRL_X6_IL")) : 1; return p; }          // mrl_set_option "x6_il": loads interleaved with the MFMAs (TR launches)
 template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, int IL = 0>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
-                                     hipStream_t stream, long a_pstride = 0) {
+                                     hipStream_t stream, long a_pstride = 0, bool ktm = false) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const int pg = ntiles > 1 ? std::max(1, x6_pg()) : 1;
@@ -498,7 +505,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
 #ifdef MRL_X6_EXPERIMENTS
         if (x6_il())
 #endif
-        return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+        return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm);
     }
     auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
     static bool raised = false;                // per instantiation
@@ -507,7 +514,8 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride, pg, x6_dither());
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride, pg,
+                       x6_dither() | (ktm ? 8 : 0));
     return hipGetLastError();
 }
 // Pre-split operands (planes.hip.h).  PA: A is a plane tensor (af.p = plane 0, a_pstride elements between planes; Bp must
@@ -515,11 +523,11 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
 // Eight-product arithmetic only (the default mode).
 template <bool PA, bool TR, class AF, class EF>
 inline hipError_t launch_gemm_x6_planes(const AF& af, long a_pstride, const uint16_t* Bp, const EF& ef, int M, int N, int K,
-                                        hipStream_t stream, long long* dbg = nullptr) {
+                                        hipStream_t stream, long long* dbg = nullptr, bool ktm = false) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (TR && N % 32 != 0) return hipErrorInvalidValue;
-    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
-    return launch_gemm_x6_cfg<AF, EF, 2, 2, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride);
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm);
 }
 template <class AF, class EF>
 inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream,

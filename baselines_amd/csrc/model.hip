@@ -389,11 +389,15 @@ static int act_planes_mode() {
 // form (two waves of one SIMD share its VALU issue and its matrix pipe: profiles/README.md), kept as an experiment knob
 // transposed-epilogue launches of the tiled split engine: split-at-the-fragment kernel (gemmx6r.hip.h, option x6_frag) or the
 // staged-planes kernel (gemmx6.hip.h); bit-identical results
+// does a transposed-epilogue launch of this width take the staged-planes kernel (which can read k-tile-major weight planes)?
+static bool x6_tr_staged(int N, const long long* dbg) { return !(x6_frag() && !dbg && N % 32 == 0 && (N <= 64 || (x6_frag() & 8))); }
+// mrl_set_option "x6_ktm" [MRL_X6_KTM, 1]: fc weight planes of the tiled split engine in k-tile-major order
+static int x6_ktm() { return get_option("x6_ktm", "MRL_X6_KTM", 1); }
 template <class AF, class EF>
-static hipError_t launch_x6_tr(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t st, long long* dbg) {
+static hipError_t launch_x6_tr(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t st, long long* dbg, bool ktm = false) {
     // (N <= 64: the 32 x 128 wave tiles of the fc layer measured slower -- fc1.fwd 1.94 -> 2.17 ms, fc1.dgrad 2.39 -> 2.52 -- unless bit 3 asks)
-    if (x6_frag() && !dbg && N % 32 == 0 && (N <= 64 || (x6_frag() & 8))) return launch_gemm_x6r(af, Bp, ef, M, N, K, st);
-    return launch_gemm_x6_planes<false, true>(af, 0, Bp, ef, M, N, K, st, dbg);
+    if (!x6_tr_staged(N, dbg)) return ktm ? hipErrorInvalidValue : launch_gemm_x6r(af, Bp, ef, M, N, K, st);
+    return launch_gemm_x6_planes<false, true>(af, 0, Bp, ef, M, N, K, st, dbg, ktm);
 }
 static int x6_specialised() { return kExp ? get_option("x6_spec", "MRL_X6_SPEC", 0) : 0; }
 // phase-stamp / phase-omission knobs exist in experiment builds only
@@ -407,7 +411,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -1948,10 +1952,12 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
                 ProfScope ps(label, 2.0 * B * (double)l.K * l.N, 0.0, st);
                 const bool pa = EXP && hprev_p && f32_split_mode() == 2 && l.K % 32 == 0 && !x6_specialised();
-                hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st, pa);        // B[n][k] = W[k][n]
-                if (e != hipSuccess) return (int)e;
                 const bool trf = (act_planes_mode() & 64) && f32_split_mode() == 2 && l.act == ACT_RELU && l.N % 32 == 0 && !x6_specialised() &&
                                  (uintptr_t)bias % 16 == 0;
+                long long* const dbgq0 = dbg_option("x6_dbg", "MRL_X6_DBG") == 1 ? dbgbuf : nullptr;
+                const bool ktm = trf && !pa && x6_ktm() && x6_tr_staged(l.N, dbgq0);
+                hipError_t e = launch_split_planes(W, l.K, l.N, true, planes, st, pa, 0, 1, 32, ktm);        // B[n][k] = W[k][n]
+                if (e != hipSuccess) return (int)e;
                 if constexpr (EXP) {
                     if (pa && !trf)
                         return (int)launch_gemm_x6_planes<true, false>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
@@ -1964,7 +1970,7 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                         if (pa) return (int)launch_gemm_x6_planes<true, true>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
                                                                               (long)B * l.K, planes, tf, B, l.N, l.K, st, dbgq);
                     }
-                    return (int)launch_x6_tr(X6DenseA{hprev, (long)l.K}, planes, tf, B, l.N, l.K, st, dbgq);
+                    return (int)launch_x6_tr(X6DenseA{hprev, (long)l.K}, planes, tf, B, l.N, l.K, st, dbgq, ktm);
                 }
                 // MRL_X6_DBG=1: phase timestamps of workgroup 0 land behind the zero page (scripts/x6_phases.py)
                 long long* dbgp = dbg_option("x6_dbg", "MRL_X6_DBG") == 1 ? dbgbuf : nullptr;
@@ -2288,7 +2294,8 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 EpiMaskAct ef{nw.dz[i - 1], l.K, hmask, lp.act};
                 const bool tr = (dx_p || ((act_planes_mode() & 8) && f32_split_mode() == 2 && !x6_specialised() && lp.act == ACT_RELU)) &&
                                 l.K % 32 == 0 && (uintptr_t)hmask % 16 == 0;
-                hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st, dz_p != nullptr);
+                const bool ktm = tr && !dz_p && x6_ktm() && x6_tr_staged(l.K, nullptr);
+                hipError_t e = launch_split_planes(params + l.w_off, l.K, l.N, false, nw.planes, st, dz_p != nullptr, 0, 1, 32, ktm);
                 if (e == hipSuccess && (dz_p || tr)) {
                     // transposed-accumulator epilogue; experiment builds: dz staged from its plane tensor, dz[i-1] leaves with
                     // its planes (planes.hip.h)
@@ -2300,7 +2307,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                         if constexpr (EXP) {
                             if (dz_p) { e = launch_gemm_x6_planes<true, true>(da, aps, nw.planes, tf, B, l.K, l.N, st); done = true; }
                         }
-                        if (!done) e = launch_x6_tr(da, nw.planes, tf, B, l.K, l.N, st, nullptr);
+                        if (!done) e = launch_x6_tr(da, nw.planes, tf, B, l.K, l.N, st, nullptr, ktm);
                         if (e == hipSuccess && dx_p) nw.dzpvalid[i - 1] = 1;
                     } else {
                         if constexpr (EXP) e = launch_gemm_x6_planes<true, false>(da, aps, nw.planes, ef, B, l.K, l.N, st);

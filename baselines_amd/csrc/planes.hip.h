@@ -130,21 +130,43 @@ __device__ __forceinline__ void quad_transpose4(float4 (&v)[4], int lane) {
 // the 32-column block whose first element has offset o (a multiple of 32) in the output tensor.  Writes the fp32 values
 // (ef.out), the plane tensor (ef.hp) and the ReLU bit mask (ef.mask: one word per block, bit = column).  All 64 lanes
 // must call it (the two halves of a block exchange their mask bits); `valid` gates the memory accesses.
+// row_ld > 0 (round 6): the rows i of the block are row_ld elements apart in the output (o = row * row_ld + first column); the fp32
+// values then leave as WHOLE 128-byte lines -- the quad's lanes exchange chunks (quad_transpose4) and store instruction s writes
+// row i0 + s of every quad, 8 rows x 8 chunks per instruction instead of 32 rows x 2 chunks.  Same values to the same addresses.
 template <class EF>
-__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, const TrAux& aux, long o, int h, bool valid, float sg = 1.f) {
+__device__ __forceinline__ void tr_block_epilogue(const EF& ef, const f32x16& acc, const TrAux& aux, long o, int h, bool valid, float sg = 1.f,
+                                                  long row_ld = 0) {
     uint32_t bits = 0;
     uint32_t pk[3][8];
+    float4 vv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int cin = 8 * g + 4 * h;
         const float4 v = ef.apply(aux, g, cin, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]), sg);
+        vv[g] = v;
         if (ef.mask)
             bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << cin;
-        if (ef.out && valid) *reinterpret_cast<float4*>(ef.out + o + cin) = v;
+        if (ef.out && valid && row_ld <= 0) *reinterpret_cast<float4*>(ef.out + o + cin) = v;
         if (ef.hp) {
             split2_bf16x3(v.x, v.y, pk[0][2 * g], pk[1][2 * g], pk[2][2 * g]);
             split2_bf16x3(v.z, v.w, pk[0][2 * g + 1], pk[1][2 * g + 1], pk[2][2 * g + 1]);
         }
+    }
+    if (ef.out && row_ld > 0) {
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int m = lane & 3;
+        // which rows of this quad are inside the output, and where its first row starts (a lane whose own row is outside still stores
+        // its chunk of the rows that are inside)
+        const unsigned long long bal = __ballot(valid);
+        const uint32_t qv = (uint32_t)(bal >> (lane & ~3)) & 0xfu;
+        const int olo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)o, 0x00, 0xf, 0xf, true);            // quad_perm:[0,0,0,0]
+        const int ohi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)o >> 32), 0x00, 0xf, 0xf, true);
+        const long o0 = (long)(((unsigned long long)(uint32_t)ohi << 32) | (uint32_t)olo);
+        quad_transpose4(vv, lane);
+        float* d = ef.out + o0 + 8 * m + 4 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if ((qv >> s) & 1u) *reinterpret_cast<float4*>(d + s * row_ld) = vv[s];
     }
     if (ef.hp && valid) {
 #pragma unroll

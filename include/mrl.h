@@ -427,6 +427,9 @@ int mrl_tune_set(const char* label, int variant);
  *                  engine.  4, 3 and 2 are bit-identical (same products, same order of accumulation).
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
+ *   "x6_ktm"      [MRL_X6_KTM, 1]  weight planes of the fc layers' tiled split launches (fc1 forward / data gradient) in k-tile-major
+ *                  order [plane][k / 32][n][k % 32]: a staging load of 16 rows x 64 bytes touches 8 whole cache lines instead of
+ *                  16 half lines (round 6); 0 = [plane][n][k].  Bit-identical.
  *   "conv_x6c"    [MRL_CONV_X6C, 1]  conv2 / conv3 forward of NatureCNN from 96 images up on the class-resident kernel
  *                  (convx6c.hip.h): a tile is whole images, the input pixels of one stride-parity class are staged once as raw
  *                  fp32 and serve all taps of the class (every input element loaded once, 4 / 2 barrier pairs per tile instead of
