@@ -383,14 +383,23 @@ struct WgTrDenseCfg {
 template <int MT>
 __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __restrict__ A, long lda, const float* __restrict__ dz,
                                                              float* __restrict__ part, long slab, int M, int K, int N,
-                                                             int ktiles, int ntiles, int rows_per_slab, int dither) {
+                                                             int ktiles, int ntiles, int rows_per_slab, int dither, int per_xcd, int nblocks) {
     using G = WgTrDenseCfg<MT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
     uint8_t* as = wt_lds;
     uint8_t* bs = wt_lds + G::A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = ktiles * ntiles;
-    const int s = blockIdx.x / T, tile = blockIdx.x - s * T;
+    // round 6: XCD-aware order.  Workgroup b runs on XCD b & 7; XCD x takes the contiguous run [x * per_xcd, (x + 1) * per_xcd) of the
+    // logical (slab, tile) list, so a slab's T tiles -- which read the SAME dz rows -- sit on one or two XCDs instead of all eight, and the
+    // ntiles workgroups that read the same A columns are neighbours in one L2 (per_xcd is a multiple of ntiles).  fc1: 252 workgroups;
+    // counter traffic 4.42 -> see profiles/README.md round 6.  xcd_order = 0: blockIdx order (round 3).
+    int lid = blockIdx.x;
+    if (per_xcd > 0) {
+        lid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= per_xcd || lid >= nblocks) return;
+    }
+    const int s = lid / T, tile = lid - s * T;
     const int kt = tile / ntiles, nt = tile - kt * ntiles;
     const int k0 = kt * G::BK, n0 = nt * G::BN;
     const long m_begin = (long)s * rows_per_slab;
@@ -541,6 +550,7 @@ __global__ __launch_bounds__(512) void wgrad_tr_dense_kernel(const float* __rest
     }
 }
 
+inline int& wgrad_tr_xcd() { static int p = getenv("MRL_WGRAD_XCD") ? atoi(getenv("MRL_WGRAD_XCD")) : 1; return p; }     // mrl_set_option "wgrad_xcd"
 struct WgTrDensePlan { int mt = 0, ktiles = 0, ntiles = 0, nslab = 0, rows_per_slab = 0; };
 // usable when the tiles divide the output exactly and the operands allow 16-byte loads
 inline WgTrDensePlan wgrad_tr_dense_plan(long M, int K, int N, long lda, int num_cus, size_t part_floats) {
@@ -561,7 +571,10 @@ inline WgTrDensePlan wgrad_tr_dense_plan(long M, int K, int N, long lda, int num
 
 inline hipError_t launch_wgrad_tr_dense(const float* A, long lda, const float* dz, float* part, long slab, int M, int K, int N,
                                         const WgTrDensePlan& p, hipStream_t stream) {
-    const unsigned blocks = (unsigned)(p.nslab * p.ktiles * p.ntiles);
+    const int nblocks = p.nslab * p.ktiles * p.ntiles;
+    // per-XCD run of the logical list: a multiple of ntiles, so the workgroups that share A columns stay together
+    const int per_xcd = wgrad_tr_xcd() ? ((nblocks + 7) / 8 + p.ntiles - 1) / p.ntiles * p.ntiles : 0;
+    const unsigned blocks = per_xcd ? (unsigned)(8 * per_xcd) : (unsigned)nblocks;
     auto go = [&](auto kern, size_t lds) {
         static bool raised = false;            // per instantiation (one lambda instantiation per kernel type)
         if (!raised) {
@@ -570,7 +583,7 @@ inline hipError_t launch_wgrad_tr_dense(const float* A, long lda, const float* d
             raised = true;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, stream, A, lda, dz, part, slab, M, K, N, p.ktiles, p.ntiles,
-                           p.rows_per_slab, x6_dither());
+                           p.rows_per_slab, x6_dither(), per_xcd, nblocks);
         return hipGetLastError();
     };
     if (p.mt == 7) return go(wgrad_tr_dense_kernel<7>, WgTrDenseCfg<7>::LDS_BYTES);
