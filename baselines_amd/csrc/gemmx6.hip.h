@@ -118,7 +118,8 @@ struct X6ConvA : ConvGeom {  // conv forward: row = output pixel (b, oy, ox), k 
 //     cycles during which it feeds nothing to the matrix pipe).
 template <class AF, class EF, int WM, int WN, bool X8, int xd = 0, bool PA = false, bool TR = false, int IL = 0>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __restrict__ Bp, EF ef, int M, int N, int K,
-                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride, int pg, int dither) {
+                                                      int mtiles, int ntiles, long long* dbg, int prio, long a_pstride, int pg, int dither,
+                                                      int kz_tiles = 0, long zslab = 0) {
     // xd (timing experiments, builds with -DMRL_X6_EXPERIMENTS, option x6_dbg = 100 + bits): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global loads in the
     // main loop, 8 = no split arithmetic (raw halves are staged), 16 = every step re-reads k tile 0 (cache hits)
     static_assert(WM * WN == 4, "4 waves");
@@ -292,7 +293,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         }
     };
     uint16_t* L0 = x6s;
-    fetch(ra0, rp0, rb0, 0);
+    // split-K over blockIdx.y (round 6; act-side fc launches whose tiles alone would leave half the chip idle): this workgroup
+    // walks the k tiles [tz0, tz1) and writes its partial sums zslab elements behind the previous split's (kz_tiles = 0: all of K)
+    const int tz0 = kz_tiles ? (int)blockIdx.y * kz_tiles : 0;
+    const int tz1 = kz_tiles ? min(ntile, tz0 + kz_tiles) : ntile;
+    fetch(ra0, rp0, rb0, tz0);
     // dbg != nullptr (timing experiments): wave 0 of workgroup 0 stamps the phase boundaries of its tiles 8..13
     auto stamp = [&](int t, int k) {
         if (dbg && blockIdx.x == 0 && tid == 0 && t >= 8 && t < 14) {
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
         }
     };
     tstamp(1);
-    for (int t = 0; t < ntile; ++t) {
+    for (int t = tz0; t < tz1; ++t) {
         stamp(t, 0);
         __syncthreads();                       // previous tile's fragment reads are done
         stamp(t, 1);
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(AF af, const uint16_t* __r
             for (int b = 0; b < 2; ++b) {
                 const int row = m0 + (wm * 2 + a) * 32 + i, cb = n0 + (wn * 2 + b) * 32;
                 const bool valid = row < M && cb < N;
-                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? (long)row * ef.ld + cb : 0L, h, valid,
+                tr_block_epilogue(ef, acc[a][b], aux[a][b], valid ? (long)row * ef.ld + cb + (long)blockIdx.y * zslab : 0L, h, valid,
                                   (!PA && (dither & 1) && (i & 8)) ? -1.f : 1.f);
             }
     } else {
@@ -474,7 +479,7 @@ inline int& x6_pg() { static int p = getenv("MRL_X6_PG") ? atoi(getenv("MRL_X6_P
 inline int& x6_il() { static int p = getenv("MRL_X6_IL") ? atoi(getenv("MRL_X6_IL")) : 1; return p; }          // mrl_set_option "x6_il": loads interleaved with the MFMAs (TR launches)
 template <class AF, class EF, int WM, int WN, bool X8, int XD = 0, bool PA = false, bool TR = false, int IL = 0>
 inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, long long* dbg,
-                                     hipStream_t stream, long a_pstride = 0, bool ktm = false) {
+                                     hipStream_t stream, long a_pstride = 0, bool ktm = false, int nz = 1, long zslab = 0) {
     constexpr int BM = WM * 64, BN = WN * 64;
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const int pg = ntiles > 1 ? std::max(1, x6_pg()) : 1;
@@ -505,7 +510,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
 #ifdef MRL_X6_EXPERIMENTS
         if (x6_il())
 #endif
-        return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm);
+        return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm, nz, zslab);
     }
     auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
     static bool raised = false;                // per instantiation
@@ -514,8 +519,9 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg, x6_prio(), a_pstride, pg,
-                       x6_dither() | (ktm ? 8 : 0));
+    const int kz_tiles = nz > 1 ? (K / X6_BK + nz - 1) / nz : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)std::max(1, nz)), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg,
+                       x6_prio(), a_pstride, pg, x6_dither() | (ktm ? 8 : 0), kz_tiles, zslab);
     return hipGetLastError();
 }
 // Pre-split operands (planes.hip.h).  PA: A is a plane tensor (af.p = plane 0, a_pstride elements between planes; Bp must
@@ -523,11 +529,11 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
 // Eight-product arithmetic only (the default mode).
 template <bool PA, bool TR, class AF, class EF>
 inline hipError_t launch_gemm_x6_planes(const AF& af, long a_pstride, const uint16_t* Bp, const EF& ef, int M, int N, int K,
-                                        hipStream_t stream, long long* dbg = nullptr, bool ktm = false) {
+                                        hipStream_t stream, long long* dbg = nullptr, bool ktm = false, int nz = 1, long zslab = 0) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (TR && N % 32 != 0) return hipErrorInvalidValue;
-    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm);
-    return launch_gemm_x6_cfg<AF, EF, 2, 2, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm);
+    if (N <= 64) return launch_gemm_x6_cfg<AF, EF, 4, 1, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm, nz, zslab);
+    return launch_gemm_x6_cfg<AF, EF, 2, 2, true, 0, PA, TR>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm, nz, zslab);
 }
 template <class AF, class EF>
 inline hipError_t launch_gemm_x6(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t stream,

@@ -33,6 +33,7 @@
 #include "wgradtr.hip.h"
 #include "c1wgrad.hip.h"
 #include "mlpstep.hip.h"
+#include "mlpact.hip.h"
 #include "comm.hip.h"
 #include "lstm.hip.h"
 
@@ -394,10 +395,11 @@ static bool x6_tr_staged(int N, const long long* dbg) { return !(x6_frag() && !d
 // mrl_set_option "x6_ktm" [MRL_X6_KTM, 1]: fc weight planes of the tiled split engine in k-tile-major order
 static int x6_ktm() { return get_option("x6_ktm", "MRL_X6_KTM", 1); }
 template <class AF, class EF>
-static hipError_t launch_x6_tr(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t st, long long* dbg, bool ktm = false) {
+static hipError_t launch_x6_tr(const AF& af, const uint16_t* Bp, const EF& ef, int M, int N, int K, hipStream_t st, long long* dbg, bool ktm = false,
+                               int nz = 1, long zslab = 0) {
     // (N <= 64: the 32 x 128 wave tiles of the fc layer measured slower -- fc1.fwd 1.94 -> 2.17 ms, fc1.dgrad 2.39 -> 2.52 -- unless bit 3 asks)
-    if (!x6_tr_staged(N, dbg)) return ktm ? hipErrorInvalidValue : launch_gemm_x6r(af, Bp, ef, M, N, K, st);
-    return launch_gemm_x6_planes<false, true>(af, 0, Bp, ef, M, N, K, st, dbg, ktm);
+    if (!x6_tr_staged(N, dbg)) return (ktm || nz > 1) ? hipErrorInvalidValue : launch_gemm_x6r(af, Bp, ef, M, N, K, st);
+    return launch_gemm_x6_planes<false, true>(af, 0, Bp, ef, M, N, K, st, dbg, ktm, nz, zslab);
 }
 static int x6_specialised() { return kExp ? get_option("x6_spec", "MRL_X6_SPEC", 0) : 0; }
 // phase-stamp / phase-omission knobs exist in experiment builds only
@@ -411,7 +413,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -1967,6 +1969,24 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
                 if (trf) {      // transposed-accumulator epilogue (16-byte stores), no mask / planes needed above an fc layer
                     TrBiasRelu tf{hout, l.N, bias, nullptr, nullptr, 0};
                     long long* dbgq = dbg_option("x6_dbg", "MRL_X6_DBG") == 1 ? dbgbuf : nullptr;
+                    // act batches (round 6): 128 x 128 tiles of a 4096-sample step are 128 workgroups for 512 slots, each walking all
+                    // of K = 3136 alone (163 us per env step of the N = 4096 rollout).  Split K over blockIdx.y into partial slabs and
+                    // finish with the bias / ReLU pass of the small-batch path.
+                    {
+                        const long tiles = (long)((B + 127) / 128) * ((l.N + 127) / 128);
+                        int nz = (int)std::min<long>(4, (2L * num_cus()) / std::max<long>(1, tiles));
+                        nz = std::min(nz, l.K / 512);
+                        const long slabz = (long)B * l.N;
+                        if (nz >= 2 && !pa && !dbgq && part && (size_t)nz * slabz <= part_floats && x6_tr_staged(l.N, dbgq) &&
+                            get_option("x6_splitk", "MRL_X6_SPLITK", 1)) {
+                            TrPartial tp{part, l.N};
+                            hipError_t e2 = launch_x6_tr(X6DenseA{hprev, (long)l.K}, planes, tp, B, l.N, l.K, st, nullptr, ktm, nz, slabz);
+                            if (e2 != hipSuccess) return (int)e2;
+                            hipLaunchKernelGGL(splitk_bias_act_kernel, dim3((unsigned)std::min<long>((slabz + 255) / 256, 2048)), dim3(256), 0, st,
+                                               part, slabz, nz, bias, l.act, hout, slabz, l.N);
+                            return (int)hipGetLastError();
+                        }
+                    }
                     if constexpr (EXP) {
                         if (pa) return (int)launch_gemm_x6_planes<true, true>(X6DenseA{reinterpret_cast<const float*>(hprev_p), (long)l.K},
                                                                               (long)B * l.K, planes, tf, B, l.N, l.K, st, dbgq);
@@ -2499,6 +2519,9 @@ static void fill_head_args(const mrl_model* m, const float* params, const Ws& ws
     for (int i = 0; i < 16; ++i) a.nvec[i] = m->d.nvec[i];
 }
 
+static bool wave_heads_shape(const HeadArgs& a) {
+    return a.has_pi_head && a.shared && a.pd_kind == MRL_PD_CATEGORICAL && a.nact <= 8 && a.nlat == 512;
+}
 static int pick_ts(HeadArgs& a, bool train) {
     HeadLds L;
     for (int ts : {32, 16, 8, 4}) {
@@ -2527,7 +2550,27 @@ static int model_act_impl(const mrl_model* m, const float* params, const void* o
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int Bc = std::min(chunk, n - c0);
         In in{(const char*)obs + (size_t)c0 * ob_bytes, nullptr};
-        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st, ws.part, ws.part_floats);       // (split-K fc layers at act batch sizes)
+        int rc = 0;
+        // the 2 x 64 tanh MLP on float observations: both layers of both nets in one launch (mlpact.hip.h; bit-identical latents)
+        const mrl_model_desc& d = m->d;
+        const bool mlp_act = get_option("mlp_act", "MRL_MLP_ACT", 1) && d.network == MRL_NET_MLP && d.num_layers == 2 && !d.layer_norm &&
+                             d.num_hidden == 64 && d.activation == MRL_ACT_TANH && d.ob_dtype != MRL_OB_U8 && !m->pi.lstm &&
+                             m->pi.L.size() == 2 && (!m->vf_copy || m->vf.L.size() == 2) && m->pi.L[0].kind == 1 &&
+                             mlp_act_lds_bytes((int)m->ob_elems, 4, 2) <= 64 * 1024;
+        if (mlp_act) {
+            MlpActArgs ma;
+            ma.params = params; ma.obs = (const float*)in.obs; ma.K0 = (int)m->ob_elems; ma.n = Bc; ma.nets = m->vf_copy ? 2 : 1;
+            const Net* nets2[2] = {&m->pi, m->vf_copy ? &m->vf : &m->pi};
+            for (int q = 0; q < 2; ++q) {
+                ma.w0[q] = nets2[q]->L[0].w_off; ma.b0[q] = nets2[q]->L[0].b_off;
+                ma.w1[q] = nets2[q]->L[1].w_off; ma.b1[q] = nets2[q]->L[1].b_off;
+            }
+            ma.lat[0] = ws.pi.h.back(); ma.lat[1] = m->vf_copy ? ws.vf.h.back() : ws.pi.h.back();
+            ProfScope ps("mlp_act", 2.0 * Bc * ma.nets * (double)(ma.K0 * 64 + 64 * 64), 0.0, st);
+            hipError_t e = launch_mlp_act_latent(ma, st);
+            if (e != hipSuccess) return (int)e;
+        } else {
+        rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st, ws.part, ws.part_floats);       // (split-K fc layers at act batch sizes)
         if (rc) return rc;
         if (m->pi.lstm) {      // one step of Bc independent sequences (policies.py:77-96 with S, M fed; act model nsteps = 1)
             const int ss = 2 * m->pi.nh;
@@ -2539,9 +2582,16 @@ static int model_act_impl(const mrl_model* m, const float* params, const void* o
             rc = net_forward(m, m->vf, in, params, ws.vf, Bc, st);
             if (rc) return rc;
         }
+        }
         HeadArgs a;
         fill_head_args(m, params, ws, a);
         if ((rc = pick_ts(a, false))) return rc;
+        // act side of narrow latents (the MLP nets): a tile's samples are finished by one thread each, so 32-sample tiles leave a
+        // 1024-env step on 32 workgroups walking serial expf / logf chains -- smaller tiles spread it over the chip (round 6:
+        // heads_act 25 -> see profiles/README.md)
+        if (a.nlat <= 128 && !wave_heads_shape(a)) {
+            while (a.TS > 4 && (Bc + a.TS - 1) / a.TS < 2 * num_cus()) a.TS >>= 1;
+        }
         a.Bc = Bc; a.row0 = c0;
         a.noise = noise; a.actions_out = actions_out; a.values_out = values_out; a.neglogp_out = neglogp_out;
         a.pdparam_out = pdparam_out;

@@ -67,6 +67,17 @@ struct TrBiasRelu {          // h = relu(acc + bias[c])  (+ ReLU bit mask of h, 
         return v;
     }
 };
+struct TrPartial {           // plain partial sums of a split-K launch (combined by splitk_bias_act_kernel, model.hip)
+    float* out; long ld;
+    static constexpr uint32_t* mask = nullptr;
+    static constexpr uint16_t* hp = nullptr;
+    static constexpr long pstride = 0;
+    __device__ __forceinline__ TrAux load_aux(long, int, int, bool) const { TrAux x; x.w = 0; return x; }
+    __device__ __forceinline__ float4 apply(const TrAux&, int, int, float4 a, float sg) const {
+        a.x *= sg; a.y *= sg; a.z *= sg; a.w *= sg;
+        return a;
+    }
+};
 struct TrMaskRelu {          // dz = acc * relu'(h) with h the fp32 output of the layer below, or its bit mask, or nothing
     float* out; long ld; const float* h; const uint32_t* hbits; uint16_t* hp; long pstride;
     static constexpr uint32_t* mask = nullptr;

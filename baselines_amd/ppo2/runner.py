@@ -132,29 +132,38 @@ class Runner(AbstractEnvRunner):
         T = self.nsteps
         fin_r, fin_l = [], []
         ro.obs[0].copy_(self.obs)                      # cursor -> slot 0
-        nxt_last = self.obs                            # reused as the landing buffer of the last step
+        ro.dones[0].copy_(self._dones_dev)             # ... the dones that entered the rollout likewise; the env then writes the
+        nxt_last = self.obs                            # dones of step t straight into slot t + 1 (no copy per step)
         if self.recurrent:
             self._mb_states = self._states_dev.clone()     # runner.py:23 mb_states = self.states (state BEFORE the rollout)
+        # the stock Model's sampling noise for all T steps in ONE generator call (its per-step launch was a tenth of an MLP env step;
+        # same distribution, the Philox stream is consumed in one piece instead of T); wrapped / subclassed models keep their own
+        from .model import Model
+        noise_all = None
+        if type(self.model) is Model and not self.recurrent and hasattr(self.model, 'make_noise'):
+            noise_all = self.model.make_noise(T * self.nenv).reshape(T, self.nenv, -1)
         for t in range(T):
             if self._ob_clip:                          # normalize_observations: the rollout holds the clipped observations
                 ro.obs[t].clamp_(-self._ob_clip, self._ob_clip)
             if self.recurrent:                         # runner.py:28 step(obs, S=self.states, M=self.dones)
                 self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t], states=self._states_dev,
-                                     masks=self._dones_dev)
+                                     masks=ro.dones[t])
+            elif noise_all is not None:
+                self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t], noise=noise_all[t])
             else:
                 self.model.step_into(ro.obs[t], ro.actions[t], ro.values[t], ro.neglogpacs[t])
-            ro.dones[t].copy_(self._dones_dev)
             obs_out = ro.obs[t + 1] if t + 1 < T else nxt_last
+            done_out = ro.dones[t + 1] if t + 1 < T else self._dones_dev
             if self._env_step_into:
                 _, _, _, info = self.env.step_into(ro.actions[t], obs_out=obs_out, rew_out=ro.rewards[t],
-                                                   done_out=self._dones_dev)
+                                                   done_out=done_out)
             else:
                 # device-resident env behind wrappers (VecNormalize, VecFrameStack, ...): the wrapper chain runs its own
                 # kernels in step_wait(); its results are copied (device to device) into the rollout slot
                 o, r, d, info = self.env.step(ro.actions[t])
                 obs_out.copy_(o.reshape(obs_out.shape))
                 ro.rewards[t].copy_(r)
-                self._dones_dev.copy_(d.view(torch.uint8) if d.dtype == torch.bool else d)
+                done_out.copy_(d.view(torch.uint8) if d.dtype == torch.bool else d)
                 if not isinstance(info, dict) or 'fin_r' not in info:
                     info = {'fin_r': torch.zeros_like(ro.rewards[t]), 'fin_l': torch.zeros_like(ro.actions[t], dtype=torch.int32).reshape(-1)[:self.nenv]}
             fin_r.append(info['fin_r'])

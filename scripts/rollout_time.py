@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Act side at shard sizes: wall time of one device rollout (nsteps act forwards + synthetic env step + rollout
 store, replayed as a hipGraph) next to one update, Atari-shaped NatureCNN.
-    python scripts/rollout_time.py [num_envs] [nsteps]        (under rocprofv3 --kernel-trace: per-kernel times of the act path)"""
+    python scripts/rollout_time.py [num_envs] [nsteps] [atari|mujoco]     (under rocprofv3 --kernel-trace: per-kernel times of the act path)"""
 import os
 import sys
 import time
@@ -17,10 +17,11 @@ from baselines_amd.ppo2 import Model, Runner  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+KIND = sys.argv[3] if len(sys.argv) > 3 else 'atari'
 torch.cuda.set_device(0)
 set_global_seeds(0)
-env = SyntheticVecEnv('atari', N, seed=1)
-policy = build_policy(env, 'cnn')
+env = SyntheticVecEnv(KIND, N, seed=1)
+policy = build_policy(env, 'cnn') if KIND == 'atari' else build_policy(env, 'mlp', value_network='copy')
 model = Model(policy=policy, ob_space=env.observation_space, ac_space=env.action_space, nbatch_act=N,
               nbatch_train=N * T // 4, nsteps=T, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
 runner = Runner(env=env, model=model, nsteps=T, gamma=0.99, lam=0.95, return_host=False)

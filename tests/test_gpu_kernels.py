@@ -556,3 +556,38 @@ def test_conv1_forward_engines_are_bit_identical(B):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('cfg', [dict(ob=376, pd='gaussian', nact=17, copy=True, n=1024), dict(ob=376, pd='gaussian', nact=17, copy=True, n=37),
+                                 dict(ob=11, pd='gaussian', nact=3, copy=False, n=200), dict(ob=4, pd='categorical', nact=2, copy=False, n=8),
+                                 dict(ob=27, pd='categorical', nact=5, copy=True, n=1001)])
+def test_fused_mlp_act_agrees_with_the_layer_wise_path(cfg):
+    """Act side of the 2 x 64 tanh MLP (common/models.py:74-103 behind policies.py:77-96 step()): the one-launch forward of both
+    layers of both nets (csrc/mlpact.hip.h, option mlp_act) forms fp32 products and fp32 sums like the layer-wise path; the order
+    of the sums differs (the tiled GEMM splits K over partial slabs at act batch sizes), so values, neglogp and pdparam agree to
+    2e-6 and categorical actions exactly; odd observation widths, shared and separate value nets, ragged last workgroups."""
+    from baselines_amd import _lib as L
+    from baselines_amd import ops
+    r = np.random.RandomState(cfg['ob'] + cfg['n'])
+    old = L.get_option('mlp_act')
+    outs = []
+    try:
+        for v in (1, 0):
+            L.set_option('mlp_act', v)
+            dm = ops.DeviceModel(network='mlp', ob_shape=(cfg['ob'],), ob_dtype=np.float32, pd_kind=cfg['pd'], nact=cfg['nact'],
+                                 value_copy=cfg['copy'], chunk=cfg['n'])
+            if v == 1:
+                params = dev((r.randn(dm.P) * 0.1).astype(np.float32))
+                obs = dev(r.randn(cfg['n'], cfg['ob']).astype(np.float32))
+                noise = dev((r.rand(cfg['n'], cfg['nact']) if cfg['pd'] == 'categorical' else r.randn(cfg['n'], cfg['nact'])).astype(np.float32))
+            a, vv, nlp, pd = dm.act(params, obs, noise, want_pdparam=True)
+            outs.append((a.cpu(), vv.cpu(), nlp.cpu(), pd.cpu()))
+    finally:
+        L.set_option('mlp_act', old)
+    assert bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
+    for q, (x, y) in enumerate(zip(outs[0], outs[1])):
+        assert x.dtype == y.dtype and x.shape == y.shape
+        if q == 0 and cfg['pd'] == 'categorical':
+            assert float((x != y).float().mean()) <= 0.002           # (an argmax over Gumbel-perturbed logits can flip on a 1e-7 tie)
+        else:
+            assert float((x.double() - y.double()).abs().max()) <= 2e-6 * max(1.0, float(y.double().abs().max()))
