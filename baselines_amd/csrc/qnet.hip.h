@@ -22,6 +22,16 @@ struct mrl_qnet {
     int nlat, lat_act;
     bool dueling;
     std::vector<int> init_kind;     // per tensor: 0 zeros, 1 orthogonal (scale in base.tensors), 2 xavier uniform
+    // learner step (round 6): the target network's forward pass runs on a side stream next to the online network's (every kernel of a
+    // batch-32 step is latency-bound on a handful of workgroups); created on the first eager mrl_qnet_td_grad call
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    mutable bool side_failed = false;
+    ~mrl_qnet() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 static long q_add_tensor(mrl_qnet* q, const std::string& name, std::vector<int> shape, int kind, double scale) {
@@ -132,7 +142,8 @@ struct QWs {
     float* zeros;
     size_t total;
 };
-constexpr int Q_SQ_BLOCKS = 64;      // partial blocks per tensor
+// sum-of-squares partials of the per-variable clip: one per Q_CHUNK-element chunk of every tensor (q_sumsq_kernel)
+static size_t q_sq_parts(const mrl_qnet* q) { return (size_t)(q->base.P / 4096 + (long)q->base.tensors.size() + 1); }
 
 static void q_carve(const mrl_qnet* q, int B, char* base, QWs& ws) {
     size_t off = 0;
@@ -159,7 +170,7 @@ static void q_carve(const mrl_qnet* q, int B, char* base, QWs& ws) {
     ws.part = (float*)take(part_floats * 4);
     ws.part_floats = part_floats;
     ws.td_scratch = take(mrl_dqn_td_scratch_bytes(B));
-    ws.sqpart = (double*)take((size_t)q->base.tensors.size() * Q_SQ_BLOCKS * 8);
+    ws.sqpart = (double*)take(q_sq_parts(q) * 8);
     ws.zeros = (float*)take(2048);
     ws.total = off;
 }
@@ -246,45 +257,86 @@ struct EpiAddMaskAct {
     }
 };
 
-struct QTensorTable { int n; long off[40]; long size[40]; };
+// Round 6: the per-variable clip + Adam pair walked every tensor with a fixed 64 blocks of scalar accesses -- the two 7744 x 256 head
+// matrices of the dueling conv_only net are 95 % of the parameters, so 128 of the ~900 blocks did nearly all the work in 121
+// dependent iterations each (q_adam 60 us + q_sumsq 37 us of a 830 us learner step).  Now a block owns one CHUNK of Q_CHUNK
+// consecutive elements of one tensor (16-byte accesses; tensors start 16-byte aligned or fall back to scalars): the table maps
+// chunk -> tensor by prefix sums, big tensors get many blocks, small ones one.
+constexpr int Q_CHUNK = 4096;
+struct QTensorTable { int n; long off[40]; long size[40]; int cbeg[41]; };      // cbeg[t]: first chunk of tensor t; cbeg[n]: chunks in all
+__device__ __forceinline__ int q_chunk_tensor(const QTensorTable& tt, int c) {
+    int t = 0;
+    while (t + 1 < tt.n && c >= tt.cbeg[t + 1]) ++t;
+    return t;
+}
 __global__ __launch_bounds__(256) void q_sumsq_kernel(const float* __restrict__ g, QTensorTable tt, double* __restrict__ part) {
     __shared__ double sh[4];
-    const int t = blockIdx.y;
+    const int c = blockIdx.x, t = q_chunk_tensor(tt, c);
+    const long lo = (long)(c - tt.cbeg[t]) * Q_CHUNK, hi = min(tt.size[t], lo + Q_CHUNK);
     const float* p = g + tt.off[t];
     double s = 0.0;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < tt.size[t]; i += (long)gridDim.x * 256L) s += (double)p[i] * (double)p[i];
+    if ((tt.off[t] & 3) == 0) {
+        const long lo4 = lo, n4 = (hi - lo) / 4;
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + lo4 + 4 * i);
+            s += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+        }
+        for (long i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256) s += (double)p[i] * (double)p[i];
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) s += (double)p[i] * (double)p[i];
+    }
     const double r = block_sum_256(s, sh);
-    if (threadIdx.x == 0) part[t * gridDim.x + blockIdx.x] = r;
+    if (threadIdx.x == 0) part[c] = r;
 }
 // per-variable tf.clip_by_norm (build_graph.py:416-421: t * clip / max(||t||, clip)) then TF-1 ApplyAdam
 __global__ __launch_bounds__(256) void q_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, QTensorTable tt, const double* __restrict__ part,
-                                                     int npart, float alpha, const float* __restrict__ alpha_dev, float beta1,
+                                                     float alpha, const float* __restrict__ alpha_dev, float beta1,
                                                      float beta2, float eps, float clip) {
+    __shared__ double sh[4];
     __shared__ float s_scale;
-    const int t = blockIdx.y;
+    const int c = blockIdx.x, t = q_chunk_tensor(tt, c);
     if (alpha_dev) alpha = alpha_dev[0];      // step size kept in device memory (replayable launch graphs)
-    if (threadIdx.x == 0) {
-        float scale = 1.f;
-        if (clip > 0.f) {
-            double s = 0.0;
-            for (int i = 0; i < npart; ++i) s += part[t * npart + i];
-            const float nrm = (float)sqrt(s);
-            scale = clip / fmaxf(nrm, clip);
+    float scale = 1.f;
+    if (clip > 0.f) {                         // the tensor's chunk partials in a fixed order: every block of the tensor forms the same sum
+        double s = 0.0;
+        for (int i = tt.cbeg[t] + (int)threadIdx.x; i < tt.cbeg[t + 1]; i += 256) s += part[i];
+        const double tot = block_sum_256(s, sh);
+        if (threadIdx.x == 0) {
+            const float nrm = (float)sqrt(tot);
+            s_scale = clip / fmaxf(nrm, clip);
         }
-        s_scale = scale;
+        __syncthreads();
+        scale = s_scale;
     }
-    __syncthreads();
-    const float scale = s_scale, omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
     const long o = tt.off[t];
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < tt.size[t]; i += (long)gridDim.x * 256L) {
-        const float x = g[o + i] * scale;
-        g[o + i] = x;
-        float mi = m[o + i], vi = v[o + i];
+    const long lo = (long)(c - tt.cbeg[t]) * Q_CHUNK, hi = min(tt.size[t], lo + Q_CHUNK);
+    auto upd = [&](float gi, float& mi, float& vi, float& pi) {
+        const float x = gi * scale;
         mi = mi + (x - mi) * omb1;
         vi = vi + (x * x - vi) * omb2;
-        m[o + i] = mi; v[o + i] = vi;
-        p[o + i] = p[o + i] - (mi * alpha) / (sqrtf(vi) + eps);
+        pi = pi - (mi * alpha) / (sqrtf(vi) + eps);
+        return x;
+    };
+    long i0 = lo;
+    if ((o & 3) == 0) {
+        const long n4 = (hi - lo) / 4;
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            const long e = o + lo + 4 * i;
+            float4 g4 = *reinterpret_cast<float4*>(g + e), m4 = *reinterpret_cast<float4*>(m + e), v4 = *reinterpret_cast<float4*>(v + e),
+                   p4 = *reinterpret_cast<float4*>(p + e);
+            g4.x = upd(g4.x, m4.x, v4.x, p4.x); g4.y = upd(g4.y, m4.y, v4.y, p4.y);
+            g4.z = upd(g4.z, m4.z, v4.z, p4.z); g4.w = upd(g4.w, m4.w, v4.w, p4.w);
+            *reinterpret_cast<float4*>(g + e) = g4; *reinterpret_cast<float4*>(m + e) = m4;
+            *reinterpret_cast<float4*>(v + e) = v4; *reinterpret_cast<float4*>(p + e) = p4;
+        }
+        i0 = lo + 4 * n4;
+    }
+    for (long i = i0 + threadIdx.x; i < hi; i += 256) {
+        float mi = m[o + i], vi = v[o + i], pi = p[o + i];
+        g[o + i] = upd(g[o + i], mi, vi, pi);
+        m[o + i] = mi; v[o + i] = vi; p[o + i] = pi;
     }
 }
 
@@ -396,16 +448,61 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
         return MRL_EINVAL;
     if (q->base.pi.L.empty()) return MRL_EUNSUP;
     hipStream_t st = (hipStream_t)stream;
-    QWs ws;
-    q_carve(q, B, (char*)workspace, ws);
-    if (ws.total > workspace_bytes) return MRL_ENOSPC;
     const int nA = q->qd.nact;
+    const size_t ob_bytes = (size_t)q->base.ob_elems * (q->qd.ob_dtype == MRL_OB_U8 ? 1 : 4);
     int rc;
-    // the two obs_tp1 passes first (their activations are not needed again), then obs_t whose activations feed the backward
-    if ((rc = q_forward(q, target_params, obs_tp1, B, ws, ws.q_tp1, st))) return rc;
-    if (double_q && (rc = q_forward(q, params, obs_tp1, B, ws, ws.q_tp1_on, st))) return rc;
-    if ((rc = q_forward(q, params, obs_t, B, ws, ws.q_t, st))) return rc;
-    if ((rc = mrl_dqn_td(ws.q_t, ws.q_tp1, double_q ? ws.q_tp1_on : nullptr, act, rew, done, weights, gamma, B, nA, td_out,
+    // Round 6.  (a) Double-Q evaluates the ONLINE network on obs_t and on obs_tp1 (build_graph.py:393-398): when the caller hands
+    // the two batches over back to back, they go through the network as ONE batch of 2 B (rows 0 .. B-1 = obs_t, whose activations
+    // feed the backward pass) -- one pass of latency-bound launches fewer.  (b) The TARGET network's pass is independent of both:
+    // with room for a second workspace it runs on a side stream next to the online pass (fork / join with events; the caller's
+    // stream -- and a graph captured from it -- sees one step).  Both need a workspace sized for it (qmodel.py allocates
+    // mrl_qnet_workspace_bytes(2 B) + mrl_qnet_workspace_bytes(B)); otherwise the three passes run one after the other as before.
+    const bool contiguous = (const char*)obs_tp1 == (const char*)obs_t + (size_t)B * ob_bytes;
+    QWs ws, wt;
+    q_carve(q, 2 * B, (char*)workspace, ws);
+    q_carve(q, B, nullptr, wt);
+    const bool roomy = ws.total + wt.total + 256 <= workspace_bytes && get_option("dqn_overlap", "MRL_DQN_OVERLAP", 1);
+    const bool merged = roomy && double_q && contiguous;
+    if (!roomy) {
+        q_carve(q, B, (char*)workspace, ws);
+        if (ws.total > workspace_bytes) return MRL_ENOSPC;
+    } else {
+        q_carve(q, B, (char*)workspace + ((ws.total + 255) & ~(size_t)255), wt);
+    }
+    bool par = roomy && !prof_enabled() && !q->side_failed;
+    if (par && !q->side) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) par = false;      // not while capturing
+        else {
+            hipError_t e = hipStreamCreateWithFlags(&q->side, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_join, hipEventDisableTiming);
+            if (e != hipSuccess) { q->side_failed = true; par = false; (void)hipGetLastError(); }
+        }
+    }
+    QWs& wtr = roomy ? wt : ws;
+    if (par) {
+        MRL_HIP_CHECK(hipEventRecord(q->ev_fork, st));
+        MRL_HIP_CHECK(hipStreamWaitEvent(q->side, q->ev_fork, 0));
+        if ((rc = q_forward(q, target_params, obs_tp1, B, wtr, wtr.q_tp1, q->side))) return rc;
+        MRL_HIP_CHECK(hipEventRecord(q->ev_join, q->side));
+    } else {
+        // the obs_tp1 passes first (their activations are not needed again), then obs_t whose activations feed the backward
+        if ((rc = q_forward(q, target_params, obs_tp1, B, wtr, wtr.q_tp1, st))) return rc;
+    }
+    const float* q_tp1_on = nullptr;
+    if (merged) {
+        if ((rc = q_forward(q, params, obs_t, 2 * B, ws, ws.q_t, st))) return rc;
+        q_tp1_on = ws.q_t + (size_t)B * nA;
+    } else {
+        if (double_q) {
+            if ((rc = q_forward(q, params, obs_tp1, B, ws, ws.q_tp1_on, st))) return rc;
+            q_tp1_on = ws.q_tp1_on;
+        }
+        if ((rc = q_forward(q, params, obs_t, B, ws, ws.q_t, st))) return rc;
+    }
+    if (par) MRL_HIP_CHECK(hipStreamWaitEvent(st, q->ev_join, 0));
+    if ((rc = mrl_dqn_td(ws.q_t, wtr.q_tp1, q_tp1_on, act, rew, done, weights, gamma, B, nA, td_out,
                          loss_out, ws.dq, ws.td_scratch, stream)))
         return rc;
     hipLaunchKernelGGL(q_dueling_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.dq, ws.av.dz.back(),
@@ -433,19 +530,24 @@ extern "C" int mrl_qnet_adam_step(const mrl_qnet* q, float* params, float* grads
     QTensorTable tt;
     tt.n = (int)q->base.tensors.size();
     if (tt.n > 40) return MRL_EUNSUP;
+    int nchunks = 0;
     for (int i = 0; i < tt.n; ++i) {
         const TensorInfo& t = q->base.tensors[i];
         long n = 1;
         for (int k = 0; k < t.ndim; ++k) n *= t.shape[k];
         tt.off[i] = t.off; tt.size[i] = n;
+        tt.cbeg[i] = nchunks;
+        nchunks += (int)((n + Q_CHUNK - 1) / Q_CHUNK);
     }
+    tt.cbeg[tt.n] = nchunks;
+    if ((size_t)nchunks > q_sq_parts(q)) return MRL_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     if (grad_norm_clipping > 0.f) {
-        hipLaunchKernelGGL(q_sumsq_kernel, dim3(Q_SQ_BLOCKS, tt.n), dim3(256), 0, st, grads, tt, ws.sqpart);
+        hipLaunchKernelGGL(q_sumsq_kernel, dim3(nchunks), dim3(256), 0, st, grads, tt, ws.sqpart);
         MRL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(q_adam_kernel, dim3(Q_SQ_BLOCKS, tt.n), dim3(256), 0, st, params, grads, adam_m, adam_v, tt, ws.sqpart,
-                       Q_SQ_BLOCKS, alpha, alpha_dev, beta1, beta2, eps, grad_norm_clipping);
+    hipLaunchKernelGGL(q_adam_kernel, dim3(nchunks), dim3(256), 0, st, params, grads, adam_m, adam_v, tt, ws.sqpart,
+                       alpha, alpha_dev, beta1, beta2, eps, grad_norm_clipping);
     MRL_LAUNCH_CHECK();
     return 0;
 }

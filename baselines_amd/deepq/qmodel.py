@@ -139,7 +139,10 @@ class QModel(object):
     def _set_batch(self, n):
         if n > self.max_batch:
             self.max_batch = int(n)
-            nbytes = int(self.lib.mrl_qnet_workspace_bytes(self.handle, self.max_batch))
+            # room for the learner step's merged online pass (2 B rows) plus a second workspace for the target network's pass on
+            # its side stream (csrc/qnet.hip.h, mrl_qnet_td_grad)
+            nbytes = (int(self.lib.mrl_qnet_workspace_bytes(self.handle, 2 * self.max_batch))
+                      + int(self.lib.mrl_qnet_workspace_bytes(self.handle, self.max_batch)) + 1024)
             self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
 
     def __del__(self):
@@ -293,12 +296,14 @@ class QModel(object):
         self._set_batch(B)
         if not graph or os.environ.get('MRL_DQN_GRAPH', '1') == '0' or _lib.prof_enabled():
             td = torch.empty(B, dtype=torch.float32, device=self.device)
-            self._step_launches(obs_t, action, reward, obs_tp1, done, weight, td, B, self._next_alpha(), None)
+            o12 = torch.cat([obs_t, obs_tp1], dim=0)     # back to back: the same merged online pass as the replayed graph (bit-identical)
+            self._step_launches(o12[:B], action, reward, o12[B:], done, weight, td, B, self._next_alpha(), None)
             self.last_td = td
             return td
         g = self._graphs.get(B)
         if g is None:
-            g = dict(o1=torch.empty_like(obs_t), o2=torch.empty_like(obs_tp1),
+            o12 = torch.empty((2 * B,) + tuple(obs_t.shape[1:]), dtype=obs_t.dtype, device=self.device)    # obs_t | obs_tp1 back to back:
+            g = dict(o1=o12[:B], o2=o12[B:],                                                                # one online pass of 2 B rows
                      a=torch.empty(B, dtype=torch.int32, device=self.device),
                      r=torch.empty(B, dtype=torch.float32, device=self.device),
                      d=torch.empty(B, dtype=torch.float32, device=self.device),
