@@ -415,13 +415,20 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
                    else model.value_dev(runner.obs))
 
     # self-check: gradient + statistics of one minibatch of the benched shape, computed in the benched
-    # chunking (one 131072-sample chunk) and again in 8192-sample chunks -- the size the parity suite verifies against the
-    # oracle entry by entry -- must agree to 1e-5 (stats); gradient: reported per entry, guarded against gross errors (see below)
+    # chunking (one 131072-sample chunk) and again in 15360-sample chunks must agree: statistics to 1e-5, EVERY gradient entry to 1e-5
+    # of the gradient's scale.
+    # Why 15360: the class-resident conv forward alternates the sign of staged rows over tiles of 3 (conv2) / 5 (conv3) whole images
+    # (DESIGN.md 3.1 / 3.7), so the last bits of its output depend on where an image sits in its tile.  With a chunk size that 3, 5, 128
+    # and 256 divide (15360; the 8192-sample remainder starts at sample 122880 = 15 * 8192) every image keeps its tile position and the
+    # two chunkings differ only in the order of the per-chunk weight-gradient sums (~1e-7 of the scale).  Round 5 compared against chunk
+    # 8192 (8192 % 3 = 2): a ReLU unit whose pre-activation is zero to rounding then took different sides in the two runs, and the
+    # gradient bound had to be relaxed to a gross-error guard (1e-3) -- which a subtly wrong tile could have hidden behind.
     self_check = None
-    if workload == 'atari' and world == 1 and nbatch_train > 8192 and os.environ.get('MRL_BENCH_SELF_CHECK', '1') != '0':
+    SC_CHUNK = 15360
+    if workload == 'atari' and world == 1 and nbatch_train > SC_CHUNK and os.environ.get('MRL_BENCH_SELF_CHECK', '1') != '0':
         ops.gae(ro.rewards, ro.values, ro.dones, last_values, runner._dones_dev, 0.99, 0.95, out=ro.returns)
         idx = torch.from_numpy(np.random.RandomState(7).permutation(nbatch)[:nbatch_train]).to(model.device)
-        dm2 = ops.DeviceModel(chunk=8192, device=model.device, **policy.device_model_kwargs())
+        dm2 = ops.DeviceModel(chunk=SC_CHUNK, device=model.device, **policy.device_model_kwargs())
         outs = []
         for dmx in (model.dm, dm2):
             g = torch.empty(dmx.P, dtype=torch.float32, device=model.device)
@@ -431,23 +438,15 @@ def run_ppo2(workload, total_envs, T, steps, warmup, chunk, world, rank, comm, w
             outs.append((g, st5))
         gscale = float(outs[1][0].abs().max())
         diff = (outs[0][0] - outs[1][0]).double()
-        # Entry by entry the two chunkings agree to ~1e-7 of the gradient's scale EXCEPT where a ReLU unit's pre-activation is zero to
-        # rounding: since round 5 the conv forward alternates signs over the rows of whole-image tiles, tile positions
-        # depend on the chunk size, so the last bits of the forward do too, and such a unit takes a different side in the two chunkings --
-        # one sample's contribution to that unit's weight-gradient column moves (scripts/chunk_diff.py: num_envs=1024, one fc1 unit of one
-        # sample, 3e-5 of the scale; conv_x6c=0 or x6_dither=0 restores 8e-8).  Two correct fp32 implementations differ the same way on
-        # unscreened data (the parity suite screens ReLU margins with the fp64 oracle and then checks every entry).  So: statistics at the
-        # 1e-5 bar, and a gross-error guard on the gradient -- a wrong tile, slab or chunk boundary moves far more than a flipped unit.
-        self_check = {'what': 'mrl_model_grad of one %d-sample minibatch: chunk %d vs chunk 8192' % (nbatch_train, model.dm.chunk),
+        self_check = {'what': 'mrl_model_grad of one %d-sample minibatch: chunk %d vs chunk %d' % (nbatch_train, model.dm.chunk, SC_CHUNK),
                       'stats_max_abs_diff': float((outs[0][1] - outs[1][1]).abs().max()),
                       'grad_max_abs_diff_over_scale': float(diff.abs().max()) / gscale,
                       'grad_rel_l2_diff': float(diff.norm()) / float(outs[1][0].double().norm()),
                       'entries_above_1e-5_of_scale': int((diff.abs() > 1e-5 * gscale).sum()),
                       'entries': int(diff.numel()),
                       'grad_scale': gscale}
-        assert (self_check['stats_max_abs_diff'] <= 1e-5 and self_check['grad_max_abs_diff_over_scale'] <= 1e-3
-                and self_check['grad_rel_l2_diff'] <= 1e-3
-                and self_check['entries_above_1e-5_of_scale'] <= self_check['entries'] // 100), self_check
+        assert (self_check['stats_max_abs_diff'] <= 1e-5 and self_check['grad_max_abs_diff_over_scale'] <= 1e-5
+                and self_check['entries_above_1e-5_of_scale'] == 0), self_check
         del dm2, outs, g, st5
         torch.cuda.empty_cache()
 

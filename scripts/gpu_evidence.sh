@@ -2,7 +2,7 @@
 # round-end evidence of the CURRENT kernel sources on one box, without the parity suite (scripts/gpu_subset.sh / gpu_check.sh run that):
 # rocprofv3 kernel trace of the bench command, PMC passes over one epoch -> profiles-shaped JSON with the source hash, then the
 # driver-shaped `python bench.py` (which attaches the counter traffic because the JSON now matches the running sources).
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r05zz}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r06z}
 cd $R; mkdir -p $O
 (rocm-smi --showproductname 2>/dev/null | head -12; lscpu | head -20; free -g | head -2) > $O/${TAG}_box.txt 2>&1
 export TMPDIR=/tmp; cd /tmp
@@ -10,6 +10,8 @@ rm -rf $O/prof_$TAG
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-other-configs > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.err
 DB=$(ls $O/prof_$TAG/*.db $O/prof_$TAG/*/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $R/scripts/rocpd_stats.py $DB > $O/${TAG}_bench_atari4096_kernel_stats.txt 2>> $O/${TAG}_prof.err
+# the timed update alone (from its GAE launch on): per-kernel averages = the minibatch-shaped launches
+[ -n "$DB" ] && python $R/scripts/rocpd_stats.py $DB --window gae_ > $O/${TAG}_bench_atari4096_kernel_stats_timed_window.txt 2>> $O/${TAG}_prof.err
 rm -rf $O/prof_$TAG
 head -8 $O/${TAG}_bench_atari4096_kernel_stats.txt | cut -c1-150
 cd $R; bash scripts/pmc_epoch.sh 4096 > $O/${TAG}_pmc.log 2>&1; tail -3 $O/${TAG}_pmc.log
