@@ -671,16 +671,7 @@ inline hipError_t launch_c1fwd3(const void* obs, const int32_t* srow, const floa
         default: break;
     }
 #endif
-    // one driver call per selected variant, not per launch (the kernel is picked at run time: remember which were raised)
-    static const void* raised[8] = {nullptr};
-    bool seen = false;
-    int slot = 0;
-    for (; slot < 8 && raised[slot]; ++slot) seen = seen || raised[slot] == (const void*)kern;
-    if (!seen) {
-        hipError_t e0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e0 != hipSuccess) return e0;
-        if (slot < 8) raised[slot] = (const void*)kern;
-    }
+    { hipError_t e0 = raise_lds_limit((const void*)kern); if (e0 != hipSuccess) return e0; }      // once per (device, kernel)
     const size_t lds = (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * C1_IMG16;          // 163584
     const int grid = std::max(1, std::min(B, num_cus));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B);
@@ -692,12 +683,7 @@ inline hipError_t launch_c1fwd2(const void* obs, const int32_t* srow, const floa
                                 int B, int num_cus, hipStream_t stream, uint16_t* hp = nullptr, long pstride = 0, bool tr_plain = false) {
     const bool tr = hp || tr_plain;
     auto kern = tr ? c1fwd2_kernel<0, true> : c1fwd2_kernel<0, false>;
-    static bool raised[2] = {false, false};
-    if (!raised[tr ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised[tr ? 1 : 0] = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const size_t lds = (size_t)3 * 32 * C1_KP * 2 + (size_t)2 * C1_IMG16;          // 163584
     const int grid = std::max(1, std::min(B, num_cus));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, static_cast<const uint8_t*>(obs), srow, w, bias, out, mask, B, hp, pstride);
@@ -710,12 +696,7 @@ inline hipError_t launch_c1fwd_lds(const void* obs, const int32_t* srow, const f
                                    uint32_t* mask, int B, int num_cus, hipStream_t stream, int dbg = 0) {
     constexpr int G = 1, WAVES = 16;
     auto kern = c1fwd_lds_kernel<G, WAVES>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const int ngroups = (B + G - 1) / G;
     const int grid = std::max(1, std::min(ngroups, num_cus));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), c1fwd_lds_bytes(G), stream, static_cast<const uint8_t*>(obs), srow, w,

@@ -473,12 +473,7 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
 inline hipError_t launch_c1wgrad_half(const void* obs, const int32_t* srow, const float* dz, int B, float* part, int nblocks,
                                       hipStream_t stream, bool pf2 = false) {
     auto kern = pf2 ? c1wgrad_half_kernel<0, true> : c1wgrad_half_kernel<0, false>;
-    static bool raised[2] = {false, false};          // per variant: no driver call on the hot path / during graph capture
-    if (!raised[pf2 ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised[pf2 ? 1 : 0] = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CH_NT), CH_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part, x6_dither());
     return hipGetLastError();
 }
@@ -505,12 +500,7 @@ inline hipError_t launch_c1wgrad(const void* obs, const int32_t* srow, const flo
     }
 #endif
     auto kern = c1wgrad_kernel<DBG>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CW_NT), CW_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part);
     return hipGetLastError();
 }

@@ -36,6 +36,13 @@ __device__ __forceinline__ long envmajor_to_row(long i, int T, int N) { return (
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Kernels that need more than 64 KB of dynamic LDS raise their limit once PER DEVICE (the attribute belongs to the device's copy of the
+// function): one driver call per (device, kernel), none on the hot path or during graph capture afterwards; safe from several host
+// threads.  (Through round 5 every launcher kept a process-wide `static bool`: a second HIP device would have skipped the call.)
+hipError_t raise_lds_limit(const void* kern, int bytes = 160 * 1024);
+// option "gae_lane" (rollout.hip owns it; mrl_set_option in model.hip writes it)
+int& gae_lane_form();
+
 // ---- optional HIP-event profiler (mrl_prof_*): per-label launch count / time / algorithmic work.
 // Events are recorded on the launch stream itself; nothing synchronises until the report is read.
 bool prof_enabled();

@@ -298,12 +298,7 @@ inline hipError_t launch_conv_x6c(const float* x, const float* w, uint16_t* plan
         default: break;
     }
 #endif
-    static bool raised[8] = {false};
-    if (!raised[slot]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised[slot] = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const int ntiles = (B + G - 1) / G;
     const int grid = std::max(1, std::min(ntiles, 2 * num_cus));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Q::LDS_BYTES, stream, x, planes, ef, B, ntiles, x6_dither());

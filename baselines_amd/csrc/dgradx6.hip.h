@@ -729,12 +729,7 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
     if (per_xcd * 8 > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)3 * (BM + BN) * X6_LDK * sizeof(uint16_t);
     auto launch = [&](auto kern) {
-        static bool raised = false;                // per instantiation (one lambda instantiation per kernel type)
-        if (!raised) {
-            hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (er != hipSuccess) return er;
-            raised = true;
-        }
+        { hipError_t er = raise_lds_limit((const void*)kern); if (er != hipSuccess) return er; }      // once per (device, kernel)
         const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);      // two workgroups per CU
         hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, hmask, mbits,
                            dx, act, B, btiles, per_xcd, total, slots, dbg, x6_prio(), dzp, (long)B * G::OH * G::OW * NF, dxp,
@@ -744,13 +739,8 @@ inline hipError_t launch_dgrad_x6(const float* dz, const float* w, const float* 
     if constexpr (C % 32 == 0 && NTN == 1 && H % S == 0 && W % S == 0) {
         // round 6: the product configuration with exact wait counts around the epilogue stores (dgrad_x6 = 2, the default)
         if (pipe) {
-            static bool raised = false;
             auto kern = dgrad_x6p_kernel<H, W, C, RF, S, NF, WM, WN>;
-            if (!raised) {
-                hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (er != hipSuccess) return er;
-                raised = true;
-            }
+            { hipError_t er = raise_lds_limit((const void*)kern); if (er != hipSuccess) return er; }      // once per (device, kernel)
             const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8) * 2L);
             hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(256), lds, stream, dz, (const uint16_t*)planes, mbits, dx, B,
                                per_xcd, total, slots, x6_dither());

@@ -611,12 +611,7 @@ inline hipError_t launch_gemm(const AF& af, const BF& bf, const EF& ef, int M, i
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     auto kern = gemm_kernel<AF, BF, EF, WM, WN, TM, TN, DB>;
     if (lds > 64 * 1024) {
-        static bool raised = false;            // per instantiation
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
+        { hipError_t e = raise_lds_limit((const void*)kern, (int)lds); if (e != hipSuccess) return e; }      // once per (device, kernel)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, bf, ef, M, N, K, ksplit,
                        mtiles, ntiles, zdim);

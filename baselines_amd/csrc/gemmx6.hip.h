@@ -513,12 +513,7 @@ inline hipError_t launch_gemm_x6_cfg(const AF& af, const uint16_t* Bp, const EF&
         return launch_gemm_x6_cfg<AF, EF, WM, WN, X8, XD, PA, TR, ILV>(af, Bp, ef, M, N, K, dbg, stream, a_pstride, ktm, nz, zslab);
     }
     auto kern = gemm_x6_kernel<AF, EF, WM, WN, X8, XD, PA, TR, IL>;
-    static bool raised = false;                // per instantiation
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const int kz_tiles = nz > 1 ? (K / X6_BK + nz - 1) / nz : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)std::max(1, nz)), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, dbg,
                        x6_prio(), a_pstride, pg, x6_dither() | (ktm ? 8 : 0), kz_tiles, zslab);

@@ -230,12 +230,7 @@ inline hipError_t launch_gemm_x6r_cfg(const AF& af, const uint16_t* Bp, const EF
     if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)BM * X6R_PITCH * sizeof(float) + (size_t)3 * BN * X6_LDK * sizeof(uint16_t);
     auto kern = gemm_x6r_kernel<AF, EF, BN, VPM, PF>;
-    static bool raised = false;                // per instantiation
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, af, Bp, ef, M, N, K, mtiles, ntiles, pg, x6_dither());
     return hipGetLastError();
 }

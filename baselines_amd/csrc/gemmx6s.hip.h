@@ -317,12 +317,7 @@ inline hipError_t launch_x6s(const P& prob, const uint16_t* Bp, long total_tiles
     const long per_xcd = (total_tiles + 7) / 8;
     const int slots = (int)std::min<long>(per_xcd, std::max(1, num_cus / 8));        // one persistent workgroup per CU
     auto go = [&](auto kern) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
+        { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
         hipLaunchKernelGGL(kern, dim3((unsigned)(slots * 8)), dim3(512), lds, stream, prob, Bp, total_tiles, per_xcd, slots, dbg);
         return hipGetLastError();
     };

@@ -302,12 +302,7 @@ inline hipError_t launch_imgres_wgrad(const void* x, const int32_t* srow, const 
                                       float* part, int nblocks, hipStream_t stream) {
     using G = ImgResCfg<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW>;
     auto kern = imgres_wgrad_kernel<U8, H, W, C, RF, STRIDE, NF, WAVES, TMW, TNW, NACC>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVES * 64), G::LDS_BYTES, stream, x, srow, dz, hcur, B, part);
     return hipGetLastError();
 }
@@ -494,12 +489,7 @@ inline hipError_t launch_imgres_u8x3_wgrad(const void* x, const int32_t* srow, c
                                            int nblocks, hipStream_t stream) {
     using G = ImgResX3Cfg<H, W, C, RF, STRIDE, NF>;
     auto kern = imgres_u8x3_wgrad_kernel<H, W, C, RF, STRIDE, NF>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, srow, dz, B, part);
     return hipGetLastError();
 }

@@ -416,12 +416,7 @@ inline hipError_t launch_lds_dgrad_async(const float* dz, const float* w, const 
                                          int num_cus, long long* dbg, hipStream_t stream) {
     using K = LdsDgradAsyncCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
     auto kern = lds_dgrad_async_kernel<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const int ngroups = (B + G - 1) / G;
     int per_role = std::max(8, std::min(num_cus / K::ROLES, (ngroups + 7) / 8 * 8) / 8 * 8);   // multiple of 8 (XCD decode)
     hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, w, hprev, out, act, B, dbg);
@@ -433,12 +428,7 @@ inline hipError_t launch_lds_dgrad(const float* dz, const float* w, const float*
                                    int num_cus, long long* dbg, hipStream_t stream) {
     using K = LdsDgradCfg<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
     auto kern = lds_dgrad_kernel<H, W, C, RF, STRIDE, NF, G, WAVES, TMW>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const int ngroups = (B + G - 1) / G;
     int per_role = std::max(8, std::min(num_cus / K::ROLES, (ngroups + 7) / 8 * 8) / 8 * 8);   // multiple of 8 (XCD decode)
     hipLaunchKernelGGL(kern, dim3(per_role * K::ROLES), dim3(WAVES * 64), K::LDS_BYTES, stream, dz, w, hprev, out, act, B, dbg);

@@ -13,6 +13,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -386,6 +389,21 @@ static int act_planes_mode() {
     if (kExp) return get_option("act_planes", "MRL_ACT_PLANES", 76);
     return get_option("tr_epilogue", "MRL_TR_EPILOGUE", 1) ? 76 : 0;       // product: transposed-accumulator epilogues on / off
 }
+namespace mrl {
+hipError_t raise_lds_limit(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kern})) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kern});
+    return e;
+}
+}  // namespace mrl
+
 // wave-specialised (producer / consumer) form of the tiled split engines (gemmx6s.hip.h): measured NOT faster than the plain
 // form (two waves of one SIMD share its VALU issue and its matrix pipe: profiles/README.md), kept as an experiment knob
 // transposed-epilogue launches of the tiled split engine: split-at-the-fragment kernel (gemmx6r.hip.h, option x6_frag) or the
@@ -413,7 +431,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -441,6 +459,7 @@ extern "C" int mrl_set_option(const char* name, int value) {
             if (!strcmp(name, "conv_x6c")) conv_x6c() = value;
             if (!strcmp(name, "wgrad_pipe")) wgrad_tr_pipe() = value;
             if (!strcmp(name, "wgrad_xcd")) wgrad_tr_xcd() = value;
+            if (!strcmp(name, "gae_lane")) gae_lane_form() = value;
             if (!strcmp(name, "lstm_e1")) lstm_e1() = value;
             if (!strcmp(name, "x6_dbg")) x6_xd() = value >= 100 ? value - 100 : 0;
             return 0;
@@ -2740,12 +2759,8 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         a.slice = (nets == 2 && get_option("mlp_slice", "MRL_MLP_SLICE", 1)) ? 1 : 0;
         const int nwg = ntiles * (a.slice ? 2 : 1);
         const size_t lds = mlp_step_lds_bytes(K0, a.slice ? 1 : nets);
-        static bool raised = false;
-        if (!raised) {
-            MRL_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_step_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            MRL_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_step_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        MRL_HIP_CHECK(raise_lds_limit((const void*)mlp_step_kernel<512>));         // once per (device, kernel)
+        MRL_HIP_CHECK(raise_lds_limit((const void*)mlp_step_kernel<256>));
         {
             // algorithmic flops: fwd + bwd of both nets on B samples
             double fl = 0.0;
@@ -2813,21 +2828,9 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
             ProfScope ps("heads_loss", 0.0, (double)Bc * (8.0 * a.nlat + (a.shared ? 0 : 8.0 * a.nlatv) + 28.0), st);
             if (wave_ok) {
                 const size_t wl = (size_t)4 * m->HP * sizeof(float);
-                static bool raised = false;
-                if (!raised && wl > 64 * 1024) {
-                    hipError_t e = hipFuncSetAttribute((const void*)heads_train_wave_kernel<8>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e != hipSuccess) return (int)e;
-                    raised = true;
-                }
+                if (wl > 64 * 1024) MRL_HIP_CHECK(raise_lds_limit((const void*)heads_train_wave_kernel<8>));        // once per (device, kernel)
                 if (a.nact <= 6 && get_option("heads_wave", "MRL_HEADS_WAVE", 2) >= 2) {
-                    static bool raised2 = false;
-                    if (!raised2 && wl > 64 * 1024) {
-                        hipError_t e = hipFuncSetAttribute((const void*)heads_train_wave2_kernel<8, 6>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        if (e != hipSuccess) return (int)e;
-                        raised2 = true;
-                    }
+                    if (wl > 64 * 1024) MRL_HIP_CHECK(raise_lds_limit((const void*)heads_train_wave2_kernel<8, 6>));
                     hipLaunchKernelGGL((heads_train_wave2_kernel<8, 6>), dim3(nblk), dim3(256), wl, st, a);
                 } else {
                     hipLaunchKernelGGL(heads_train_wave_kernel<8>, dim3(nblk), dim3(256), wl, st, a);

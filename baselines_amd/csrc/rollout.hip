@@ -9,6 +9,10 @@ using namespace mrl;
 #include <string>
 #include <vector>
 
+namespace mrl {
+int& gae_lane_form() { static int v = getenv("MRL_GAE_LANE") ? atoi(getenv("MRL_GAE_LANE")) : 1; return v; }
+}
+
 extern "C" int mrl_version(void) { return MRL_VERSION; }
 
 // ------------------------------------------------------------------------------------------
@@ -278,9 +282,9 @@ extern "C" int mrl_gae(const float* rew, const float* val, const uint8_t* done, 
                        int T, int N, void* stream) {
     if (T <= 0 || N <= 0 || !rew || !val || !done || !last_val || !last_done || !ret_out) return MRL_EINVAL;
     ProfScope ps("gae", 0.0, 17.0 * T * N + 9.0 * N, (hipStream_t)stream);
-    static const int lane_form = getenv("MRL_GAE_LANE") ? atoi(getenv("MRL_GAE_LANE")) : 1;      // 0: the LDS-staged kernel (A/B; bit-identical)
+    // option "gae_lane" [MRL_GAE_LANE, 1]; 0: the LDS-staged kernel at every size (A/B; bit-identical)
     // a lane per environment needs a wave's worth of environments; smaller vector envs keep the 16-per-workgroup form
-    if (lane_form && N >= 64) {
+    if (mrl::gae_lane_form() && N >= 64) {
         hipLaunchKernelGGL(gae_lane_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, rew, val, done, last_val, last_done,
                            (float)gamma, gamma * lam, adv_out, ret_out, T, N);
     } else {

@@ -339,12 +339,7 @@ inline hipError_t launch_wgrad_tr(const float* x, const float* dz, int B, float*
     const bool pipe = DBG == 0 && wgrad_tr_pipe() != 0;
     auto kern = pipe ? wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD, DBG, DBG == 0>
                      : wgrad_tr_kernel<H, W, C, RF, STRIDE, NF, WAVES, TM, TN, XPAD, DPAD, DBG, false>;
-    static bool raised[2] = {false, false};
-    if (!raised[pipe]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised[pipe] = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(G::NT), G::LDS_BYTES, stream, x, dz, B, part, x6_dither() & 1);
     return hipGetLastError();
 }
@@ -576,12 +571,7 @@ inline hipError_t launch_wgrad_tr_dense(const float* A, long lda, const float* d
     const int per_xcd = wgrad_tr_xcd() ? ((nblocks + 7) / 8 + p.ntiles - 1) / p.ntiles * p.ntiles : 0;
     const unsigned blocks = per_xcd ? (unsigned)(8 * per_xcd) : (unsigned)nblocks;
     auto go = [&](auto kern, size_t lds) {
-        static bool raised = false;            // per instantiation (one lambda instantiation per kernel type)
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
+        { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, stream, A, lda, dz, part, slab, M, K, N, p.ktiles, p.ntiles,
                            p.rows_per_slab, x6_dither(), per_xcd, nblocks);
         return hipGetLastError();

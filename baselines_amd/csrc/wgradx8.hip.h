@@ -253,12 +253,7 @@ inline hipError_t launch_wgrad_x8_cfg(const AF& af, const float* dz, float* part
                                       hipStream_t stream) {
     const size_t lds = (size_t)3 * (WM * 64 + WN * 64) * WX_LDK * sizeof(uint16_t);
     auto kern = wgrad_x8_kernel<AF, WM, WN, NT>;
-    static bool raised = false;                // per instantiation
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     const int T = p.ktiles * p.ntiles;
     const long blocks = (long)((p.nslab + 7) / 8) * T * 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, stream, af, dz, part, slab, M, K, N, p.ktiles, p.ntiles, p.nslab,

@@ -433,12 +433,7 @@ inline hipError_t launch_wres_u8x3(const WresFwdA<true>& al, const float* w, con
                                    int num_cus, hipStream_t stream) {
     const size_t lds = (size_t)3 * 32 * (K + 8) * sizeof(uint16_t);
     auto kern = wres_u8x3_kernel<EF, PF, WAVES>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     long want = (total_tiles + WAVES - 1) / WAVES;
     int grid = (int)std::min<long>(std::max<long>(want, 1), num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, al, w, ef, K, N, total_tiles);
@@ -528,12 +523,7 @@ inline hipError_t launch_wres(const AL& al, const BL& bl, const EF& ef, int zc, 
     const int KP = wres_kp(K);
     const size_t lds = (size_t)zc * NT * 32 * KP * sizeof(float);
     auto kern = wres_kernel<AL, BL, EF, NT, PF, WAVES>;
-    static bool raised = false;                // per instantiation
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     long want = (total_tiles + WAVES - 1) / WAVES;
     int grid = (int)std::min<long>(std::max<long>(want, 1), num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, al, bl, ef, zc, K, N, KP, total_tiles);

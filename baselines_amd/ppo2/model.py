@@ -60,13 +60,18 @@ def checkpoint_to_flat(loaded, tensors):
     def put(key, t, arr):
         name, shape, off, size = t
         a = np.asarray(arr, np.float32)
-        if a.size != size or (a.ndim and tuple(a.shape) != tuple(shape) and a.ndim != 1):
+        # the variable's own shape, or -- only where that cannot be mistaken for another layout -- a flat array of a variable
+        # that is itself 1-D or scalar (tf_util.py:369 assigns through tf.assign, which requires the exact shape)
+        flat_ok = a.ndim == 1 and len([d for d in shape if d != 1]) <= 1
+        if a.size != size or (tuple(a.shape) != tuple(shape) and not flat_ok and a.ndim != 0):
             raise ValueError('checkpoint variable %s has shape %s, the model expects %s' % (name, a.shape, tuple(shape)))
         out[key].append((off, a.reshape(-1)))
 
     n = len(tensors)
     if isinstance(loaded, list):
-        assert len(loaded) in (n, 3 * n + 2), 'number of variables loaded mismatches len(variables)'
+        # (the params-only list is an extension: tf_util.load_variables demands len == number of global variables)
+        if len(loaded) not in (n, 3 * n + 2):
+            raise ValueError('number of variables loaded mismatches len(variables)')           # tf_util.py:363's message, -O-proof
         for t, a in zip(tensors, loaded[:n]):
             put('params', t, a)
         if len(loaded) > n:

@@ -427,6 +427,19 @@ int mrl_tune_set(const char* label, int variant);
  *                  engine.  4, 3 and 2 are bit-identical (same products, same order of accumulation).
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
+ *   "gae_lane"    [MRL_GAE_LANE, 1]  GAE(lambda) with one environment per lane from 64 environments up (gae_lane_kernel); 0 = the
+ *                  LDS-staged 16-environments-per-workgroup kernel at every size.  Bit-identical (and to the reference's Runner.run).
+ *   "mlp_act"     [MRL_MLP_ACT, 1]  act side of the 2 x 64 tanh MLP nets on float observations: both layers of both nets in ONE launch
+ *                  (csrc/mlpact.hip.h); 0 = layer by layer on the tiled GEMM.  Agree to 2e-6 (different order of the fp32 sums).
+ *   "x6_splitk"   [MRL_X6_SPLITK, 1]  act-side fc launches of the tiled split engine whose tiles alone leave half the chip idle (fc1 of
+ *                  NatureCNN at num_envs <= 8192): K split over blockIdx.y into partial slabs + the bias / activation pass; 0 = one
+ *                  workgroup walks all of K.
+ *   "wgrad_xcd"   [MRL_WGRAD_XCD, 1]  fc weight gradient (wgrad_tr): XCD x takes a contiguous run of the (sample slab, tile) list, so the
+ *                  workgroups that read the same rows share an L2 (fc1: counter traffic 4.3 -> 2.1 GB per launch); 0 = launch order.
+ *                  Bit-identical.
+ *   "dqn_overlap" [MRL_DQN_OVERLAP, 1]  mrl_qnet_td_grad: the online network's obs_t / obs_tp1 passes as one batch when the caller hands
+ *                  them over back to back, the target network's pass on a side stream (needs a workspace of
+ *                  mrl_qnet_workspace_bytes(2 B) + mrl_qnet_workspace_bytes(B)); 0 = three passes one after the other.
  *   "x6_ktm"      [MRL_X6_KTM, 1]  weight planes of the fc layers' tiled split launches (fc1 forward / data gradient) in k-tile-major
  *                  order [plane][k / 32][n][k % 32]: a staging load of 16 rows x 64 bytes touches 8 whole cache lines instead of
  *                  16 half lines (round 6); 0 = [plane][n][k].  Bit-identical.
@@ -458,7 +471,9 @@ int mrl_tune_set(const char* label, int variant);
  *   "mlp_slice"   [MRL_MLP_SLICE, 1]  separate policy / value nets: one workgroup per (32-sample tile, net) instead of one per
  *                  tile -- half the serial chain per workgroup, 256 instead of 128 workgroups for a 4096-sample minibatch
  *   "heads_wave"  [MRL_HEADS_WAVE, 2]  loss / head-gradient kernel for the NatureCNN head shape: 2 = two samples per wave-step (lane half =
- *                  sample for the loss algebra; <= 6 actions, else as 1), 1 = one sample per wave-step (bit-identical), 0 = generic tile kernel
+ *                  sample for the loss algebra; <= 6 actions, else as 1), 1 = one sample per wave-step (bit-identical), 0 = generic tile kernel.
+ *                  Any non-zero value also selects the ACT side's wave-per-sample heads kernel (heads_act_wave_kernel: the same
+ *                  dot-product form; actions identical, values / neglogp within 1e-6 of the tile kernel's)
  * Builds with -DMRL_X6_EXPERIMENTS (MRL_BUILD_DEFINES, csrc/build.py) add the measured-and-dropped variants that
  * profiles/README.md and scripts/ab_options.py refer to ("act_planes", "x6_il", "x6_spec", "*_dbg", ...); they are not part of
  * the product library.  Returns MRL_EINVAL for unknown names.  mrl_get_option reports the value in effect. */

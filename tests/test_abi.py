@@ -313,7 +313,7 @@ def test_reference_shaped_checkpoints_load_by_name_and_as_legacy_list(lib, kind)
         out = checkpoint_to_flat(loaded, tensors)
         np.testing.assert_array_equal(flat(out, 'params'), want['params'])
         assert out['adam_m'] == [] and out['adam_v'] == [] and out['beta_powers'] is None
-    with pytest.raises(AssertionError, match='number of variables loaded mismatches'):
+    with pytest.raises(ValueError, match='number of variables loaded mismatches'):
         checkpoint_to_flat(list(arrays[:n + 1]), tensors)
     with pytest.raises(KeyError):
         d = dict(zip(names, arrays))

@@ -174,3 +174,28 @@ def test_every_row_prices_its_sites_with_algorithmic_bytes_and_the_pipe_it_runs_
                nbatch_train=4096, prof_steps=1, P=57763)
     roof, _ = bench.dominant_roofline(res, sites, 'mujoco')
     assert roof['kernel'] == 'mlp_step' and roof['alg_bytes'] == 4096 * (1504 + 8 + 16 + 68) + 8 * 57763 and roof['pipe'] == 'fp32 MFMA'
+
+
+def test_committed_headline_counters_belong_to_the_committed_kernel_sources():
+    """Release-time guard: the newest committed bench line quotes counter traffic from the newest
+    profiles/*_pmc_hbm.json, and that file was collected from the kernel sources in the tree.  A kernel edit without a new counter
+    pass makes bench.py WITHHOLD the traffic (legal, see above) -- but then the committed headline line is stale evidence: this test
+    warns about it (and fails under MRL_RELEASE_CHECK=1, which the round-end evidence script sets)."""
+    import glob
+    import sys
+    import warnings
+    sys.path.insert(0, ROOT)
+    import bench
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_atari4096.json')), key=bench.profile_round_key)
+    pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm.json')), key=bench.profile_round_key)
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    problems = []
+    src = (d.get('roofline') or {}).get('traffic_source')
+    if src != 'profiles/' + os.path.basename(pmcs[-1]):
+        problems.append('%s quotes counters from %r, the newest counter file is %s' % (os.path.basename(lines[-1]), src, os.path.basename(pmcs[-1])))
+    if json.load(open(pmcs[-1]))['source_sha16'] != bench.source_sha16():
+        problems.append('%s was collected from other kernel sources than the tree holds (%s)' % (os.path.basename(pmcs[-1]), bench.source_sha16()))
+    if problems:
+        if os.environ.get('MRL_RELEASE_CHECK') == '1':
+            pytest.fail('; '.join(problems))
+        warnings.warn('stale headline evidence: ' + '; '.join(problems))

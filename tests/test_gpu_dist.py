@@ -23,7 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from tests.test_dist_gloo import KW, WORLD, _data, _emulate, _free_port      # noqa: E402
+from tests.test_dist_gloo import KW, NENV, _data, _emulate, _free_port      # noqa: E402
+
+WORLD = 2
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +69,7 @@ def _worker(rank, port, weights, micro, out):
     from baselines_amd.ppo2.microbatched_model import MicrobatchedModel
     comm = default_comm()
     assert comm.Get_size() == WORLD and comm.native is None          # gloo: collectives through torch.distributed
-    N, T = 8, 4
+    N, T = NENV, 4
     lo, hi = shard_envs(N, rank, WORLD)
     nloc = (hi - lo) * T
     np.random.seed(rank)                       # ranks draw DIFFERENT initial weights; rank 0's must win (sync_from_root)
@@ -103,7 +105,7 @@ def test_two_product_models_on_one_gpu_match_reference_algebra(weights):
     np.testing.assert_array_equal(p0, p1)                 # replicas stay bit-identical (check_synced also ran inside)
     assert not np.array_equal(s0, s1)                     # loss statistics are rank-local, not reduced
     np.random.seed(0)
-    ref = _emulate(weights)                               # rank 0's initial weights == np.random.seed(0) stream
+    ref = _emulate(weights, WORLD)                               # rank 0's initial weights == np.random.seed(0) stream
     np.testing.assert_allclose(p0, ref, rtol=0, atol=5e-6)
 
 

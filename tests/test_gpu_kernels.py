@@ -27,12 +27,22 @@ def dev(x):
 @pytest.mark.parametrize('name', ['t128_n8', 't5_n3', 't37_n70', 't1_n4', 't64_n129_alldone', 't64_n65_nodone',
                                   't300_n33_g1', 't16_n64_lam0'])
 def test_gae_bit_exact_vs_reference_golden(golden_dir, name):
+    from baselines_amd import _lib as L
     ops = _ops()
     g = np.load(os.path.join(golden_dir, 'runner_%s.npz' % name))
     ret, adv = ops.gae(dev(g['in_rewards']), dev(g['in_values']), dev(g['in_dones']), dev(g['in_last_values']),
                        dev(g['in_last_dones']), float(g['gamma']), float(g['lam']), want_advs=True)
     got = ops.sf01(ret).cpu().numpy()
     np.testing.assert_array_equal(got, g['out_returns'])      # bit-exact vs the reference's Runner.run
+    # option gae_lane = 0: the LDS-staged kernel at every size -- the same bits (at N >= 64 the default is the lane kernel)
+    assert L.get_option('gae_lane') == 1
+    L.set_option('gae_lane', 0)
+    try:
+        ret0, adv0 = ops.gae(dev(g['in_rewards']), dev(g['in_values']), dev(g['in_dones']), dev(g['in_last_values']),
+                             dev(g['in_last_dones']), float(g['gamma']), float(g['lam']), want_advs=True)
+    finally:
+        L.set_option('gae_lane', 1)
+    assert torch.equal(ret0, ret) and torch.equal(adv0, adv)
     ret_o, adv_o = O.gae(g['in_rewards'], g['in_values'], g['in_dones'], g['in_last_values'], g['in_last_dones'],
                          float(g['gamma']), float(g['lam']))
     np.testing.assert_array_equal(adv.cpu().numpy(), adv_o)
@@ -591,3 +601,29 @@ def test_fused_mlp_act_agrees_with_the_layer_wise_path(cfg):
             assert float((x != y).float().mean()) <= 0.002           # (an argmax over Gumbel-perturbed logits can flip on a 1e-7 tie)
         else:
             assert float((x.double() - y.double()).abs().max()) <= 2e-6 * max(1.0, float(y.double().abs().max()))
+
+
+def test_act_heads_wave_kernel_agrees_with_the_tile_kernel():
+    """heads_wave also selects the ACT side's wave-per-sample heads kernel (policies.py:77-96 on the NatureCNN latent): actions equal,
+    values / neglogp / logits within 1e-6 of the tile kernel's (a different order of the 512-term dot products)."""
+    from baselines_amd import _lib as L
+    from baselines_amd import ops
+    n = 333
+    r = np.random.RandomState(5)
+    old = L.get_option('heads_wave')
+    outs = []
+    try:
+        for v in (2, 0):
+            L.set_option('heads_wave', v)
+            dm = ops.DeviceModel(network='cnn', ob_shape=(84, 84, 4), ob_dtype=np.uint8, pd_kind='categorical', nact=6, chunk=n)
+            if v == 2:
+                params = dev((r.randn(dm.P) * 0.02).astype(np.float32))
+                obs = dev(r.randint(0, 256, (n, 84, 84, 4)).astype(np.uint8))
+                noise = dev(r.rand(n, 6).astype(np.float32))
+            a, vv, nlp, pd = dm.act(params, obs, noise, want_pdparam=True)
+            outs.append((a.cpu(), vv.cpu(), nlp.cpu(), pd.cpu()))
+    finally:
+        L.set_option('heads_wave', old)
+    assert float((outs[0][0] != outs[1][0]).float().mean()) <= 0.01
+    for x, y in zip(outs[0][1:], outs[1][1:]):
+        assert float((x.double() - y.double()).abs().max()) <= 1e-6 * max(1.0, float(y.double().abs().max()))
