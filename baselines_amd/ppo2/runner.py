@@ -140,7 +140,8 @@ class Runner(AbstractEnvRunner):
         # same distribution, the Philox stream is consumed in one piece instead of T); wrapped / subclassed models keep their own
         from .model import Model
         noise_all = None
-        if type(self.model) is Model and not self.recurrent and hasattr(self.model, 'make_noise'):
+        if (isinstance(self.model, Model) and not self.recurrent and type(self.model).step_into is Model.step_into
+                and type(self.model).make_noise is Model.make_noise):       # (MicrobatchedModel etc.: the same act side)
             noise_all = self.model.make_noise(T * self.nenv).reshape(T, self.nenv, -1)
         for t in range(T):
             if self._ob_clip:                          # normalize_observations: the rollout holds the clipped observations
