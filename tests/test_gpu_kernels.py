@@ -345,7 +345,7 @@ def test_engine_options_agree():
         return g.cpu().numpy(), st.cpu().numpy()
 
     names = ['u8_bf16x3', 'f32_bf16x6', 'mlp_fused', 'dgrad_x6', 'relu_bits', 'c1_lds', 'wgrad_x8', 'c1_wgrad2', 'tr_epilogue',
-             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c', 'wgrad_pipe', 'heads_wave', 'x6_ktm']
+             'wgrad_tr', 'x6_pg', 'mlp_slice', 'mlp_waves', 'x6_dither', 'x6_frag', 'conv_x6c', 'wgrad_pipe', 'heads_wave', 'x6_ktm', 'wgrad_xcd']
     # builds with -DMRL_X6_EXPERIMENTS also carry the measured-and-dropped variants (plane tensors, separate load phase)
     experiments = True
     try:
@@ -409,6 +409,7 @@ def test_engine_options_agree():
                  ('split engines, LDS-resident fp32 data gradients', dict(defaults, dgrad_x6=0), 3e-6),
                  ('split engines, data gradients with the generic position-major kernel (round 5)', dict(defaults, dgrad_x6=1), 3e-6),
                  ('split engines, fc weight planes in [plane][n][k] order (round 5)', dict(defaults, x6_ktm=0), 3e-6),
+                 ('split engines, fc weight gradient workgroups in launch order (round 5)', dict(defaults, wgrad_xcd=0), 3e-6),
                  ('split engines, act\' from the fp32 activations instead of the ReLU bit masks', dict(defaults, relu_bits=0), 3e-6),
                  ('split engines, row-major accumulators and epilogues (no transposed epilogues)', dict(defaults, tr_epilogue=0), 3e-6),
                  ('split engines, one row panel at a time through the column tiles', dict(defaults, x6_pg=1), 3e-6),
@@ -468,7 +469,8 @@ def test_engine_options_agree():
                      ('split engines (default)', 'split engines, loss / head gradients one sample per wave-step'),
                      # dgrad_x6p_kernel (round 6: exact wait counts around the epilogue stores) is the same arithmetic in the same order
                      ('split engines (default)', 'split engines, data gradients with the generic position-major kernel (round 5)'),
-                     ('split engines (default)', 'split engines, fc weight planes in [plane][n][k] order (round 5)')):
+                     ('split engines (default)', 'split engines, fc weight planes in [plane][n][k] order (round 5)'),
+                     ('split engines (default)', 'split engines, fc weight gradient workgroups in launch order (round 5)')):
             np.testing.assert_array_equal(by_name[a][0], by_name[b][0], err_msg=b)
             np.testing.assert_array_equal(by_name[a][1], by_name[b][1], err_msg=b)
         # ... also where conv3's 256-image tiles divide the batch (1152 % 256 != 0 sends conv3 to the generic kernel above), on
