@@ -431,7 +431,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -1935,6 +1935,26 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
         } else {
             ConvPatchKC<false> af;
             fill_conv(af, l, hprev, npix, nullptr);
+            // small batches (round 6; the Q-network's conv2 / conv3 at batch 32-64: 13-41 workgroups walking K = 512 / 576 alone, 48 us
+            // each, a quarter of the learner step): split K over the z dimension into partial slabs, then the bias / activation pass of
+            // the small-batch fc path adds them in fixed order
+            const int bm = 128, bn = (var == V_128x32) ? 32 : 64;
+            const long tiles = (long)((npix + bm - 1) / bm) * ((l.NF + bn - 1) / bn);
+            if (part && tiles * 4 <= num_cus() && l.K >= 256 && l.K % 32 == 0 && get_option("conv_splitk", "MRL_CONV_SPLITK", 1)) {
+                int ns = (int)std::min<long>(std::min<long>(8, l.K / 128), num_cus() / std::max<long>(1, tiles));
+                const int ksplit = ((l.K + ns - 1) / ns + 31) / 32 * 32;
+                ns = (l.K + ksplit - 1) / ksplit;
+                const long slab = (long)npix * l.NF;
+                if (ns > 1 && (size_t)ns * slab <= part_floats) {
+                    EpiPartialPlain ep{part, slab, l.NF};
+                    int rc = gemm_dispatch(l.name, "fwd", var, af, bf, ep, npix, l.NF, l.K, ns, ksplit, st, 2.0 * npix * (double)l.K * l.NF);
+                    if (rc) return rc;
+                    ProfScope ps("splitk_bias_act", 0.0, 4.0 * slab * (ns + 1), st);
+                    hipLaunchKernelGGL(splitk_bias_act_kernel, dim3((unsigned)std::min<long>((slab + 255) / 256, 1024)), dim3(256), 0, st,
+                                       part, slab, ns, bias, l.act, hout, slab, l.NF);
+                    return (int)hipGetLastError();
+                }
+            }
             return gemm_dispatch(l.name, "fwd", var, af, bf, ef, npix, l.NF, l.K, 1, l.K, st);
         }
     } else {

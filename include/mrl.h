@@ -440,6 +440,9 @@ int mrl_tune_set(const char* label, int variant);
  *   "dqn_overlap" [MRL_DQN_OVERLAP, 1]  mrl_qnet_td_grad: the online network's obs_t / obs_tp1 passes as one batch when the caller hands
  *                  them over back to back, the target network's pass on a side stream (needs a workspace of
  *                  mrl_qnet_workspace_bytes(2 B) + mrl_qnet_workspace_bytes(B)); 0 = three passes one after the other.
+ *   "conv_splitk" [MRL_CONV_SPLITK, 1]  hidden conv layers on the generic tiled engine at small batches (the Q-network's conv2 / conv3 at
+ *                  batch 32-64: a few dozen workgroups walking K alone): K split over the z dimension into partial slabs + the bias /
+ *                  activation pass; 0 = one workgroup per output tile walks all of K.
  *   "x6_ktm"      [MRL_X6_KTM, 1]  weight planes of the fc layers' tiled split launches (fc1 forward / data gradient) in k-tile-major
  *                  order [plane][k / 32][n][k % 32]: a staging load of 16 rows x 64 bytes touches 8 whole cache lines instead of
  *                  16 half lines (round 6); 0 = [plane][n][k].  Bit-identical.

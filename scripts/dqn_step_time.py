@@ -2,7 +2,7 @@
 """Config 5's learner step alone (prioritized sample -> Q-network TD step replayed as a hipGraph -> priority update) at batch 32 out of
 a small resident replay: wall time per step; under `rocprofv3 --kernel-trace` (scripts/gpu_trace.sh, GAPS=.) the per-kernel times and
 whether the branches of the replayed graph overlap (kernels busy > 100 % of the window).
-    python scripts/dqn_step_time.py [steps] [capacity]"""
+    python scripts/dqn_step_time.py [steps] [capacity] [graph|eager]"""
 import os
 import sys
 import time
@@ -35,7 +35,8 @@ def step(graph=True):
     buf.update_priorities_from_td(idx, td)
 
 
-for g in (True, False):
+MODES = {'graph': (True,), 'eager': (False,)}.get(sys.argv[3] if len(sys.argv) > 3 else '', (True, False))
+for g in MODES:
     for _ in range(5):
         step(g)
     torch.cuda.synchronize()
