@@ -2645,8 +2645,11 @@ static int model_act_impl(const mrl_model* m, const float* params, const void* o
         ProfScope ps("heads_act", 0.0, (double)Bc * (4.0 * a.nlat + (a.shared ? 0 : 4.0 * a.nlatv) + 16.0), st);
         const bool wave_ok = a.has_pi_head && a.shared && a.pd_kind == MRL_PD_CATEGORICAL && a.nact <= 8 && a.nlat == 512 &&
                              (uintptr_t)a.lat % 16 == 0 && get_option("heads_wave", "MRL_HEADS_WAVE", 2);
-        if (wave_ok)       // one wave per sample, up to 8 samples per wave
-            hipLaunchKernelGGL(heads_act_wave_kernel<8>, dim3(std::max(1, std::min((Bc + 3) / 4, 2048))), dim3(256), 0, st, a);
+        if (wave_ok) {     // one wave per sample at a time; from ~1024 samples up a wave takes several (its 14 KB of head weights are
+            // loaded once per wave with strided scalar loads: at num_envs = 4096 one sample per wave spent 32 us mostly on that)
+            const int spw = std::max(1, std::min(8, Bc / 1024));
+            hipLaunchKernelGGL(heads_act_wave_kernel<8>, dim3(std::max(1, std::min((Bc + 4 * spw - 1) / (4 * spw), 2048))), dim3(256), 0, st, a);
+        }
         else
             hipLaunchKernelGGL(heads_act_kernel, dim3(std::min(ntiles, HEAD_MAXBLK)), dim3(256), lds, st, a);
         MRL_LAUNCH_CHECK();
