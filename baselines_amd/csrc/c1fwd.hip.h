@@ -404,9 +404,24 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
     }
     __syncthreads();
     const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wp + (long)i * C1_KP + 8 * h);
-    // tiles of this wave: waves 0-4 -> (2w, 2w+1), waves 5, 6, 7 -> 10, 11, 12
-    const int t0 = wave < 5 ? 2 * wave : 5 + wave;
-    const bool two = wave < 5;
+    // tiles of this wave.  Row-major accumulators (TR = false): waves 0-4 -> (2w, 2w+1), waves 5, 6, 7 -> 10, 11, 12 (the last one:
+    // 16 pixels computed as 32).  TR, round 6: an image's phase lasts as long as its busiest SIMD, and SIMD 0 (waves 0 and 4)
+    // carried FOUR tiles where the others carry three -- leaving one tile out (timing experiment) took the kernel from 2.76 to 2.29 ms.
+    // Now the twelve whole tiles go three to a SIMD (waves 0-3 -> (2w, 2w+1), waves 4-7 -> 8 .. 11) and the 16 pixels 384 .. 399
+    // are two 16-pixel x 16-channel blocks on v_mfma_f32_16x16x32_bf16 (24 instructions each, no padding rows), one on wave 4, one
+    // on wave 5: 3.25 / 3.25 / 3 / 3 tile times per SIMD instead of 4 / 3 / 3 / 3.
+    const int t0 = TR ? (wave < 4 ? 2 * wave : 4 + wave) : (wave < 5 ? 2 * wave : 5 + wave);
+    const bool two = TR ? wave < 4 : wave < 5;
+    const bool mini = TR && (wave == 4 || wave == 5);
+    const int chalf = wave & 1;                            // mini block: channels 16 chalf .. 16 chalf + 15 (wave 4: 0, wave 5: 1)
+    const int l16 = lane & 15, kg4 = lane >> 4;           // 16x16x32 operand roles: row / column l16, k group kg4 (8 consecutive k)
+    const int mini_aoff = (((384 + l16) / C1_OW * C1_S * C1_W + ((384 + l16) % C1_OW) * C1_S) * C1_C + 8 * kg4) * 2;
+    const uint8_t* const mini_w = reinterpret_cast<const uint8_t*>(wp + (long)(16 * chalf + l16) * C1_KP + 8 * kg4);
+    typedef float c1_f32x4 __attribute__((ext_vector_type(4)));
+    c1_f32x4 pend16 = {0.f, 0.f, 0.f, 0.f};               // ReLU'd mini block of the previous image
+    float bias16[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias16[r] = bias[16 * chalf + 4 * kg4 + r];
     int aoff[2];                                          // byte offset of this lane's patch inside an LDS image, per tile
     int pixl[2];                                          // TR: output pixel of this lane, per tile
 #pragma unroll
@@ -426,8 +441,20 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
 
     // one image: MFMAs with (EPI) the previous image's epilogue, the next image's staging and the loads of the one after that
     // issued between them.  TWO: this wave owns two tiles.
-    auto phase = [&](auto two_c, auto epi_c, const uint8_t* cur, uint8_t* nxt, int bnext2) {
-        constexpr bool TWO = decltype(two_c)::value, EPI = decltype(epi_c)::value;
+    // the previous image's mini block: lane (l16, kg4) holds pixel 384 + l16, channels 16 chalf + 4 kg4 .. + 3
+    auto mini_flush = [&]() {
+        *reinterpret_cast<c1_f32x4*>(out + (ppix0 + 384 + l16) * C1_NF + 16 * chalf + 4 * kg4) = pend16;
+        if constexpr (MASK) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bits |= min(__float_as_uint(pend16[r]), 1u) << (4 * kg4 + r);
+            bits |= (uint32_t)__shfl_xor((int)bits, 16);
+            bits |= (uint32_t)__shfl_xor((int)bits, 32);
+            if (lane < 16) reinterpret_cast<uint16_t*>(mask)[2 * (ppix0 + 384 + l16) + chalf] = (uint16_t)bits;      // its half of the pixel's word
+        }
+    };
+    auto phase = [&](auto two_c, auto epi_c, auto mini_c, const uint8_t* cur, uint8_t* nxt, int bnext2) {
+        constexpr bool TWO = decltype(two_c)::value, EPI = decltype(epi_c)::value, MINI = decltype(mini_c)::value;
         constexpr int NU = TWO ? 2 : 1;
         const uint8_t* arow[2] = {cur + aoff[0], cur + aoff[1]};
         f32x16 acc[2];
@@ -561,6 +588,21 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
                 if (lane < (t == TILES - 1 ? 16 : 32)) mask[ppix0 + t * 32 + lane] = (uint32_t)mw[u];
             }
         }
+        if constexpr (MINI) {
+            if constexpr (EPI) mini_flush();
+            c1_f32x4 a4 = {bias16[0], bias16[1], bias16[2], bias16[3]};
+#pragma unroll
+            for (int ky = 0; ky < C1_RF; ++ky) {             // one patch row = 32 k per instruction
+                const c1_u32x4 af = *reinterpret_cast<const c1_u32x4*>(cur + mini_aoff + ky * (C1_W * C1_C) * 2);
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl) {
+                    const c1_u32x4 wf = *reinterpret_cast<const c1_u32x4*>(mini_w + (ky * 32 + pl * 32 * C1_KP) * 2);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, af), a4, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend16[r] = fmaxf(a4[r], 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -575,9 +617,9 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
     // (0.6 ms of 2.8 per 131072 images).  Entered from a peeled copy of its own body, the counts are exact (vmcnt(10)).
     int par = 0;
     bool first = true;
-#define MRL_C1_STEP(TWOC, EPIC)                                                                                   \
+#define MRL_C1_STEP(TWOC, EPIC, MINIC)                                                                            \
     {                                                                                                            \
-        phase(TWOC, EPIC, img + par * C1_IMG16, img + (par ^ 1) * C1_IMG16, b + 2 * G);                           \
+        phase(TWOC, EPIC, MINIC, img + par * C1_IMG16, img + (par ^ 1) * C1_IMG16, b + 2 * G);                    \
         ppix0 = (long)b * C1_PIX;                                                                                \
         first = false;                                                                                           \
         b += G;                                                                                                  \
@@ -585,20 +627,29 @@ __global__ __launch_bounds__(512) void c1fwd3_kernel(const uint8_t* __restrict__
         __syncthreads(); /* next image staged; this image's patch reads are done */                              \
     }
     if (two) {
-        if (b < B) MRL_C1_STEP(T_{}, F_{})
+        if (b < B) MRL_C1_STEP(T_{}, F_{}, F_{})
         if (b < B) {
-            MRL_C1_STEP(T_{}, T_{})
-            while (b < B) MRL_C1_STEP(T_{}, T_{})
+            MRL_C1_STEP(T_{}, T_{}, F_{})
+            while (b < B) MRL_C1_STEP(T_{}, T_{}, F_{})
+        }
+    } else if (mini) {
+        if constexpr (TR) {
+            if (b < B) MRL_C1_STEP(F_{}, F_{}, T_{})
+            if (b < B) {
+                MRL_C1_STEP(F_{}, T_{}, T_{})
+                while (b < B) MRL_C1_STEP(F_{}, T_{}, T_{})
+            }
         }
     } else {
-        if (b < B) MRL_C1_STEP(F_{}, F_{})
+        if (b < B) MRL_C1_STEP(F_{}, F_{}, F_{})
         if (b < B) {
-            MRL_C1_STEP(F_{}, T_{})
-            while (b < B) MRL_C1_STEP(F_{}, T_{})
+            MRL_C1_STEP(F_{}, T_{}, F_{})
+            while (b < B) MRL_C1_STEP(F_{}, T_{}, F_{})
         }
     }
 #undef MRL_C1_STEP
     // the last image's epilogue
+    if (!first && TR && mini) mini_flush();
     if (!first && TR) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

@@ -424,7 +424,10 @@ int mrl_tune_set(const char* label, int variant);
  *                  one after it are issued between the MFMAs of the current image), transposed accumulators with 16-byte
  *                  stores; 3 = the same pipeline with row-major accumulators; 2 = the same arithmetic in lock-step phases
  *                  (multiply, epilogue, stage, barrier); 1 = uint8 images converted per fragment; 0 = weights-resident gather
- *                  engine.  4, 3 and 2 are bit-identical (same products, same order of accumulation).
+ *                  engine.  3 and 2 are bit-identical (same products, same order of accumulation); 4 (round 6) spreads the twelve whole 32-pixel tiles
+ *                  of an image three to a SIMD and multiplies the pixels 384 .. 399 as two 16 x 16 blocks on v_mfma_f32_16x16x32_bf16
+ *                  (no padded tile on the busiest SIMD: 2.80 -> 2.50 ms per 131072 images): the same exact products added in groups of
+ *                  32 instead of 16 for those pixels, within 1e-6 of 3 / 2.
  *   "x6_pg"       [MRL_X6_PG, 8]  tile order of the tiled split engines: row panels of an XCD that advance through the column
  *                  tiles together (a weight tile pulled into that XCD's L2 serves x6_pg row panels); 1 = one panel at a time
  *   "gae_lane"    [MRL_GAE_LANE, 1]  GAE(lambda) with one environment per lane from 64 environments up (gae_lane_kernel); 0 = the

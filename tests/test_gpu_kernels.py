@@ -540,8 +540,9 @@ def test_precomputed_advantage_statistics_feed_the_fused_mlp_step_bit_identicall
 @pytest.mark.parametrize('B', [1, 257, 4109])
 def test_conv1_forward_engines_are_bit_identical(B):
     """The image-resident first-layer kernels (c1fwd.hip.h: software pipeline with transposed / row-major accumulators,
-    lock-step phases) form the same exact products in the same order: logits, values and the whole
-    gradient (it goes through the ReLU bit masks the forward writes) are bit-identical between them -- one image, a batch that
+    lock-step phases) form the same exact products: logits, values and the whole
+    gradient (it goes through the ReLU bit masks the forward writes) are bit-identical between the row-major pipeline and the lock-step
+    kernel, and within 1e-6 of them for the balanced transposed pipeline (see below) -- one image, a batch that
     leaves persistent workgroups with 1-2 images and one with 16 (two peeled phases + the steady-state loop)."""
     from baselines_amd import _lib as L
     from baselines_amd import ops
@@ -565,9 +566,13 @@ def test_conv1_forward_engines_are_bit_identical(B):
     finally:
         L.set_option('c1_lds', old)
     assert float(outs[0][2].abs().max()) > 0 and bool(torch.isfinite(outs[0][2]).all())
-    for o in outs[1:]:
-        for a, b in zip(outs[0], o):
-            assert torch.equal(a, b)
+    # c1_lds = 3 and 2: bit-identical.  c1_lds = 4 (round 6): the same products, but the pixels 384 .. 399 of every image are multiplied
+    # by v_mfma_f32_16x16x32_bf16 (one patch row = 32 k per instruction) instead of padded 32x32x16 tiles, which adds the same exact
+    # products in groups of 32 instead of 16: last-bit differences in those 16 pixels, everything held to 1e-6 of its scale
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a.double() - b.double()).abs().max()) <= 1e-6 * max(float(b.double().abs().max()), 1e-30)
 
 
 @pytest.mark.parametrize('cfg', [dict(ob=376, pd='gaussian', nact=17, copy=True, n=1024), dict(ob=376, pd='gaussian', nact=17, copy=True, n=37),
