@@ -471,8 +471,17 @@ __global__ __launch_bounds__(CH_NT, 2) void c1wgrad_half_kernel(const uint8_t* _
 }
 
 inline hipError_t launch_c1wgrad_half(const void* obs, const int32_t* srow, const float* dz, int B, float* part, int nblocks,
-                                      hipStream_t stream, bool pf2 = false) {
+                                      hipStream_t stream, bool pf2 = false, int dbg = 0) {
     auto kern = pf2 ? c1wgrad_half_kernel<0, true> : c1wgrad_half_kernel<0, false>;
+#ifdef MRL_X6_EXPERIMENTS       // phase omissions (timing only): option c1_dbg = 64 + bits (1 no MFMA phase, 2 no staging pass, 4 no loads, 8 no MFMAs, 16 no image staging, 32 no dz staging)
+    switch (pf2 ? dbg : 0) {
+        case 1: kern = c1wgrad_half_kernel<1, true>; break;   case 2: kern = c1wgrad_half_kernel<2, true>; break;
+        case 4: kern = c1wgrad_half_kernel<4, true>; break;   case 8: kern = c1wgrad_half_kernel<8, true>; break;
+        case 16: kern = c1wgrad_half_kernel<16, true>; break; case 32: kern = c1wgrad_half_kernel<32, true>; break;
+        case 6: kern = c1wgrad_half_kernel<6, true>; break;   case 48: kern = c1wgrad_half_kernel<48, true>; break;
+        default: break;
+    }
+#endif
     { hipError_t e = raise_lds_limit((const void*)kern); if (e != hipSuccess) return e; }      // once per (device, kernel)
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CH_NT), CH_LDS, stream, static_cast<const uint8_t*>(obs), srow, dz, B, part, x6_dither());
     return hipGetLastError();

@@ -2210,7 +2210,8 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
                 ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
-                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, st, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3);
+                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, st, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3,
+                                                   std::max(0, dbg_option("c1_dbg", "MRL_C1_DBG") - 64));
                 if (e != hipSuccess) return (int)e;
             }
             rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
