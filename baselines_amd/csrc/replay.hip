@@ -16,6 +16,7 @@
 #include <math.h>
 
 #include "common.hip.h"
+#include "powcr.hip.h"
 
 using namespace mrl;
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
             if (!mine(i)) continue;
             if (td) {
                 double p = fabs((double)td[j]) + eps;       // deepq.py:302  new_priorities = |td| + eps
-                v = pow(p, alpha);
+                v = mrl::pow_cr(p, alpha);                   // correctly rounded (powcr.hip.h): = Python's ** wherever glibc rounds correctly
                 lmax = fmax(lmax, p);
             } else {
                 v = leaf[j];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(1024) void tree_update_kernel(double* sum_tree, dou
         } else {
             i = (ring_start + j) % ring_maxsize;
             // device fast path: the leaf is max_priority ** alpha of the RUNNING maximum kept on the device (no host read-back)
-            v = max_priority ? pow(max_priority[0], alpha) : leaf_const;
+            v = max_priority ? mrl::pow_cr(max_priority[0], alpha) : leaf_const;
             // a wrapped ring range cannot name a slot twice unless n > maxsize (rejected on the host)
         }
         if (write) {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const double* sum_tree,
         s_total = sum_prefix(sum_tree, capacity, length - 2);       // sum(0, len-1): newest element excluded (quirk)
         s_all = tload(sum_tree + 1);                                 // sum()
         double p_min = tload(min_tree + 1) / s_all;                  // min() / sum()
-        s_maxw = pow(p_min * (double)length, -beta);
+        s_maxw = mrl::pow_cr(p_min * (double)length, -beta);
     }
     __syncthreads();
     const double every = s_total / (double)B;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const double* sum_tree,
         long leaf = node - capacity;
         idx_out[i] = (int32_t)leaf;
         double p_sample = tload(sum_tree + node) / s_all;
-        double w = pow(p_sample * (double)length, -beta) / s_maxw;
+        double w = mrl::pow_cr(p_sample * (double)length, -beta) / s_maxw;
         if (w_out) w_out[i] = w;
         if (w32_out) w32_out[i] = (float)w;
     }

@@ -139,13 +139,17 @@ def test_per_device_fast_path_and_full_size_properties():
     inner = np.arange(1, cap)
     np.testing.assert_array_equal(s[inner], s[2 * inner] + s[2 * inner + 1])
     np.testing.assert_array_equal(m[inner], np.minimum(m[2 * inner], m[2 * inner + 1]))
-    # leaves: last duplicate wins, value = pow(|td| + eps, alpha) within 4 ulp of libm
+    # leaves: last duplicate wins, value = (|td| + eps) ** alpha.  The device computes it correctly rounded (csrc/powcr.hip.h, round 6;
+    # ROCm's own pow was one ulp off Python's `**` in 16 % of the inputs): equal to Python's unless glibc's pow itself misrounds (about
+    # one input in a thousand, tests/test_powcr.py), never more than one ulp apart
     idx_h, td_h = idx.cpu().numpy(), td.cpu().numpy().astype(np.float64)
     last = {}
     for i, t in zip(idx_h, td_h):
         last[int(i)] = (abs(t) + 1e-6) ** 0.6
     got = s[cap + np.array(list(last.keys()))]
-    np.testing.assert_allclose(got, np.array(list(last.values())), rtol=1e-15 * 4)
+    want = np.array(list(last.values()))
+    ulp = np.abs(got.view(np.int64) - want.view(np.int64))
+    assert ulp.max() <= 1 and int((ulp != 0).sum()) <= 3, (int(ulp.max()), int((ulp != 0).sum()))
     assert buf._current_max_priority() == pytest.approx(max(1.0, float(np.abs(td_h).max() + 1e-6)), rel=1e-12)
 
 
@@ -163,3 +167,44 @@ def test_dqn_td_huber_vs_oracle(B, nA, double_q):
     np.testing.assert_allclose(td.cpu().numpy(), td_o, rtol=0, atol=1e-6)
     np.testing.assert_allclose(float(loss.item()), float(loss_o), rtol=1e-5)        # tolerance of the float path: 1e-5
     np.testing.assert_allclose(dq.cpu().numpy(), dq_o, rtol=1e-6, atol=1e-9)
+
+
+def test_device_priorities_are_correctly_rounded_powers():
+    """mrl_per_update_from_td over 2^17 random TD errors: every leaf is the NEAREST double to (|td| + eps) ** alpha (70-digit decimal
+    reference on a sample), bit-equal to the host build of the same source, and equal to Python's `**` except for glibc's own
+    misroundings (<= 0.3 %; deepq/replay_buffer.py:169-191, deepq/deepq.py:302)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from decimal import Decimal, getcontext
+    from baselines_amd.deepq import PrioritizedReplayBuffer
+    cap = 1 << 17
+    buf = PrioritizedReplayBuffer(cap, 0.6)
+    rng = np.random.RandomState(5)
+    n = 4096
+    ob = rng.randint(0, 256, (n, 4)).astype(np.uint8)
+    for _ in range(cap // n):
+        buf.add_batch(ob, rng.randint(0, 6, n), rng.randn(n).astype(np.float32), ob, np.zeros(n, np.float32))
+    td = (torch.randn(cap, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 3).float()
+    idx = torch.arange(cap, device='cuda', dtype=torch.int32)
+    buf.update_priorities_from_td(idx, td, eps=1e-6)
+    s, _ = buf.trees_numpy()
+    got = s[cap:2 * cap]
+    p = np.abs(td.cpu().numpy().astype(np.float64)) + 1e-6
+    ref = np.array([float(v) ** 0.6 for v in p])
+    ulp = np.abs(got.view(np.int64) - ref.view(np.int64))
+    assert ulp.max() <= 1 and (ulp != 0).mean() <= 3e-3, (int(ulp.max()), float((ulp != 0).mean()))
+    getcontext().prec = 70
+    a = Decimal(0.6)
+    for v, g in zip(p[:3000], got[:3000]):
+        assert float((Decimal(float(v)).ln() * a).exp()) == g
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 'h.cpp'), 'w').write('#include "powcr.hip.h"\nextern "C" void f(const double* x, double a, double* o, long n) '
+                                                   '{ for (long i = 0; i < n; ++i) o[i] = mrl::pow_cr(x[i], a); }\n')
+        subprocess.check_call(['g++', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-I' + os.path.join(root, 'baselines_amd', 'csrc'),
+                               os.path.join(d, 'h.cpp'), '-o', os.path.join(d, 'h.so')])
+        L = ctypes.CDLL(os.path.join(d, 'h.so'))
+        host = np.empty_like(p)
+        L.f(p.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(0.6), host.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(p.size))
+    np.testing.assert_array_equal(got, host)
