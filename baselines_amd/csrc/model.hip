@@ -431,7 +431,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1}, {"dqn_latdgrad", "MRL_DQN_LATDGRAD", 1}, {"dqn_wstream", "MRL_DQN_WSTREAM", 1}, {"dqn_heads", "MRL_DQN_HEADS", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -606,6 +606,10 @@ struct StepCtx {
     bool final_chunk = true;
     int early_layer = -1;       // pi-net layer after whose weight gradient [early_lo, P) is complete and can travel
     long early_lo = 0;
+    // latency-bound batches (the DQN learner step): the weight gradients -- off the dz chain -- go to this stream, forked per layer
+    // with ev_fork once dz[i] is there; ws.part then belongs to that stream and the CALLER joins it before the gradient is read
+    hipStream_t wstream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z part[z*slab + i]   (fixed order -> deterministic).
@@ -2092,6 +2096,10 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
     for (auto& v : nw.dzpvalid) v = 0;
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
+        if (l.ln && ctx.wstream) {     // the layer-norm reduction below uses ws.part on `st`: wait for the weight gradients in flight
+            MRL_HIP_CHECK(hipEventRecord(ctx.ev_join, ctx.wstream));
+            MRL_HIP_CHECK(hipStreamWaitEvent(st, ctx.ev_join, 0));
+        }
         if (l.ln) {
             // nw.dz[i] arrives as the gradient w.r.t. the activation's input = the layer-norm output; turn it into the gradient
             // w.r.t. the affine map's output (in place) and reduce dbeta | dgamma over the rows
@@ -2129,6 +2137,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         if (rows > 0x7fffffffL || l.b_off != l.w_off + (long)l.K * l.N) return MRL_EUNSUP;
         // ---- weight + bias gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n], db[n] = sum_rows dz[row][n]
         //      (split-K over rows; the bias column sums ride on the B operand's LDS image)
+        hipStream_t stw = st;
+        if (ctx.wstream) {
+            MRL_HIP_CHECK(hipEventRecord(ctx.ev_fork, st));
+            MRL_HIP_CHECK(hipStreamWaitEvent(ctx.wstream, ctx.ev_fork, 0));
+            stw = ctx.wstream;
+        }
         int var = pick_variant(l.name, "wgrad", l.K, l.N);
         const long slab = (long)l.K * l.N + l.N;
         const void* asrc = first ? in.obs : (const void*)hprev;
@@ -2152,11 +2166,11 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             {
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
-                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
-                hipError_t e = launch_wgrad_tr_dense(hprev, l.K, dz, ws.part, slab, (int)rows, l.K, l.N, wd, st);
+                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, stw);
+                hipError_t e = launch_wgrad_tr_dense(hprev, l.K, dz, ws.part, slab, (int)rows, l.K, l.N, wd, stw);
                 if (e != hipSuccess) return (int)e;
             }
-            rc = reduce_slabs(ws.part, slab, wd.nslab, grads + l.w_off, slab, accumulate, st, &ctx);
+            rc = reduce_slabs(ws.part, slab, wd.nslab, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (trw) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
@@ -2165,12 +2179,12 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             {
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
-                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
+                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, stw);
                 const int wtv = get_option("wgrad_tr", "MRL_WGRAD_TR", 1);
                 hipError_t e;
 #define MRL_WT(XP2, DP2, XP3, DP3, DBG)                                                                                   \
-    (ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, XP2, DP2, DBG>(hprev, dz, B, ws.part, nblocks, st)       \
-             : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, XP3, DP3, DBG>(hprev, dz, B, ws.part, nblocks, st))
+    (ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, XP2, DP2, DBG>(hprev, dz, B, ws.part, nblocks, stw)       \
+             : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, XP3, DP3, DBG>(hprev, dz, B, ws.part, nblocks, stw))
                 switch (wtv) {
 #ifdef MRL_X6_EXPERIMENTS       // 2-4: timing experiments (unpadded pixel strides; staging / MFMA phase left out)
                 case 2: e = MRL_WT(0, 0, 0, 0, 0); break;
@@ -2182,24 +2196,24 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
 #undef MRL_WT
                 if (e != hipSuccess) return (int)e;
             }
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (wx.cfg) {
             char label[40];
             if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
             hipError_t e;
             {
-                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, st);
+                ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, stw);
                 if (l.kind == 0) {
                     X6ConvA ca;
                     fill_conv(ca, l, hprev, (int)rows, nullptr);
-                    e = launch_wgrad_x8(ca, dz, ws.part, slab, (int)rows, l.K, l.N, wx, st);
+                    e = launch_wgrad_x8(ca, dz, ws.part, slab, (int)rows, l.K, l.N, wx, stw);
                 } else {
-                    e = launch_wgrad_x8(X6DenseA{hprev, (long)l.K}, dz, ws.part, slab, (int)rows, l.K, l.N, wx, st);
+                    e = launch_wgrad_x8(X6DenseA{hprev, (long)l.K}, dz, ws.part, slab, (int)rows, l.K, l.N, wx, stw);
                 }
             }
             if (e != hipSuccess) return (int)e;
-            rc = reduce_slabs(ws.part, slab, wx.nslab, grads + l.w_off, slab, accumulate, st, &ctx);
+            rc = reduce_slabs(ws.part, slab, wx.nslab, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (ik == 1 && first && !tuned(l, "wgrad") && get_option("u8_bf16x3", "MRL_U8_BF16X3", 1) &&
                    get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 2) {
@@ -2209,20 +2223,20 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             {
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
-                ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, st);
-                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, st, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3,
+                ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, stw);
+                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, stw, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3,
                                                    std::max(0, dbg_option("c1_dbg", "MRL_C1_DBG") - 64));
                 if (e != hipSuccess) return (int)e;
             }
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (ik && (var == V_IMGRES || tune_table().find(std::string(l.name) + ".wgrad") == tune_table().end())) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
             nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;
-            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, nullptr, B, ws.part, nblocks, st);
+            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, nullptr, B, ws.part, nblocks, stw);
             if (rc) return rc;
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, st, &ctx);
+            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else {
         if (var >= V_WRES16) var = l.N <= 32 ? V_128x32 : (l.N <= 64 ? V_128x64_W41 : V_128x128);
@@ -2236,27 +2250,27 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             if (first && m->d.ob_dtype != MRL_OB_U8) {
                 ConvPatchMC<2> af;
                 fill_conv(af, l, in.obs, (int)rows, in.srow);
-                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, stw);
             } else if (first) {
                 ConvPatchMC<1> af;
                 fill_conv(af, l, in.obs, (int)rows, in.srow);
-                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, stw);
             } else {
                 ConvPatchMC<false> af;
                 fill_conv(af, l, hprev, (int)rows, nullptr);
-                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, (int)rows, sp.nsplit, sp.ksplit, stw);
             }
         } else {
             if (first) {
                 RowMC af{(const float*)in.obs, l.K, l.K, B, is_vec(in.obs, l.K), in.srow};
-                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, stw);
             } else {
                 RowMC af{hprev, l.K, l.K, B, is_vec(hprev, l.K), nullptr};
-                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, st);
+                rc = gemm_dispatch(l.name, "wgrad", var, af, bfm, ep, l.K, l.N, B, sp.nsplit, sp.ksplit, stw);
             }
         }
         if (rc) return rc;
-        rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, st, &ctx);
+        rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, stw, &ctx);
         if (rc) return rc;
         }
         // data parallel: the tail of the flat gradient [this layer .. heads] is final -> it travels (RCCL, communication

@@ -14,6 +14,7 @@
 //                       gradients w.r.t. the online variables only, each clipped by its OWN norm (tf.clip_by_norm, 10)
 //   act               deepq/build_graph.py:146-199: argmax_a q, replaced by a uniform random action with probability eps
 #pragma once
+#include "qheads.hip.h"
 
 struct mrl_qnet {
     mrl_qnet_desc qd;
@@ -164,6 +165,8 @@ static void q_carve(const mrl_qnet* q, int B, char* base, QWs& ws) {
     do_net(q->base.pi, ws.feat);
     do_net(q->av, ws.av);
     if (q->dueling) do_net(q->sv, ws.sv);
+    if (q->qd.nhidden == 1)      // K-split partials of the fused heads' hidden layer (qheads.hip.h): up to 16 x [B][N_a + N_s]
+        part_floats = std::max(part_floats, (size_t)16 * std::min(B, 256) * (q->av.L[0].N + (q->dueling ? q->sv.L[0].N : 0)));
     const size_t qa = (size_t)B * q->qd.nact * 4;
     ws.q_t = (float*)take(qa); ws.q_tp1 = (float*)take(qa); ws.q_tp1_on = (float*)take(qa); ws.dq = (float*)take(qa);
     ws.dlat_tmp = (float*)take((size_t)B * q->nlat * 4);
@@ -244,6 +247,70 @@ __global__ __launch_bounds__(256) void q_policy_kl_kernel(const float* __restric
     }
     const double t = block_sum_256(s, sh);
     if (threadIdx.x == 0) out[0] = (float)(t / (double)B);
+}
+// Round 6: the data gradient of the head(s) into the latent at learner batch sizes.  dlat[b][k] = act'(lat[b][k]) * (sum_n dzA[b][n] WA[k][n]
+// + sum_n dzB[b][n] WB[k][n]) is a 32-row GEMM (batch 32: deepq.py:100) whose 2 x 7744 x 256 weights are read once: on the 128 x 128
+// tile engine it ran as 2 launches of 61 workgroups with 32 of 128 rows live and 8 dependent k steps each (48 + 68 us of a 730 us
+// learner step).  Here a workgroup owns 32 latent columns, its NW waves split the reduction (both heads' hidden units, concatenated)
+// and run it on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) straight from 16-byte loads --
+// lane (r, half) holds dz[b0 + r][8c + 4 half ..+3] and W[k0 + r][the same four n]: the reduction index of an MFMA step only has to
+// be the SAME n on both operands --, the partial tiles are summed through LDS in wave order (deterministic).
+struct QLatDgradArgs {
+    const float* dz[2]; const float* W[2]; int N[2];     // per head: dz [B][N], W [K][N]; N % 8 == 0 (N[1] == 0: one head)
+    const float* h; int act;                              // latent activations (act' source) or nullptr
+    float* out; int B, K;
+    int w16[2];                                           // W rows 16-byte aligned (else 8: two 8-byte loads per fragment)
+};
+__device__ __forceinline__ float4 q_ld4(const float* p, bool a16) {
+    if (a16) return *reinterpret_cast<const float4*>(p);
+    const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void q_lat_dgrad_kernel(QLatDgradArgs a) {
+    __shared__ float red[NW][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
+    const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int c0 = a.N[0] >> 3, ctot = c0 + (a.N[1] >> 3);
+    const int per = (ctot + NW - 1) / NW, cb = wave * per, ce = min(ctot, cb + per);
+    const bool brow = b0 + r < a.B, krow = k0 + r < a.K;
+    const float* dzr[2] = {a.dz[0] + (long)(b0 + r) * a.N[0] + 4 * hf, a.dz[1] ? a.dz[1] + (long)(b0 + r) * a.N[1] + 4 * hf : nullptr};
+    const float* wr[2] = {a.W[0] + (long)(k0 + r) * a.N[0] + 4 * hf, a.W[1] ? a.W[1] + (long)(k0 + r) * a.N[1] + 4 * hf : nullptr};
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int U = 4;
+    for (int c = cb; c < ce; c += U) {
+        float4 fa[U], fb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c + u;
+            const bool live = cc < ce;
+            const int hd = cc >= c0;
+            const long o = 8L * (hd ? cc - c0 : cc);
+            fa[u] = (live && brow) ? *reinterpret_cast<const float4*>(dzr[hd] + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            fb[u] = (live && krow) ? q_ld4(wr[hd] + o, a.w16[hd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].x, fb[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].y, fb[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].z, fb[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].w, fb[u].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][(i >> 2) * 8 + hf * 4 + (i & 3)][r] = acc[i];      // row = sample, column = latent unit
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 1024; idx += 64 * NW) {
+        const int b = idx >> 5, k = idx & 31;
+        if (b0 + b >= a.B || k0 + k >= a.K) continue;
+        float v = red[0][b][k];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w][b][k];
+        const long o = (long)(b0 + b) * a.K + k0 + k;
+        a.out[o] = a.h ? v * act_bwd_from_out(a.h[o], a.act) : v;
+    }
 }
 // out = (out_prev + acc) * act'(h): second half of a two-source data gradient
 struct EpiAddMaskAct {
@@ -340,6 +407,86 @@ __global__ __launch_bounds__(256) void q_adam_kernel(float* __restrict__ p, floa
     }
 }
 
+// ---- fused heads (qheads.hip.h) ---------------------------------------------------------------------------------------
+static int q_lat_dgrad(const mrl_qnet* q, const float* params, QWs& ws, float* dlat, int B, hipStream_t st);
+static bool q_heads_fused_ok(const mrl_qnet* q, int B) {
+    if (B > 256 || q->qd.nhidden != 1 || q->qd.layer_norm || q->qd.nact > QH_MAXOUT || q->nlat % 8 || q->base.pi.L.empty() ||
+        !get_option("dqn_heads", "MRL_DQN_HEADS", 1))
+        return false;
+    if (!tune_table().empty())
+        for (const char* nm : {"av0", "av1", "sv0", "sv1"})
+            for (const char* pass : {".fwd", ".wgrad", ".dgrad"})
+                if (tune_table().count(std::string(nm) + pass)) return false;
+    if (q->av.L.size() != 2 || q->av.L[0].N % 32 || (q->dueling && (q->sv.L.size() != 2 || q->sv.L[0].N % 32))) return false;
+    return true;
+}
+static QHeads q_heads_desc(const mrl_qnet* q, const float* params) {
+    QHeads hd{};
+    const Net* nets[2] = {&q->av, &q->sv};
+    hd.nheads = q->dueling ? 2 : 1;
+    hd.K = q->nlat;
+    for (int i = 0; i < hd.nheads; ++i) {
+        const Layer &l0 = nets[i]->L[0], &l1 = nets[i]->L[1];
+        hd.W0[i] = params + l0.w_off; hd.b0[i] = params + l0.b_off; hd.W1[i] = params + l1.w_off; hd.b1[i] = params + l1.b_off;
+        hd.N0[i] = l0.N; hd.nout[i] = l1.N;
+    }
+    return hd;
+}
+// latent [B][K] -> hidden activations (ws.av.h[0], ws.sv.h[0]), raw head outputs (h[1]) and q_out
+static int q_heads_forward_fused(const mrl_qnet* q, const float* lat, const float* params, QWs& ws, int B, float* q_out, hipStream_t st) {
+    const QHeads hd = q_heads_desc(q, params);
+    const int ntot = hd.N0[0] + (hd.nheads > 1 ? hd.N0[1] : 0), ntiles = ntot / 32, kc = hd.K / 8;
+    const int MT = B <= 32 ? 1 : 2, zg = (B + 32 * MT - 1) / (32 * MT);
+    long S = std::max(1, std::min(16, 512 / (ntiles * zg)));
+    S = std::min<long>(S, (long)(ws.part_floats / ((size_t)B * ntot)));
+    S = std::min<long>(S, std::max(1, kc / 8));
+    if (S < 1) return MRL_ENOSPC;
+    const int cps = (int)((kc + S - 1) / S);
+    S = (kc + cps - 1) / cps;
+    {
+        ProfScope ps("heads.fwd", 2.0 * B * (double)hd.K * ntot, 0.0, st);
+        if (MT == 1) hipLaunchKernelGGL(q_heads_fwd_kernel<1>, dim3(ntiles, (int)S, zg), dim3(512), 0, st, hd, lat, B, ws.part, cps);
+        else hipLaunchKernelGGL(q_heads_fwd_kernel<2>, dim3(ntiles, (int)S, zg), dim3(512), 0, st, hd, lat, B, ws.part, cps);
+        MRL_LAUNCH_CHECK();
+    }
+    ProfScope ps("heads.out", 0.0, 4.0 * B * (double)ntot * (S + 2), st);
+    hipLaunchKernelGGL(q_heads_out_kernel, dim3(B), dim3(256), 0, st, hd, ws.part, (int)S, B, ws.av.h[0], q->dueling ? ws.sv.h[0] : nullptr,
+                       ws.av.h[1], q->dueling ? ws.sv.h[1] : nullptr, q_out);
+    MRL_LAUNCH_CHECK();
+    return 0;
+}
+// dq [B][nA] -> gradients of all four head tensors (+ biases) in the flat gradient, and (q_lat_dgrad) the latent's gradient
+static int q_heads_backward_fused(const mrl_qnet* q, const float* lat, const float* params, QWs& ws, float* grads, float* dlat, int B,
+                                  hipStream_t st, StepCtx& ctx) {
+    const QHeads hd = q_heads_desc(q, params);
+    const Layer &a0 = q->av.L[0], &a1 = q->av.L[1];
+    const Layer* s0 = q->dueling ? &q->sv.L[0] : nullptr;
+    const Layer* s1 = q->dueling ? &q->sv.L[1] : nullptr;
+    const int ntot = hd.N0[0] + (hd.nheads > 1 ? hd.N0[1] : 0);
+    {
+        ProfScope ps("heads.bwd", 0.0, 12.0 * B * (double)ntot, st);
+        hipLaunchKernelGGL(q_heads_bwd_kernel, dim3(B + hd.nheads), dim3(256), (size_t)B * hd.nout[0] * sizeof(float), st, hd, ws.dq, B,
+                           ws.av.h[0], s0 ? ws.sv.h[0] : nullptr, ws.av.dz[1], s0 ? ws.sv.dz[1] : nullptr, ws.av.dz[0],
+                           s0 ? ws.sv.dz[0] : nullptr, grads + a1.w_off, grads + a1.b_off, s1 ? grads + s1->w_off : nullptr,
+                           s1 ? grads + s1->b_off : nullptr);
+        MRL_LAUNCH_CHECK();
+    }
+    hipStream_t stw = st;
+    if (ctx.wstream) {
+        MRL_HIP_CHECK(hipEventRecord(ctx.ev_fork, st));
+        MRL_HIP_CHECK(hipStreamWaitEvent(ctx.wstream, ctx.ev_fork, 0));
+        stw = ctx.wstream;
+    }
+    {
+        ProfScope ps("heads0.wgrad", 2.0 * B * (double)hd.K * ntot, 0.0, stw);
+        hipLaunchKernelGGL(q_heads_wgrad_kernel, dim3((hd.K + 31) / 32, (ntot / 32 + 3) / 4), dim3(256), 0, stw, hd, lat, ws.av.dz[0],
+                           s0 ? ws.sv.dz[0] : nullptr, B, grads + a0.w_off, grads + a0.b_off, s0 ? grads + s0->w_off : nullptr,
+                           s0 ? grads + s0->b_off : nullptr);
+        MRL_LAUNCH_CHECK();
+    }
+    return q_lat_dgrad(q, params, ws, dlat, B, st);
+}
+
 // ---- forward --------------------------------------------------------------------------------------------------------
 static int q_heads_forward(const mrl_qnet* q, const Net& net, const float* lat, const float* params, NetWs& nw, int B,
                            hipStream_t st, float* part, size_t part_floats) {
@@ -366,6 +513,7 @@ static int q_forward(const mrl_qnet* q, const float* params, const void* obs, in
     int rc = net_forward(&q->base, q->base.pi, in, params, ws.feat, B, st, ws.part, ws.part_floats);
     if (rc) return rc;
     const float* lat = ws.feat.h.back();
+    if (q_heads_fused_ok(q, B)) return q_heads_forward_fused(q, lat, params, ws, B, q_out, st);
     if ((rc = q_heads_forward(q, q->av, lat, params, ws.av, B, st, ws.part, ws.part_floats))) return rc;
     if (q->dueling && (rc = q_heads_forward(q, q->sv, lat, params, ws.sv, B, st, ws.part, ws.part_floats))) return rc;
     hipLaunchKernelGGL(q_dueling_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.av.h.back(),
@@ -415,14 +563,14 @@ extern "C" int mrl_qnet_policy_kl(const float* q_a, const float* q_b, int n, int
 
 // ---- TD gradient --- deepq/build_graph.py:380-421 -------------------------------------------------------------------
 static int q_heads_backward(const mrl_qnet* q, const Net& net, const float* lat, const float* params, NetWs& nw, QWs& qws,
-                            float* grads, float* dlat, bool add, int B, hipStream_t st) {
+                            float* grads, float* dlat, bool add, int B, hipStream_t st, StepCtx& ctx, bool into_latent = true) {
     // weight gradients of the head layers + data gradients between them (net_backward treats `in.obs` as the fc input)
     Ws ws{};
     ws.part = qws.part; ws.part_floats = qws.part_floats; ws.zeros = qws.zeros;
     In in{lat, nullptr};
-    StepCtx ctx;
     int rc = net_backward<kExp>(&q->base, net, in, params, nw, ws, grads, B, 0, st, ctx, false);
     if (rc) return rc;
+    if (!into_latent) return 0;
     // into the latent: dlat (+)= dz0 @ W0^T, masked by act'(latent) when it is the last contribution
     const Layer& l0 = net.L[0];
     const float* dz = nw.dz[0];
@@ -437,6 +585,36 @@ static int q_heads_backward(const mrl_qnet* q, const Net& net, const float* lat,
     }
     EpiMaskAct ef{q->dueling ? qws.dlat_tmp : dlat, l0.K, q->dueling ? nullptr : hm, q->lat_act};
     return gemm_dispatch(l0.name, "dgrad", dv, af, bf, ef, B, l0.K, l0.N, 1, l0.N, st);
+}
+// both heads' first layers into the latent in one launch (q_lat_dgrad_kernel); false: shapes / alignment it does not take
+static bool q_lat_dgrad_ok(const mrl_qnet* q, const float* params, const QWs& ws, int B) {
+    if (B > 256 || !get_option("dqn_latdgrad", "MRL_DQN_LATDGRAD", 1) || tune_table().count("av0.dgrad") || tune_table().count("sv0.dgrad"))
+        return false;
+    const Net* nets[2] = {&q->av, q->dueling ? &q->sv : nullptr};
+    const NetWs* nws[2] = {&ws.av, &ws.sv};
+    for (int i = 0; i < 2; ++i) {
+        if (!nets[i]) continue;
+        const Layer& l0 = nets[i]->L[0];
+        if (l0.kind != 1 || l0.N % 8 || l0.K != nets[0]->L[0].K || (uintptr_t)(params + l0.w_off) % 8 || (uintptr_t)nws[i]->dz[0] % 16) return false;
+    }
+    return true;
+}
+static int q_lat_dgrad(const mrl_qnet* q, const float* params, QWs& ws, float* dlat, int B, hipStream_t st) {
+    QLatDgradArgs a{};
+    const Layer& la = q->av.L[0];
+    a.dz[0] = ws.av.dz[0]; a.W[0] = params + la.w_off; a.N[0] = la.N; a.w16[0] = (uintptr_t)a.W[0] % 16 == 0;
+    double fl = 2.0 * B * (double)la.K * la.N;
+    if (q->dueling) {
+        const Layer& ls = q->sv.L[0];
+        a.dz[1] = ws.sv.dz[0]; a.W[1] = params + ls.w_off; a.N[1] = ls.N; a.w16[1] = (uintptr_t)a.W[1] % 16 == 0;
+        fl += 2.0 * B * (double)ls.K * ls.N;
+    }
+    a.h = q->base.pi.L.empty() ? nullptr : ws.feat.h.back();
+    a.act = q->lat_act; a.out = dlat; a.B = B; a.K = la.K;
+    ProfScope ps("heads0.dgrad", fl, 0.0, st);
+    hipLaunchKernelGGL(q_lat_dgrad_kernel<8>, dim3((a.K + 31) / 32, (B + 31) / 32), dim3(512), 0, st, a);
+    MRL_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const float* target_params, const void* obs_t,
@@ -505,18 +683,35 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
     if ((rc = mrl_dqn_td(ws.q_t, wtr.q_tp1, q_tp1_on, act, rew, done, weights, gamma, B, nA, td_out,
                          loss_out, ws.dq, ws.td_scratch, stream)))
         return rc;
-    hipLaunchKernelGGL(q_dueling_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.dq, ws.av.dz.back(),
-                       q->dueling ? ws.sv.dz.back() : nullptr, B, nA);
-    MRL_LAUNCH_CHECK();
     const float* lat = ws.feat.h.back();
     float* dlat = ws.feat.dz.back();
-    if ((rc = q_heads_backward(q, q->av, lat, params, ws.av, ws, grads_out, dlat, false, B, st))) return rc;
-    if (q->dueling && (rc = q_heads_backward(q, q->sv, lat, params, ws.sv, ws, grads_out, dlat, true, B, st))) return rc;
+    const bool fused = q_heads_fused_ok(q, B) && q_lat_dgrad_ok(q, params, ws, B);
+    if (!fused) {
+        hipLaunchKernelGGL(q_dueling_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.dq, ws.av.dz.back(),
+                           q->dueling ? ws.sv.dz.back() : nullptr, B, nA);
+        MRL_LAUNCH_CHECK();
+    }
+    // the weight gradients hang off the dz chain: with the side stream free again (the target pass was joined above) they run there,
+    // next to the data gradients (StepCtx::wstream); joined below, before the caller's stream reads the gradient
+    StepCtx ctx;
+    if (par && get_option("dqn_wstream", "MRL_DQN_WSTREAM", 1)) { ctx.wstream = q->side; ctx.ev_fork = q->ev_fork; ctx.ev_join = q->ev_join; }
+    const bool one_dgrad = q_lat_dgrad_ok(q, params, ws, B);
+    if (fused) {
+        if ((rc = q_heads_backward_fused(q, lat, params, ws, grads_out, dlat, B, st, ctx))) return rc;
+    } else {
+    if ((rc = q_heads_backward(q, q->av, lat, params, ws.av, ws, grads_out, dlat, false, B, st, ctx, !one_dgrad))) return rc;
+    if (q->dueling && (rc = q_heads_backward(q, q->sv, lat, params, ws.sv, ws, grads_out, dlat, true, B, st, ctx, !one_dgrad))) return rc;
+    if (one_dgrad && (rc = q_lat_dgrad(q, params, ws, dlat, B, st))) return rc;
+    }
     Ws mws{};
     mws.part = ws.part; mws.part_floats = ws.part_floats; mws.zeros = ws.zeros;
     In in{obs_t, nullptr};
-    StepCtx ctx;
-    return net_backward<kExp>(&q->base, q->base.pi, in, params, ws.feat, mws, grads_out, B, 0, st, ctx, false);
+    rc = net_backward<kExp>(&q->base, q->base.pi, in, params, ws.feat, mws, grads_out, B, 0, st, ctx, false);
+    if (ctx.wstream) {
+        MRL_HIP_CHECK(hipEventRecord(q->ev_join, q->side));
+        MRL_HIP_CHECK(hipStreamWaitEvent(st, q->ev_join, 0));
+    }
+    return rc;
 }
 
 // per-variable clip_by_norm + Adam (deepq/deepq.py:205-208: tf.train.AdamOptimizer(lr), grad_norm_clipping=10)

@@ -53,6 +53,31 @@ __global__ __launch_bounds__(256) void take_rows_kernel(const V* __restrict__ sr
     }
 }
 
+// the whole minibatch in one launch: obs_t rows, obs_tp1 rows and (the last B items) the three scalar columns
+template <typename V>
+__global__ __launch_bounds__(256) void gather_all_kernel(const V* __restrict__ o1, const V* __restrict__ o2, const int32_t* __restrict__ act,
+                                                         const float* __restrict__ rew, const float* __restrict__ done,
+                                                         const int32_t* __restrict__ idx, V* __restrict__ o1_out, V* __restrict__ o2_out,
+                                                         int32_t* __restrict__ act_out, float* __restrict__ rew_out,
+                                                         float* __restrict__ done_out, long B, int rowv) {
+    const long per = B * rowv, total = 2 * per + B;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += (long)gridDim.x * 256L) {
+        if (q >= 2 * per) {
+            const long b = q - 2 * per;
+            const long i = idx[b];
+            act_out[b] = act[i]; rew_out[b] = rew[i]; done_out[b] = done[i];
+            continue;
+        }
+        const bool second = q >= per;
+        const long qq = second ? q - per : q;
+        const long b = qq / rowv;
+        const int c = (int)(qq - b * rowv);
+        const long s = (long)idx[b] * rowv + c;
+        if (second) o2_out[qq] = o2[s];
+        else o1_out[qq] = o1[s];
+    }
+}
+
 static int pick_unit(int row_bytes, const void* a, const void* b) {
     auto al = [](const void* p, int k) { return ((uintptr_t)p % k) == 0; };
     if (row_bytes % 16 == 0 && al(a, 16) && al(b, 16)) return 16;
@@ -382,6 +407,14 @@ extern "C" int mrl_replay_gather(const void* obs_t_buf, const void* obs_tp1_buf,
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps("replay_gather", 0.0, 2.0 * B * (2.0 * ob_bytes + 12.0) + 4.0 * B, st);
     int rc;
+    if (B > 0 && pick_unit(ob_bytes, obs_t_buf, obs_t_out) == 16 && pick_unit(ob_bytes, obs_tp1_buf, obs_tp1_out) == 16) {
+        const int rowv = ob_bytes / 16;
+        const int blocks = (int)std::min<long>((2L * B * rowv + B + 255) / 256, 16384);
+        hipLaunchKernelGGL(gather_all_kernel<uint4>, dim3(blocks), dim3(256), 0, st, (const uint4*)obs_t_buf, (const uint4*)obs_tp1_buf, act_buf,
+                           rew_buf, done_buf, idx, (uint4*)obs_t_out, (uint4*)obs_tp1_out, act_out, rew_out, done_out, (long)B, rowv);
+        MRL_LAUNCH_CHECK();
+        return 0;
+    }
     if ((rc = take_rows(obs_t_buf, idx, obs_t_out, B, ob_bytes, st))) return rc;
     if ((rc = take_rows(obs_tp1_buf, idx, obs_tp1_out, B, ob_bytes, st))) return rc;
     if ((rc = take_rows(act_buf, idx, act_out, B, 4, st))) return rc;

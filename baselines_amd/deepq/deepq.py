@@ -141,12 +141,17 @@ def learn(env, network, seed=None, lr=5e-4, total_timesteps=100000, buffer_size=
     checkpoints.load_existing(load_path)
 
     def train_step(t):
+        # the minibatch is gathered straight into the captured step's static input buffers when the replay stores observations
+        # in the form the network takes them (not for one-hot encoded Discrete observations)
+        gin = model.graph_inputs(batch_size)
+        if tuple(gin['o1'].shape[1:]) != tuple(replay_buffer._ob_shape) or gin['o1'].dtype != replay_buffer._ob_dtype:
+            gin = None
         if prioritized_replay:
-            o1, a, r, o2, d, w, idx = replay_buffer.sample_dev(batch_size, beta=beta_schedule.value(t))
+            o1, a, r, o2, d, w, idx = replay_buffer.sample_dev(batch_size, beta=beta_schedule.value(t), out=gin)
             td = model.train_dev(o1, a, r, o2, d, w)
             replay_buffer.update_priorities_from_td(idx, td, eps=prioritized_replay_eps)
         else:
-            o1, a, r, o2, d = replay_buffer.sample_dev(batch_size)
+            o1, a, r, o2, d = replay_buffer.sample_dev(batch_size, out=gin)
             model.train_dev(o1, a, r, o2, d, model.ones(batch_size))
 
     n_actions = float(env.action_space.n)

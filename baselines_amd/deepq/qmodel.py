@@ -300,20 +300,14 @@ class QModel(object):
             self._step_launches(o12[:B], action, reward, o12[B:], done, weight, td, B, self._next_alpha(), None)
             self.last_td = td
             return td
-        g = self._graphs.get(B)
-        if g is None:
-            o12 = torch.empty((2 * B,) + tuple(obs_t.shape[1:]), dtype=obs_t.dtype, device=self.device)    # obs_t | obs_tp1 back to back:
-            g = dict(o1=o12[:B], o2=o12[B:],                                                                # one online pass of 2 B rows
-                     a=torch.empty(B, dtype=torch.int32, device=self.device),
-                     r=torch.empty(B, dtype=torch.float32, device=self.device),
-                     d=torch.empty(B, dtype=torch.float32, device=self.device),
-                     w=torch.empty(B, dtype=torch.float32, device=self.device),
-                     td=torch.empty(B, dtype=torch.float32, device=self.device),
-                     alpha=torch.zeros(1, dtype=torch.float32, device=self.device), graph=None, ws=self.workspace.data_ptr())
-            self._graphs[B] = g
+        g = self.graph_inputs(B, tuple(obs_t.shape[1:]), obs_t.dtype)
         for k, src in (('o1', obs_t), ('o2', obs_tp1), ('a', action), ('r', reward), ('d', done), ('w', weight)):
-            g[k].copy_(src)
-        g['alpha'].fill_(float(self._next_alpha()))
+            if src.data_ptr() != g[k].data_ptr():        # a minibatch sampled straight into the static buffers needs no copy
+                g[k].copy_(src)
+        alpha = float(self._next_alpha())
+        if alpha != g['alpha_host']:                     # constant after Adam's bias correction has saturated in fp32
+            g['alpha'].fill_(alpha)
+            g['alpha_host'] = alpha
         if g['graph'] is None or g['ws'] != self.workspace.data_ptr():
             # first step at this batch size: run it eagerly from the static buffers (also warms every kernel up), capture the
             # launch sequence for the following steps
@@ -334,6 +328,25 @@ class QModel(object):
             g['graph'].replay()
         self.last_td = g['td']
         return g['td']
+
+    def graph_inputs(self, B, ob_shape=None, ob_dtype=None):
+        """The static input buffers of the captured step at batch size B (o1 | o2 back to back: one online pass of 2 B rows).
+        `ReplayBuffer.sample_dev(..., out=model.graph_inputs(B))` gathers the minibatch straight into them."""
+        g = self._graphs.get(B)
+        if g is None:
+            if ob_shape is None:
+                ob_shape, ob_dtype = ((self.ob_onehot,), torch.float32) if self.ob_onehot else (tuple(self.ob_shape), self.torch_ob_dtype)
+            o12 = torch.empty((2 * B,) + tuple(ob_shape), dtype=ob_dtype, device=self.device)
+            g = dict(o1=o12[:B], o2=o12[B:],
+                     a=torch.empty(B, dtype=torch.int32, device=self.device),
+                     r=torch.empty(B, dtype=torch.float32, device=self.device),
+                     d=torch.empty(B, dtype=torch.float32, device=self.device),
+                     w=torch.empty(B, dtype=torch.float32, device=self.device),
+                     td=torch.empty(B, dtype=torch.float32, device=self.device),
+                     alpha=torch.zeros(1, dtype=torch.float32, device=self.device), alpha_host=0.0, graph=None,
+                     ws=self.workspace.data_ptr())
+            self._graphs[B] = g
+        return g
 
     def train(self, obs_t, action, reward, obs_tp1, done, weight):
         """one optimizer step; returns td_errors f32 [B] on the host (build_graph.py:430-441)"""

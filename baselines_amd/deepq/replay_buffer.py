@@ -85,13 +85,19 @@ class ReplayBuffer(object):
                        np.asarray(obs_tp1)[None], np.asarray([float(done)], np.float32))
 
     # ---- sampling --------------------------------------------------------------------------
-    def _gather_dev(self, idx_dev):
+    def _gather_dev(self, idx_dev, out=None):
+        """`out`: a dict of preallocated destination tensors o1 / o2 / a / r / d (`QModel.graph_inputs(B)`: the minibatch then lands in
+        the captured optimizer step's static input buffers and `train_dev` has nothing to copy)"""
         B = int(idx_dev.numel())
-        o1 = torch.empty((B,) + self._ob_shape, dtype=self._ob_dtype, device=self.device)
-        o2 = torch.empty_like(o1)
-        a = torch.empty(B, dtype=torch.int32, device=self.device)
-        r = torch.empty(B, dtype=torch.float32, device=self.device)
-        d = torch.empty(B, dtype=torch.float32, device=self.device)
+        if out is not None:
+            o1, o2, a, r, d = out['o1'], out['o2'], out['a'], out['r'], out['d']
+            assert tuple(o1.shape) == (B,) + tuple(self._ob_shape) and o1.dtype == self._ob_dtype and o1.is_contiguous() and o2.is_contiguous()
+        else:
+            o1 = torch.empty((B,) + self._ob_shape, dtype=self._ob_dtype, device=self.device)
+            o2 = torch.empty_like(o1)
+            a = torch.empty(B, dtype=torch.int32, device=self.device)
+            r = torch.empty(B, dtype=torch.float32, device=self.device)
+            d = torch.empty(B, dtype=torch.float32, device=self.device)
         check(_lib.load().mrl_replay_gather(ptr(self._obs_t), ptr(self._obs_tp1), ptr(self._act), ptr(self._rew),
                                             ptr(self._done), ptr(idx_dev), B, self._ob_bytes, ptr(o1), ptr(o2), ptr(a),
                                             ptr(r), ptr(d), stream_ptr()), 'mrl_replay_gather')
@@ -109,11 +115,11 @@ class ReplayBuffer(object):
         idxes = [random.randint(0, self._len - 1) for _ in range(batch_size)]
         return self._encode_sample(idxes)
 
-    def sample_dev(self, batch_size):
+    def sample_dev(self, batch_size, out=None):
         """the same draw (same `random` stream, same indices) with the minibatch left on the device:
-        -> (obs_t, actions int32, rewards f32, obs_tp1, dones f32) device tensors"""
+        -> (obs_t, actions int32, rewards f32, obs_tp1, dones f32) device tensors (`out`: see _gather_dev)"""
         idxes = [random.randint(0, self._len - 1) for _ in range(batch_size)]
-        return self._gather_dev(torch.as_tensor(np.asarray(idxes, dtype=np.int32), device=self.device))
+        return self._gather_dev(torch.as_tensor(np.asarray(idxes, dtype=np.int32), device=self.device), out)
 
 
 class PrioritizedReplayBuffer(ReplayBuffer):
@@ -152,18 +158,19 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         return start, n
 
     # ---- sampling --------------------------------------------------------------------------
-    def sample_dev(self, batch_size, beta, uniforms=None):
-        """-> (obs_t, actions int32, rewards, obs_tp1, dones, weights f32, idxes int32), all device tensors"""
+    def sample_dev(self, batch_size, beta, uniforms=None, out=None):
+        """-> (obs_t, actions int32, rewards, obs_tp1, dones, weights f32, idxes int32), all device tensors
+        (`out`: destination tensors o1 / o2 / a / r / d / w, see _gather_dev)"""
         assert beta > 0
         if uniforms is None:
             uniforms = [random.random() for _ in range(batch_size)]       # replay_buffer.py:112
         u = torch.as_tensor(np.asarray(uniforms, dtype=np.float64), device=self.device)
         idx = torch.empty(batch_size, dtype=torch.int32, device=self.device)
         w64 = torch.empty(batch_size, dtype=torch.float64, device=self.device)
-        w32 = torch.empty(batch_size, dtype=torch.float32, device=self.device)
+        w32 = out['w'] if out is not None else torch.empty(batch_size, dtype=torch.float32, device=self.device)
         check(_lib.load().mrl_per_sample(ptr(self._sum), ptr(self._min), self._capacity, self._len, batch_size, ptr(u),
                                          float(beta), ptr(idx), ptr(w64), ptr(w32), stream_ptr()), 'mrl_per_sample')
-        o1, a, r, o2, d = self._gather_dev(idx)
+        o1, a, r, o2, d = self._gather_dev(idx, out)
         self._last_w64 = w64
         return o1, a, r, o2, d, w32, idx
 

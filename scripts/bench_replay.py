@@ -83,7 +83,7 @@ qm = QModel(build_q_func('conv_only'), Box(0, 255, SHAPE, np.uint8), NA, lr=1e-4
 
 
 def dqn_step(B=32, beta=0.4, graph=True):
-    o1, a, r, o2, d, w, idx = buf.sample_dev(B, beta)
+    o1, a, r, o2, d, w, idx = buf.sample_dev(B, beta, out=qm.graph_inputs(B))   # gathered into the captured step's static inputs
     td = qm.train_dev(o1, a, r, o2, d, w, graph=graph)       # device TD errors, no host round trip
     buf.update_priorities_from_td(idx, td)
 

@@ -18,6 +18,7 @@ from baselines_amd.deepq import PrioritizedReplayBuffer, QModel, build_q_func  #
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 CAP = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 SHAPE, NA = (84, 84, 4), 6
+ZERO_COPY = os.environ.get('ZERO_COPY', '1') != '0'     # sample into the captured step's static input buffers (deepq.learn does)
 torch.cuda.set_device(0)
 gen = torch.Generator(device='cuda').manual_seed(0)
 buf = PrioritizedReplayBuffer(CAP, alpha=0.6)
@@ -30,7 +31,7 @@ qm = QModel(build_q_func('conv_only'), Box(0, 255, SHAPE, np.uint8), NA, lr=1e-4
 
 
 def step(graph=True):
-    o1, a, r, o2, d, w, idx = buf.sample_dev(32, 0.4)
+    o1, a, r, o2, d, w, idx = buf.sample_dev(32, 0.4, out=qm.graph_inputs(32) if ZERO_COPY else None)
     td = qm.train_dev(o1, a, r, o2, d, w, graph=graph)
     buf.update_priorities_from_td(idx, td)
 

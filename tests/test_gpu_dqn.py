@@ -270,6 +270,74 @@ def test_train_dev_graph_replay_is_bit_identical_to_eager_launches(name):
     assert float((qa.params - torch.from_numpy(qa.get_flat_params()).cuda()).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('name,B', [('conv_only_dueling', 32), ('conv_only_small', 48), ('mlp_plain', 7), ('nature_cnn', 100)])
+def test_fused_heads_agree_with_the_layer_wise_path(name, B):
+    """The four-kernel form of the dueling heads (csrc/qheads.hip.h: fp32 matrix pipe, K split over workgroups, direct weight-gradient
+    stores) and the one-launch data gradient into the latent against the layer-by-layer tile engines (options dqn_heads / dqn_latdgrad = 0):
+    the same sums in another order -- q values, TD errors and every gradient tensor within 2e-6 of the tensor's scale."""
+    from baselines_amd import _lib
+    qm, _, _, b = _pair(name, B, 5)
+    dev = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x)).cuda().to(dt)
+    o12 = torch.cat([qm._obs(b['obs_t']), qm._obs(b['obs_tp1'])], dim=0)         # back to back: the merged online pass of 2 B rows
+    a, r, d, w = dev(b['act'], torch.int32), dev(b['rew'], torch.float32), dev(b['done'], torch.float32), dev(b['w'], torch.float32)
+    out = {}
+    try:
+        for mode in (1, 0):
+            _lib.set_option('dqn_heads', mode)
+            _lib.set_option('dqn_latdgrad', mode)
+            td = torch.empty(B, dtype=torch.float32, device='cuda')
+            qm.grads.zero_()
+            _lib.check(qm.lib.mrl_qnet_td_grad(qm.handle, _lib.ptr(qm.params), _lib.ptr(qm.target), _lib.ptr(o12[:B]), _lib.ptr(a), _lib.ptr(r),
+                                               _lib.ptr(o12[B:]), _lib.ptr(d), _lib.ptr(w), 0.99, 1, B, _lib.ptr(qm.grads), _lib.ptr(td),
+                                               _lib.ptr(qm._loss), _lib.ptr(qm.workspace), qm.workspace.numel(), _lib.stream_ptr()),
+                       'mrl_qnet_td_grad')
+            out[mode] = (qm.q_values(b['obs_t']).copy(), td.cpu().numpy(), qm.grads.cpu().numpy().copy(), float(qm._loss.cpu()))
+    finally:
+        _lib.set_option('dqn_heads', 1)
+        _lib.set_option('dqn_latdgrad', 1)
+    (q1, td1, g1, l1), (q0, td0, g0, l0) = out[1], out[0]
+    assert np.abs(q1 - q0).max() <= 2e-6 * max(1.0, np.abs(q0).max())
+    assert np.abs(td1 - td0).max() <= 4e-6 * max(1.0, np.abs(td0).max())
+    assert abs(l1 - l0) <= 2e-6 * max(1.0, abs(l0))
+    for t in qm.tensors:
+        sl = slice(t['offset'], t['offset'] + t['size'])
+        sc = max(np.abs(g0[sl]).max(), 1e-3 * np.abs(g0).max())
+        assert np.abs(g1[sl] - g0[sl]).max() <= 4e-6 * sc, (t['name'], np.abs(g1[sl] - g0[sl]).max(), sc)
+    assert np.abs(g1).max() > 0
+
+
+def test_sampling_into_the_graph_inputs_equals_the_copying_route():
+    """`sample_dev(..., out=model.graph_inputs(B))` gathers the minibatch (one launch) straight into the captured optimizer step's static
+    buffers; `train_dev` then copies nothing.  Same indices, same step: parameters and priorities equal the route through fresh tensors
+    bit for bit."""
+    from baselines_amd.deepq import PrioritizedReplayBuffer
+    B, n = 16, 200
+    runs = []
+    for zero_copy in (False, True):
+        qm, _, _, _ = _pair('conv_only_small', B, 11)
+        ob_shape = CASES['conv_only_small']['ob'].shape
+        rng = np.random.RandomState(3)
+        random.seed(5)
+        buf = PrioritizedReplayBuffer(256, alpha=0.6)
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        buf.add_batch(dev(rng.randint(0, 256, (n,) + ob_shape).astype(np.uint8)), dev(rng.randint(0, 4, n).astype(np.int32)),
+                      dev(rng.randn(n).astype(np.float32)), dev(rng.randint(0, 256, (n,) + ob_shape).astype(np.uint8)),
+                      dev((rng.rand(n) < 0.1).astype(np.float32)))
+        tds = []
+        for step in range(4):
+            out = qm.graph_inputs(B) if zero_copy else None
+            o1, a, r, o2, d, w, idx = buf.sample_dev(B, 0.4, out=out)
+            if zero_copy:
+                assert o1.data_ptr() == out['o1'].data_ptr() and w.data_ptr() == out['w'].data_ptr()
+            td = qm.train_dev(o1, a, r, o2, d, w)
+            buf.update_priorities_from_td(idx, td)
+            tds.append(td.cpu().numpy().copy())
+        runs.append((qm.get_flat_params(), np.stack(tds), buf.trees_numpy()))
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    np.testing.assert_array_equal(runs[0][2][0], runs[1][2][0])
+
+
 def test_prioritized_buffer_device_path_keeps_the_running_max_on_the_device():
     """`add` after `update_priorities_from_td`: the new leaves are max_priority ** alpha with the maximum the device path
     maintains (replay_buffer.py:100-105, 191) -- no host read-back; the trees equal the host path's to 1e-12 relative."""
