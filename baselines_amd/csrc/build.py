@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['rollout.hip', 'model.hip', 'envs.hip', 'replay.hip', 'wrappers.hip', 'comm.hip']
-HEADERS = ['common.hip.h', 'gemm.hip.h', 'wres.hip.h', 'imgres.hip.h', 'ldsdgrad.hip.h', 'mlpstep.hip.h', 'mlpact.hip.h', 'powcr.hip.h', 'gemmx6.hip.h', 'dgradx6.hip.h', 'gemmx6s.hip.h', 'gemmx6r.hip.h', 'convx6c.hip.h', 'c1fwd.hip.h', 'wgradx8.hip.h', 'wgradtr.hip.h', 'c1wgrad.hip.h', 'comm.hip.h', 'lstm.hip.h', 'qnet.hip.h', 'qheads.hip.h', 'planes.hip.h',
+HEADERS = ['common.hip.h', 'gemm.hip.h', 'wres.hip.h', 'imgres.hip.h', 'ldsdgrad.hip.h', 'mlpstep.hip.h', 'mlpact.hip.h', 'powcr.hip.h', 'gemmx6.hip.h', 'dgradx6.hip.h', 'gemmx6s.hip.h', 'gemmx6r.hip.h', 'convx6c.hip.h', 'c1fwd.hip.h', 'wgradx8.hip.h', 'wgradtr.hip.h', 'c1wgrad.hip.h', 'comm.hip.h', 'lstm.hip.h', 'qnet.hip.h', 'qheads.hip.h', 'convskinny.hip.h', 'planes.hip.h',
            os.path.join('..', '..', 'include', 'mrl.h')]
 LIB = os.path.join(HERE, 'libmrl.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

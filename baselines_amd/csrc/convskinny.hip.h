@@ -1,0 +1,110 @@
+// Convolution layers at latency-bound batch sizes (the DQN learner's batch 32 / 64, actor batches): register-direct implicit GEMMs on the
+// fp32 matrix pipe (round 6).
+//
+// The tiled engine (gemm.hip.h) stages one 128 x 32 operand tile per barrier pair with ONE tile of global loads in flight: at a few dozen
+// workgroups every k step costs a full memory round trip (2.7 - 5.5 us per step measured on the Q-network's SAME-padded conv layers:
+// 13 - 26 us per forward layer, 22 - 50 us per data gradient).  Here a workgroup owns 32 output rows x 32 TN columns, its NW waves split the
+// reduction and keep U chunks of 16-byte (A) / 4-byte (B) loads in flight straight into MFMA operand registers -- no LDS staging, no barrier
+// in the main loop --, and the NW partial tiles are summed through LDS in wave order (deterministic).  Hundreds of small workgroups
+// instead of dozens of large ones: two or more are co-resident per CU and cover each other's load latency.
+// Operand trick as in qheads.hip.h: lane (r, half) of v_mfma_f32_32x32x2_f32 supplies A[row r][kk = half] and B[kk = half][col r]; chunk c
+// of 8 reduction indices gives half h the four consecutive indices 8c + 4h .. + 3 (one per MFMA step), so an operand whose reduction index
+// is contiguous in memory arrives as one 16-byte load per chunk.
+#pragma once
+
+namespace mrl {
+
+// ---- forward: out[pixel][n] = act(bias[n] + sum_k patch(pixel)[k] W[k][n]) -----------------------------------------------------------------
+// SRC as conv_ld (0: fp32 activations, 1: uint8 pixels / 255, 2: fp32 pixels / 255); SAME / VALID padding through ConvGeom
+template <int SRC, int TN, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvGeom g, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, int NF, int act) {
+    __shared__ float red[NW][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32 * TN;
+    const int kc = g.kconv >> 3, per = (kc + NW - 1) / NW, cb = wave * per, ce = min(kc, cb + per);
+    // this lane's pixel
+    const int m = min(m0 + r, g.npix - 1);
+    const int ohw = g.OH * g.OW;
+    const int b = (int)g.d_ohw.div((uint32_t)m), rr = m - b * ohw;
+    const int oy = (int)g.d_ow.div((uint32_t)rr), ox = rr - oy * g.OW;
+    const long img = g.srow ? (long)g.srow[b] : (long)b;
+    const int iy0 = oy * g.stride - g.pad_t, ix0 = ox * g.stride - g.pad_l;
+    const long base = ((img * g.H + iy0) * g.W + ix0) * g.C;
+    const bool rowlive = m0 + r < g.npix;
+    const float* wp = w + n0 + r;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // chunks in groups of U, the next group's loads issued before the current group's MFMAs (two register sets, ping-pong)
+    constexpr int U = 4;
+    float4 fa[2][U];
+    float fb[2][U][TN][4];
+    auto load = [&](int set, int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = c + u < ce;
+            const int k = 8 * (c + u) + 4 * hf;
+            const int ky = (int)g.d_rowk.div((uint32_t)k), kr = k - ky * g.rowk;
+            const int kx = (int)g.d_c.div((uint32_t)kr);
+            const bool ok = live && rowlive && (unsigned)(iy0 + ky) < (unsigned)g.H && (unsigned)(ix0 + kx) < (unsigned)g.W;
+            fa[set][u] = ok ? conv_ld<SRC>(g.p, base + (long)ky * g.W * g.C + kr) : f4zero();
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[set][u][t][j] = (live && n0 + 32 * t + r < NF) ? wp[(long)(k + j) * NF + 32 * t] : 0.f;
+        }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].x, fb[set][u][t][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].y, fb[set][u][t][1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].z, fb[set][u][t][2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].w, fb[set][u][t][3], acc[t], 0, 0, 0);
+            }
+    };
+    if (cb < ce) load(0, cb);
+    for (int c = cb; c < ce; c += 2 * U) {
+        if (c + U < ce) load(1, c + U);
+        mma(0);
+        if (c + U < ce) {
+            if (c + 2 * U < ce) load(0, c + 2 * U);
+            mma(1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        if (t) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][(i >> 2) * 8 + hf * 4 + (i & 3)][r] = acc[t][i];      // row = pixel, column = filter
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 1024; idx += 64 * NW) {
+            const int p = idx >> 5, n = n0 + 32 * t + (idx & 31);
+            if (m0 + p >= g.npix || n >= NF) continue;
+            float v = red[0][p][idx & 31];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v += red[q][p][idx & 31];
+            out[(long)(m0 + p) * NF + n] = act_fwd(v + bias[n], act);
+        }
+    }
+}
+
+template <int SRC>
+static hipError_t launch_conv_skinny_fwd(const ConvGeom& g, const float* w, const float* bias, float* out, int NF, int act, hipStream_t st) {
+    const int mt = (g.npix + 31) / 32;
+    if (NF % 64 == 0) {
+        if (g.kconv > 256) hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 2, 8>), dim3(mt, NF / 64), dim3(512), 0, st, g, w, bias, out, NF, act);
+        else hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 2, 4>), dim3(mt, NF / 64), dim3(256), 0, st, g, w, bias, out, NF, act);
+    } else {
+        if (g.kconv > 256) hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 1, 8>), dim3(mt, (NF + 31) / 32), dim3(512), 0, st, g, w, bias, out, NF, act);
+        else hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 1, 4>), dim3(mt, (NF + 31) / 32), dim3(256), 0, st, g, w, bias, out, NF, act);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mrl

@@ -37,6 +37,7 @@
 #include "c1wgrad.hip.h"
 #include "mlpstep.hip.h"
 #include "mlpact.hip.h"
+#include "convskinny.hip.h"
 #include "comm.hip.h"
 #include "lstm.hip.h"
 
@@ -431,7 +432,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1}, {"dqn_latdgrad", "MRL_DQN_LATDGRAD", 1}, {"dqn_wstream", "MRL_DQN_WSTREAM", 1}, {"dqn_heads", "MRL_DQN_HEADS", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1}, {"dqn_latdgrad", "MRL_DQN_LATDGRAD", 1}, {"dqn_wstream", "MRL_DQN_WSTREAM", 1}, {"dqn_heads", "MRL_DQN_HEADS", 1}, {"conv_skinny", "MRL_CONV_SKINNY", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},
@@ -1796,6 +1797,13 @@ static int imgres_dispatch(int kind, const Layer& l, const void* x, const int32_
 }
 
 static bool tuned(const Layer& l, const char* pass);
+// the skinny-tile conv kernels (convskinny.hip.h) take over from the tiled engine where that one is latency-bound
+static bool conv_skinny_ok(const Layer& l, int npix, const void* src, const char* pass) {
+    if (!get_option("conv_skinny", "MRL_CONV_SKINNY", 1) || tuned(l, pass)) return false;
+    if (l.C % 4 || l.K % 8 || l.NF % 32 || (uintptr_t)src % 16) return false;
+    return ((long)npix + 127) / 128 * ((l.NF + 63) / 64) <= 2L * num_cus();
+}
+
 template <bool EXP>
 static int layer_forward(const mrl_model* m, const Layer& l, bool first, const In& in, const float* hprev,
                          const float* params, float* hout, uint16_t* planes, long long* dbgbuf, int B, hipStream_t st,
@@ -1927,6 +1935,18 @@ static int layer_forward(const mrl_model* m, const Layer& l, bool first, const I
             }
         }
         if (var >= V_WRES16) var = l.NF <= 32 ? V_128x32 : V_128x64_W41;
+        // latency-bound sizes (a few hundred 128-row tiles at most: the Q-network's layers at learner / actor batches): register-direct
+        // skinny tiles (convskinny.hip.h)
+        if (conv_skinny_ok(l, npix, src, "fwd")) {
+            char label[40];
+            if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
+            ProfScope ps(label, 2.0 * npix * (double)l.K * l.NF, 0.0, st);
+            ConvGeom cg;
+            fill_conv(cg, l, src, npix, first ? in.srow : nullptr);
+            return (int)(f32in ? launch_conv_skinny_fwd<2>(cg, W, bias, hout, l.NF, l.act, st)
+                         : first ? launch_conv_skinny_fwd<1>(cg, W, bias, hout, l.NF, l.act, st)
+                                 : launch_conv_skinny_fwd<0>(cg, W, bias, hout, l.NF, l.act, st));
+        }
         EpiBiasAct ef{hout, l.NF, bias, l.act};
         if (f32in) {
             ConvPatchKC<2> af;

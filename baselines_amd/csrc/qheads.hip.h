@@ -50,29 +50,41 @@ __global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeads hd, const float
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // chunks in groups of U, the next group's loads issued before the current group's MFMAs (two register sets, ping-pong)
     constexpr int U = 4;
-    for (int c = cb; c < ce; c += U) {
-        float4 fa[U][MT];
-        float fb[U][4];
+    float4 fa[2][U][MT];
+    float fb[2][U][4];
+    auto load = [&](int set, int c) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool live = c + u < ce;
             const long k = 8L * (c + u) + 4 * hf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[u][j] = live ? W[(k + j) * N] : 0.f;
+            for (int j = 0; j < 4; ++j) fb[set][u][j] = live ? W[(k + j) * N] : 0.f;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-                fa[u][t] = (live && alive[t]) ? *reinterpret_cast<const float4*>(ar[t] + 8L * (c + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                fa[set][u][t] = (live && alive[t]) ? *reinterpret_cast<const float4*>(ar[t] + 8L * (c + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto mma = [&](int set) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][t].x, fb[u][0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][t].y, fb[u][1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][t].z, fb[u][2], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][t].w, fb[u][3], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u][t].x, fb[set][u][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u][t].y, fb[set][u][1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u][t].z, fb[set][u][2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u][t].w, fb[set][u][3], acc[t], 0, 0, 0);
             }
+    };
+    if (cb < ce) load(0, cb);
+    for (int c = cb; c < ce; c += 2 * U) {
+        if (c + U < ce) load(1, c + U);
+        mma(0);
+        if (c + U < ce) {
+            if (c + 2 * U < ce) load(0, c + 2 * U);
+            mma(1);
+        }
     }
     const int ncol = blockIdx.x * 32;       // column in the concatenated hidden vector
 #pragma unroll
@@ -92,14 +104,20 @@ __global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeads hd, const float
     }
 }
 
-// deterministic block sum of floats over 256 threads (wave shuffles, then the four wave sums in order); valid in every thread
-__device__ __forceinline__ float q_block_sum(float v, float* sh /* 4 floats, reusable after the call's second barrier */) {
+// deterministic block sums of eight floats at once over 256 threads (wave shuffles, then the four wave sums in order; one barrier pair);
+// valid in every thread
+__device__ __forceinline__ void q_block_sum8(float (&v)[8], float (*sh)[8] /* [4][8] */) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[threadIdx.x >> 6][j] = v[j];
     __syncthreads();
-    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ((sh[0][j] + sh[1][j]) + sh[2][j]) + sh[3][j];
 }
 
 // ---- forward: per sample, hidden activations + output layers + dueling combine ---------------------------------------------------------
@@ -108,7 +126,7 @@ constexpr int QH_MAXOUT = 32;
 __global__ __launch_bounds__(256) void q_heads_out_kernel(QHeads hd, const float* __restrict__ part, int S, int B, float* __restrict__ h0a,
                                                           float* __restrict__ h0s, float* __restrict__ oa, float* __restrict__ os,
                                                           float* __restrict__ q) {
-    __shared__ float sh[4];
+    __shared__ float sh[4][8];
     __shared__ float outs[QH_MAXOUT + 1];
     const int b = blockIdx.x;
     const int ntot = hd.N0[0] + (hd.nheads > 1 ? hd.N0[1] : 0);
@@ -120,8 +138,15 @@ __global__ __launch_bounds__(256) void q_heads_out_kernel(QHeads hd, const float
 #pragma unroll
             for (int j = 0; j < 8; ++j) p[j] = 0.f;
             for (int n = threadIdx.x; n < N; n += 256) {
+                const float* pp = part + (long)b * ntot + col0 + n;
                 float v = 0.f;
-                for (int s = 0; s < S; ++s) v += part[((long)s * B + b) * ntot + col0 + n];
+                int s = 0;
+                for (; s + 4 <= S; s += 4) {              // four partials in flight, summed in split order
+                    const float x0 = pp[(long)s * B * ntot], x1 = pp[(long)(s + 1) * B * ntot], x2 = pp[(long)(s + 2) * B * ntot],
+                                x3 = pp[(long)(s + 3) * B * ntot];
+                    v = (((v + x0) + x1) + x2) + x3;
+                }
+                for (; s < S; ++s) v += pp[(long)s * B * ntot];
                 v = fmaxf(v + hd.b0[head][n], 0.f);
                 if (j0 == 0) hout[(long)b * N + n] = v;
                 const float* w1 = hd.W1[head] + (long)n * no + j0;
@@ -129,12 +154,13 @@ __global__ __launch_bounds__(256) void q_heads_out_kernel(QHeads hd, const float
                 for (int j = 0; j < 8; ++j)
                     if (j0 + j < no) p[j] += v * w1[j];
             }
+            q_block_sum8(p, sh);
+            float mine = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j0 + j >= no) break;
-                const float t = q_block_sum(p[j], sh);
-                if (threadIdx.x == 0) outs[head ? QH_MAXOUT : j0 + j] = t + hd.b1[head][j0 + j];
-            }
+            for (int j = 0; j < 8; ++j)
+                if ((int)threadIdx.x == j) mine = p[j];
+            if (threadIdx.x < 8 && j0 + (int)threadIdx.x < no)
+                outs[head ? QH_MAXOUT : j0 + threadIdx.x] = mine + hd.b1[head][j0 + threadIdx.x];
         }
     }
     __syncthreads();
@@ -216,7 +242,18 @@ __global__ __launch_bounds__(256) void q_heads_bwd_kernel(QHeads hd, const float
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-            for (int b = 0; b < B; ++b) {
+            int b = 0;
+            for (; b + 8 <= B; b += 8) {                 // eight activations in flight, accumulated in sample order
+                float hv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = h0[(long)(b + u) * N + n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j0 + j < no) acc[j] += hv[u] * dsh[(b + u) * no + j0 + j];
+            }
+            for (; b < B; ++b) {
                 const float hv = h0[(long)b * N + n];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)

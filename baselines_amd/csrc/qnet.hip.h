@@ -279,24 +279,36 @@ __global__ __launch_bounds__(64 * NW) void q_lat_dgrad_kernel(QLatDgradArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // chunks in groups of U, the next group's loads issued before the current group's MFMAs (two register sets, ping-pong)
     constexpr int U = 4;
-    for (int c = cb; c < ce; c += U) {
-        float4 fa[U], fb[U];
+    float4 fa[2][U], fb[2][U];
+    auto load = [&](int set, int c) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int cc = c + u;
             const bool live = cc < ce;
             const int hd = cc >= c0;
             const long o = 8L * (hd ? cc - c0 : cc);
-            fa[u] = (live && brow) ? *reinterpret_cast<const float4*>(dzr[hd] + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            fb[u] = (live && krow) ? q_ld4(wr[hd] + o, a.w16[hd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            fa[set][u] = (live && brow) ? *reinterpret_cast<const float4*>(dzr[hd] + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            fb[set][u] = (live && krow) ? q_ld4(wr[hd] + o, a.w16[hd]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto mma = [&](int set) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].x, fb[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].y, fb[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].z, fb[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].w, fb[u].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].x, fb[set][u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].y, fb[set][u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].z, fb[set][u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].w, fb[set][u].w, acc, 0, 0, 0);
+        }
+    };
+    if (cb < ce) load(0, cb);
+    for (int c = cb; c < ce; c += 2 * U) {
+        if (c + U < ce) load(1, c + U);
+        mma(0);
+        if (c + U < ce) {
+            if (c + 2 * U < ce) load(0, c + 2 * U);
+            mma(1);
         }
     }
 #pragma unroll

@@ -271,9 +271,10 @@ def test_train_dev_graph_replay_is_bit_identical_to_eager_launches(name):
 
 
 @pytest.mark.parametrize('name,B', [('conv_only_dueling', 32), ('conv_only_small', 48), ('mlp_plain', 7), ('nature_cnn', 100)])
-def test_fused_heads_agree_with_the_layer_wise_path(name, B):
+def test_small_batch_kernels_agree_with_the_tile_engines(name, B):
     """The four-kernel form of the dueling heads (csrc/qheads.hip.h: fp32 matrix pipe, K split over workgroups, direct weight-gradient
-    stores) and the one-launch data gradient into the latent against the layer-by-layer tile engines (options dqn_heads / dqn_latdgrad = 0):
+    stores), the one-launch data gradient into the latent and the skinny-tile conv kernels (csrc/convskinny.hip.h) against the
+    layer-by-layer tile engines (options dqn_heads / dqn_latdgrad / conv_skinny = 0):
     the same sums in another order -- q values, TD errors and every gradient tensor within 2e-6 of the tensor's scale."""
     from baselines_amd import _lib
     qm, _, _, b = _pair(name, B, 5)
@@ -283,8 +284,8 @@ def test_fused_heads_agree_with_the_layer_wise_path(name, B):
     out = {}
     try:
         for mode in (1, 0):
-            _lib.set_option('dqn_heads', mode)
-            _lib.set_option('dqn_latdgrad', mode)
+            for o in ('dqn_heads', 'dqn_latdgrad', 'conv_skinny'):
+                _lib.set_option(o, mode)
             td = torch.empty(B, dtype=torch.float32, device='cuda')
             qm.grads.zero_()
             _lib.check(qm.lib.mrl_qnet_td_grad(qm.handle, _lib.ptr(qm.params), _lib.ptr(qm.target), _lib.ptr(o12[:B]), _lib.ptr(a), _lib.ptr(r),
@@ -293,8 +294,8 @@ def test_fused_heads_agree_with_the_layer_wise_path(name, B):
                        'mrl_qnet_td_grad')
             out[mode] = (qm.q_values(b['obs_t']).copy(), td.cpu().numpy(), qm.grads.cpu().numpy().copy(), float(qm._loss.cpu()))
     finally:
-        _lib.set_option('dqn_heads', 1)
-        _lib.set_option('dqn_latdgrad', 1)
+        for o in ('dqn_heads', 'dqn_latdgrad', 'conv_skinny'):
+            _lib.set_option(o, 1)
     (q1, td1, g1, l1), (q0, td0, g0, l0) = out[1], out[0]
     assert np.abs(q1 - q0).max() <= 2e-6 * max(1.0, np.abs(q0).max())
     assert np.abs(td1 - td0).max() <= 4e-6 * max(1.0, np.abs(td0).max())
