@@ -107,4 +107,107 @@ static hipError_t launch_conv_skinny_fwd(const ConvGeom& g, const float* w, cons
     return hipGetLastError();
 }
 
+// 16 bytes from an address that is only known to be 8-byte aligned (weights inside the flat parameter vector)
+__device__ __forceinline__ float4 sk_ld4(const float* p, bool a16) {
+    if (a16) return *reinterpret_cast<const float4*>(p);
+    const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// ---- data gradient (gather form, stride-parity classes as DgradGeom): rows = input pixels of class z, k = (tap, filter) -----------------------
+// dX[b, iy, ix, c] = act'(h) * sum_{tap (a, b2), n} dz[b, yy - a, xx - b2, n] W[py + s a, px + s b2, c, n];  NF % 8 == 0: a chunk of 8 k
+// stays inside one tap, so both operands arrive as 16-byte loads along n.  grid (row tiles of 32, channel tiles of 32 TN, classes)
+template <int TN, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_skinny_dgrad_kernel(DgradGeom g, const float* __restrict__ dz, const float* __restrict__ w,
+                                                                    EpiDgradConv ef, int w16) {
+    __shared__ float red[NW][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32 * TN, z = blockIdx.z;
+    const int py = z / g.stride, px = z - py * g.stride;
+    const int perimg = g.HY * g.WX, Mz = g.B * perimg;
+    const int kc = (g.taps * g.taps * g.NF) >> 3, per = (kc + NW - 1) / NW, cb = wave * per, ce = min(kc, cb + per);
+    const int m = min(m0 + r, Mz - 1);
+    const bool rowlive = m0 + r < Mz;
+    const int b = (int)g.d_per.div((uint32_t)m), rr = m - b * perimg;
+    const int yy = (int)g.d_wx.div((uint32_t)rr), xx = rr - yy * g.WX;
+    const long pb = (long)b * g.OH * g.OW;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    constexpr int U = 4;
+    float4 fa[2][U], fb[2][U][TN];
+    auto load = [&](int set, int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = c + u < ce;
+            const int k = 8 * (c + u) + 4 * hf;
+            const int tap = (int)g.d_nf.div((uint32_t)k), n = k - tap * g.NF;
+            const int a = (int)g.d_taps.div((uint32_t)tap), b2 = tap - a * g.taps;
+            const int oy = yy - a, ox = xx - b2;
+            const bool oka = live && rowlive && (unsigned)oy < (unsigned)g.OH && (unsigned)ox < (unsigned)g.OW;
+            fa[set][u] = oka ? *reinterpret_cast<const float4*>(dz + (pb + oy * g.OW + ox) * g.NF + n) : f4zero();
+            const int ky = py + g.stride * a, kx = px + g.stride * b2;
+            const bool okb = live && ky < g.rf && kx < g.rf;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int cc = c0 + 32 * t + r;
+                fb[set][u][t] = (okb && cc < g.C) ? sk_ld4(w + ((long)(ky * g.rf + kx) * g.C + cc) * g.NF + n, w16) : f4zero();
+            }
+        }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].x, fb[set][u][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].y, fb[set][u][t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].z, fb[set][u][t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].w, fb[set][u][t].w, acc[t], 0, 0, 0);
+            }
+    };
+    if (cb < ce) load(0, cb);
+    for (int c = cb; c < ce; c += 2 * U) {
+        if (c + U < ce) load(1, c + U);
+        mma(0);
+        if (c + U < ce) {
+            if (c + 2 * U < ce) load(0, c + 2 * U);
+            mma(1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        if (t) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][(i >> 2) * 8 + hf * 4 + (i & 3)][r] = acc[t][i];      // row = input pixel, column = channel
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 1024; idx += 64 * NW) {
+            const int p = idx >> 5, cc = c0 + 32 * t + (idx & 31);
+            if (m0 + p >= Mz || cc >= g.C) continue;
+            const long o = ef.addr(m0 + p, cc, z);
+            if (o < 0) continue;
+            float v = red[0][p][idx & 31];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v += red[q][p][idx & 31];
+            ef.put(o, v, ef.aux(o, cc));
+        }
+    }
+}
+
+static hipError_t launch_conv_skinny_dgrad(const DgradGeom& g, const float* dz, const float* w, const EpiDgradConv& ef, hipStream_t st) {
+    const int Mz = g.B * g.HY * g.WX, mt = (Mz + 31) / 32, zc = g.stride * g.stride;
+    const int w16 = (uintptr_t)w % 16 == 0;
+    const bool deep = g.taps * g.taps * g.NF > 256;
+    if (g.C % 64 == 0) {
+        if (deep) hipLaunchKernelGGL((conv_skinny_dgrad_kernel<2, 8>), dim3(mt, g.C / 64, zc), dim3(512), 0, st, g, dz, w, ef, w16);
+        else hipLaunchKernelGGL((conv_skinny_dgrad_kernel<2, 4>), dim3(mt, g.C / 64, zc), dim3(256), 0, st, g, dz, w, ef, w16);
+    } else {
+        if (deep) hipLaunchKernelGGL((conv_skinny_dgrad_kernel<1, 8>), dim3(mt, (g.C + 31) / 32, zc), dim3(512), 0, st, g, dz, w, ef, w16);
+        else hipLaunchKernelGGL((conv_skinny_dgrad_kernel<1, 4>), dim3(mt, (g.C + 31) / 32, zc), dim3(256), 0, st, g, dz, w, ef, w16);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace mrl

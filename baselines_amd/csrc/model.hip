@@ -491,7 +491,9 @@ static Split pick_split(int variant, int Mp, int Np, long Kp) {
     const int bm = kVariantBM[variant % V_COUNT], bn = kVariantBN[variant % V_COUNT];
     long tiles = (long)((Mp + bm - 1) / bm) * ((Np + bn - 1) / bn);
     long ns = std::max<long>(1, WGRAD_TARGET_WGS / std::max<long>(1, tiles));
-    long maxns = std::max<long>(1, Kp / 256);
+    // at least 256 reduction rows per split -- 64 where the whole problem is a few hundred workgroups (latency-bound: more, shorter
+    // workgroups per CU cover each other's load round trips; the Q-network's conv weight gradients at batch 32: 44 -> 17 us)
+    long maxns = std::max<long>(1, Kp / ((Kp <= 32768 && get_option("conv_skinny", "MRL_CONV_SKINNY", 1)) ? 64 : 256));
     ns = std::min(ns, maxns);
     long ks = (Kp + ns - 1) / ns;
     ks = (ks + 31) / 32 * 32;
@@ -2373,6 +2375,15 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                     WresEpiDgrad we; static_cast<DgradGeom&>(we) = g; we.out = nw.dz[i - 1]; we.hprev = hprev;
                     we.act = lp.act; we.tiles_per_class = tpc;
                     rc = wres_dispatch(l.name, "dgrad", dv, l.C, wa, wb, we, zc, Kd, tpc * zc, fl, st);
+                } else if (get_option("conv_skinny", "MRL_CONV_SKINNY", 1) && !overridden && l.NF % 8 == 0 && l.C % 32 == 0 &&
+                           (uintptr_t)dz % 16 == 0 && (uintptr_t)(params + l.w_off) % 8 == 0 &&
+                           ((long)Md + 127) / 128 * (l.stride * l.stride) <= 2L * num_cus()) {
+                    // latency-bound sizes: register-direct skinny tiles (convskinny.hip.h)
+                    char label[40];
+                    if (prof_enabled()) snprintf(label, sizeof label, "%s.dgrad", l.name);
+                    ProfScope ps(label, fl, 0.0, st);
+                    EpiDgradConv ef; static_cast<DgradGeom&>(ef) = g; ef.out = nw.dz[i - 1]; ef.h = hmask; ef.act = lp.act;
+                    rc = (int)launch_conv_skinny_dgrad(g, dz, params + l.w_off, ef, st);
                 } else {
                     if (dv >= V_WRES16) dv = l.C <= 32 ? V_128x32 : V_128x64_W41;
                     DgradA af; static_cast<DgradGeom&>(af) = g; af.dz = dz;
