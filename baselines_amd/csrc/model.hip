@@ -611,7 +611,11 @@ struct StepCtx {
     long early_lo = 0;
     // latency-bound batches (the DQN learner step): the weight gradients -- off the dz chain -- go to this stream, forked per layer
     // with ev_fork once dz[i] is there; ws.part then belongs to that stream and the CALLER joins it before the gradient is read
-    hipStream_t wstream = nullptr;
+    // (round-robin over up to three streams, each with its own split-K scratch wpart[j] of ws.part_floats floats, so that the weight
+    // gradients of consecutive layers overlap too)
+    hipStream_t wstream[3] = {nullptr, nullptr, nullptr};
+    float* wpart[3] = {nullptr, nullptr, nullptr};
+    int nwstream = 0, wrr = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
@@ -2118,9 +2122,11 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
     for (auto& v : nw.dzpvalid) v = 0;
     for (int i = (int)net.L.size() - 1; i >= 0; --i) {
         const Layer& l = net.L[i];
-        if (l.ln && ctx.wstream) {     // the layer-norm reduction below uses ws.part on `st`: wait for the weight gradients in flight
-            MRL_HIP_CHECK(hipEventRecord(ctx.ev_join, ctx.wstream));
-            MRL_HIP_CHECK(hipStreamWaitEvent(st, ctx.ev_join, 0));
+        if (l.ln && ctx.nwstream) {     // the layer-norm reduction below uses ws.part on `st`: wait for the weight gradients in flight
+            for (int j = 0; j < ctx.nwstream; ++j) {
+                MRL_HIP_CHECK(hipEventRecord(ctx.ev_join, ctx.wstream[j]));
+                MRL_HIP_CHECK(hipStreamWaitEvent(st, ctx.ev_join, 0));
+            }
         }
         if (l.ln) {
             // nw.dz[i] arrives as the gradient w.r.t. the activation's input = the layer-norm output; turn it into the gradient
@@ -2160,10 +2166,13 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         // ---- weight + bias gradient: dW[k][n] = sum_rows A[row][k] * dz[row][n], db[n] = sum_rows dz[row][n]
         //      (split-K over rows; the bias column sums ride on the B operand's LDS image)
         hipStream_t stw = st;
-        if (ctx.wstream) {
+        float* wpart = ws.part;
+        if (ctx.nwstream) {
+            const int j = ctx.wrr++ % ctx.nwstream;
             MRL_HIP_CHECK(hipEventRecord(ctx.ev_fork, st));
-            MRL_HIP_CHECK(hipStreamWaitEvent(ctx.wstream, ctx.ev_fork, 0));
-            stw = ctx.wstream;
+            MRL_HIP_CHECK(hipStreamWaitEvent(ctx.wstream[j], ctx.ev_fork, 0));
+            stw = ctx.wstream[j];
+            if (ctx.wpart[j]) wpart = ctx.wpart[j];
         }
         int var = pick_variant(l.name, "wgrad", l.K, l.N);
         const long slab = (long)l.K * l.N + l.N;
@@ -2189,10 +2198,10 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
                 ProfScope ps(label, 2.0 * rows * (double)l.K * l.N, 0.0, stw);
-                hipError_t e = launch_wgrad_tr_dense(hprev, l.K, dz, ws.part, slab, (int)rows, l.K, l.N, wd, stw);
+                hipError_t e = launch_wgrad_tr_dense(hprev, l.K, dz, wpart, slab, (int)rows, l.K, l.N, wd, stw);
                 if (e != hipSuccess) return (int)e;
             }
-            rc = reduce_slabs(ws.part, slab, wd.nslab, grads + l.w_off, slab, accumulate, stw, &ctx);
+            rc = reduce_slabs(wpart, slab, wd.nslab, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (trw) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
@@ -2205,8 +2214,8 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 const int wtv = get_option("wgrad_tr", "MRL_WGRAD_TR", 1);
                 hipError_t e;
 #define MRL_WT(XP2, DP2, XP3, DP3, DBG)                                                                                   \
-    (ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, XP2, DP2, DBG>(hprev, dz, B, ws.part, nblocks, stw)       \
-             : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, XP3, DP3, DBG>(hprev, dz, B, ws.part, nblocks, stw))
+    (ik == 2 ? launch_wgrad_tr<20, 20, 32, 4, 2, 64, 8, 2, 2, XP2, DP2, DBG>(hprev, dz, B, wpart, nblocks, stw)       \
+             : launch_wgrad_tr<9, 9, 64, 3, 1, 64, 12, 3, 1, XP3, DP3, DBG>(hprev, dz, B, wpart, nblocks, stw))
                 switch (wtv) {
 #ifdef MRL_X6_EXPERIMENTS       // 2-4: timing experiments (unpadded pixel strides; staging / MFMA phase left out)
                 case 2: e = MRL_WT(0, 0, 0, 0, 0); break;
@@ -2218,7 +2227,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
 #undef MRL_WT
                 if (e != hipSuccess) return (int)e;
             }
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
+            rc = reduce_slabs(wpart, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (wx.cfg) {
             char label[40];
@@ -2229,13 +2238,13 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 if (l.kind == 0) {
                     X6ConvA ca;
                     fill_conv(ca, l, hprev, (int)rows, nullptr);
-                    e = launch_wgrad_x8(ca, dz, ws.part, slab, (int)rows, l.K, l.N, wx, stw);
+                    e = launch_wgrad_x8(ca, dz, wpart, slab, (int)rows, l.K, l.N, wx, stw);
                 } else {
-                    e = launch_wgrad_x8(X6DenseA{hprev, (long)l.K}, dz, ws.part, slab, (int)rows, l.K, l.N, wx, stw);
+                    e = launch_wgrad_x8(X6DenseA{hprev, (long)l.K}, dz, wpart, slab, (int)rows, l.K, l.N, wx, stw);
                 }
             }
             if (e != hipSuccess) return (int)e;
-            rc = reduce_slabs(ws.part, slab, wx.nslab, grads + l.w_off, slab, accumulate, stw, &ctx);
+            rc = reduce_slabs(wpart, slab, wx.nslab, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (ik == 1 && first && !tuned(l, "wgrad") && get_option("u8_bf16x3", "MRL_U8_BF16X3", 1) &&
                    get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 2) {
@@ -2246,19 +2255,19 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
                 char label[40];
                 if (prof_enabled()) snprintf(label, sizeof label, "%s.wgrad", l.name);
                 ProfScope ps(label, 2.0 * B * l.OH * l.OW * (double)l.K * l.NF, 0.0, stw);
-                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, ws.part, nblocks, stw, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3,
+                hipError_t e = launch_c1wgrad_half(asrc, in.srow, dz, B, wpart, nblocks, stw, get_option("c1_wgrad2", "MRL_C1_WGRAD2", 3) >= 3,
                                                    std::max(0, dbg_option("c1_dbg", "MRL_C1_DBG") - 64));
                 if (e != hipSuccess) return (int)e;
             }
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
+            rc = reduce_slabs(wpart, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else if (ik && (var == V_IMGRES || tune_table().find(std::string(l.name) + ".wgrad") == tune_table().end())) {
             int nblocks = (int)std::min<long>(std::min<long>(num_cus(), IMGRES_MAX_BLOCKS), B);
             nblocks = (int)std::min<long>(nblocks, (long)(ws.part_floats / slab));
             if (nblocks < 1) return MRL_ENOSPC;
-            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, nullptr, B, ws.part, nblocks, stw);
+            rc = imgres_dispatch(ik, l, asrc, first ? in.srow : nullptr, dz, nullptr, B, wpart, nblocks, stw);
             if (rc) return rc;
-            rc = reduce_slabs(ws.part, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
+            rc = reduce_slabs(wpart, slab, nblocks, grads + l.w_off, slab, accumulate, stw, &ctx);
             if (rc) return rc;
         } else {
         if (var >= V_WRES16) var = l.N <= 32 ? V_128x32 : (l.N <= 64 ? V_128x64_W41 : V_128x128);
@@ -2266,7 +2275,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
         //      (split-K over rows; the bias column sums ride on the B operand's LDS image)
         const Split sp = pick_split(var, l.K, l.N, rows);
         if ((size_t)sp.nsplit * slab > ws.part_floats) return MRL_ENOSPC;
-        EpiPartial ep{ws.part, slab, l.N, (long)l.K * l.N};
+        EpiPartial ep{wpart, slab, l.N, (long)l.K * l.N};
         RowMC bfm{dz, l.N, l.N, (int)rows, is_vec(dz, l.N), nullptr};
         if (l.kind == 0) {
             if (first && m->d.ob_dtype != MRL_OB_U8) {
@@ -2292,7 +2301,7 @@ static int net_backward(const mrl_model* m, const Net& net, const In& in, const 
             }
         }
         if (rc) return rc;
-        rc = reduce_slabs(ws.part, slab, sp.nsplit, grads + l.w_off, slab, accumulate, stw, &ctx);
+        rc = reduce_slabs(wpart, slab, sp.nsplit, grads + l.w_off, slab, accumulate, stw, &ctx);
         if (rc) return rc;
         }
         // data parallel: the tail of the flat gradient [this layer .. heads] is final -> it travels (RCCL, communication

@@ -25,13 +25,15 @@ struct mrl_qnet {
     std::vector<int> init_kind;     // per tensor: 0 zeros, 1 orthogonal (scale in base.tensors), 2 xavier uniform
     // learner step (round 6): the target network's forward pass runs on a side stream next to the online network's (every kernel of a
     // batch-32 step is latency-bound on a handful of workgroups); created on the first eager mrl_qnet_td_grad call
-    mutable hipStream_t side = nullptr;
+    mutable hipStream_t side = nullptr, side2 = nullptr, side3 = nullptr;     // side2 / side3: weight gradients of consecutive layers
     mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     mutable bool side_failed = false;
     ~mrl_qnet() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
+        if (side2) (void)hipStreamDestroy(side2);
+        if (side3) (void)hipStreamDestroy(side3);
     }
 };
 
@@ -138,6 +140,7 @@ struct QWs {
     NetWs feat, av, sv;
     float *q_t, *q_tp1, *q_tp1_on, *dq, *dlat_tmp;
     float* part; size_t part_floats;
+    float *part2, *part3;    // split-K scratch of the weight gradients on the second / third side stream
     void* td_scratch;
     double* sqpart;          // per-tensor sum-of-squares partials
     float* zeros;
@@ -171,6 +174,8 @@ static void q_carve(const mrl_qnet* q, int B, char* base, QWs& ws) {
     ws.q_t = (float*)take(qa); ws.q_tp1 = (float*)take(qa); ws.q_tp1_on = (float*)take(qa); ws.dq = (float*)take(qa);
     ws.dlat_tmp = (float*)take((size_t)B * q->nlat * 4);
     ws.part = (float*)take(part_floats * 4);
+    ws.part2 = (float*)take(part_floats * 4);
+    ws.part3 = (float*)take(part_floats * 4);
     ws.part_floats = part_floats;
     ws.td_scratch = take(mrl_dqn_td_scratch_bytes(B));
     ws.sqpart = (double*)take(q_sq_parts(q) * 8);
@@ -484,10 +489,11 @@ static int q_heads_backward_fused(const mrl_qnet* q, const float* lat, const flo
         MRL_LAUNCH_CHECK();
     }
     hipStream_t stw = st;
-    if (ctx.wstream) {
+    if (ctx.nwstream) {
+        const int j = ctx.wrr++ % ctx.nwstream;
         MRL_HIP_CHECK(hipEventRecord(ctx.ev_fork, st));
-        MRL_HIP_CHECK(hipStreamWaitEvent(ctx.wstream, ctx.ev_fork, 0));
-        stw = ctx.wstream;
+        MRL_HIP_CHECK(hipStreamWaitEvent(ctx.wstream[j], ctx.ev_fork, 0));
+        stw = ctx.wstream[j];
     }
     {
         ProfScope ps("heads0.wgrad", 2.0 * B * (double)hd.K * ntot, 0.0, stw);
@@ -665,6 +671,8 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) par = false;      // not while capturing
         else {
             hipError_t e = hipStreamCreateWithFlags(&q->side, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->side2, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->side3, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_fork, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_join, hipEventDisableTiming);
             if (e != hipSuccess) { q->side_failed = true; par = false; (void)hipGetLastError(); }
@@ -706,7 +714,12 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
     // the weight gradients hang off the dz chain: with the side stream free again (the target pass was joined above) they run there,
     // next to the data gradients (StepCtx::wstream); joined below, before the caller's stream reads the gradient
     StepCtx ctx;
-    if (par && get_option("dqn_wstream", "MRL_DQN_WSTREAM", 1)) { ctx.wstream = q->side; ctx.ev_fork = q->ev_fork; ctx.ev_join = q->ev_join; }
+    if (par && get_option("dqn_wstream", "MRL_DQN_WSTREAM", 1)) {
+        ctx.nwstream = std::min(3, get_option("dqn_wstream", "MRL_DQN_WSTREAM", 1) == 1 ? 3 : get_option("dqn_wstream", "MRL_DQN_WSTREAM", 1) - 1);
+        ctx.wstream[0] = q->side; ctx.wstream[1] = q->side2; ctx.wstream[2] = q->side3;
+        ctx.wpart[0] = ws.part; ctx.wpart[1] = ws.part2; ctx.wpart[2] = ws.part3;
+        ctx.ev_fork = q->ev_fork; ctx.ev_join = q->ev_join;
+    }
     const bool one_dgrad = q_lat_dgrad_ok(q, params, ws, B);
     if (fused) {
         if ((rc = q_heads_backward_fused(q, lat, params, ws, grads_out, dlat, B, st, ctx))) return rc;
@@ -719,8 +732,8 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
     mws.part = ws.part; mws.part_floats = ws.part_floats; mws.zeros = ws.zeros;
     In in{obs_t, nullptr};
     rc = net_backward<kExp>(&q->base, q->base.pi, in, params, ws.feat, mws, grads_out, B, 0, st, ctx, false);
-    if (ctx.wstream) {
-        MRL_HIP_CHECK(hipEventRecord(q->ev_join, q->side));
+    for (int j = 0; j < ctx.nwstream; ++j) {
+        MRL_HIP_CHECK(hipEventRecord(q->ev_join, ctx.wstream[j]));
         MRL_HIP_CHECK(hipStreamWaitEvent(st, q->ev_join, 0));
     }
     return rc;
