@@ -14,14 +14,36 @@
 
 namespace mrl {
 
+// Predicated loads WITHOUT control flow: the address falls back to a location that is always readable and the value is selected
+// afterwards.  `ok ? *p : 0` compiles to a branch around the load, and behind a branch the compiler no longer knows how many loads are in
+// flight: every wait becomes s_waitcnt vmcnt(0) and the ping-pong prefetch below is serialised (measured: 173 branches, only vmcnt(0)).
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
+__device__ __forceinline__ float4 ldz4(const float* p, const float* safe, bool ok) { return sel4(ok, *reinterpret_cast<const float4*>(ok ? p : safe)); }
+__device__ __forceinline__ float ldz1(const float* p, const float* safe, bool ok) { const float v = *(ok ? p : safe); return ok ? v : 0.f; }
+// 16 bytes from an address that is 16-byte (A16) or only 8-byte aligned (weights inside the flat parameter vector)
+template <bool A16> __device__ __forceinline__ float4 ldz4w(const float* p, const float* safe, bool ok) {
+    const float* q = ok ? p : safe;
+    if (A16) return sel4(ok, *reinterpret_cast<const float4*>(q));
+    const float2 lo = *reinterpret_cast<const float2*>(q), hi = *reinterpret_cast<const float2*>(q + 2);
+    return sel4(ok, make_float4(lo.x, lo.y, hi.x, hi.y));
+}
+
 // ---- forward: out[pixel][n] = act(bias[n] + sum_k patch(pixel)[k] W[k][n]) -----------------------------------------------------------------
 // SRC as conv_ld (0: fp32 activations, 1: uint8 pixels / 255, 2: fp32 pixels / 255); SAME / VALID padding through ConvGeom
+// Two independent problems of the same layer shape in one launch (the DQN step's online pass of 2 B rows and target pass of B rows: other
+// weights, other input, no reason to run one after the other): blocks [0, mt0) belong to p0, the rest to p1.
+struct ConvSkinnyProb { ConvGeom g; const float* w; const float* bias; float* out; };
 template <int SRC, int TN, int NW>
-__global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvGeom g, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                  float* __restrict__ out, int NF, int act) {
+__global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvSkinnyProb p0, ConvSkinnyProb p1, int mt0, int NF, int act) {
     __shared__ float red[NW][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32 * TN;
+    const bool second = (int)blockIdx.x >= mt0;
+    const ConvSkinnyProb& P = second ? p1 : p0;
+    const ConvGeom& g = P.g;
+    const float* __restrict__ w = P.w;
+    const float* __restrict__ bias = P.bias;
+    float* __restrict__ out = P.out;
+    const int m0 = ((int)blockIdx.x - (second ? mt0 : 0)) * 32, n0 = blockIdx.y * 32 * TN;
     const int kc = g.kconv >> 3, per = (kc + NW - 1) / NW, cb = wave * per, ce = min(kc, cb + per);
     // this lane's pixel
     const int m = min(m0 + r, g.npix - 1);
@@ -39,7 +61,7 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvGeom g, co
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     // chunks in groups of U, the next group's loads issued before the current group's MFMAs (two register sets, ping-pong)
-    constexpr int U = 4;
+    constexpr int U = TN == 2 ? 2 : 4;
     float4 fa[2][U];
     float fb[2][U][TN][4];
     auto load = [&](int set, int c) {
@@ -50,11 +72,11 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvGeom g, co
             const int ky = (int)g.d_rowk.div((uint32_t)k), kr = k - ky * g.rowk;
             const int kx = (int)g.d_c.div((uint32_t)kr);
             const bool ok = live && rowlive && (unsigned)(iy0 + ky) < (unsigned)g.H && (unsigned)(ix0 + kx) < (unsigned)g.W;
-            fa[set][u] = ok ? conv_ld<SRC>(g.p, base + (long)ky * g.W * g.C + kr) : f4zero();
+            fa[set][u] = sel4(ok, conv_ld<SRC>(g.p, ok ? base + (long)ky * g.W * g.C + kr : 0L));
 #pragma unroll
             for (int t = 0; t < TN; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[set][u][t][j] = (live && n0 + 32 * t + r < NF) ? wp[(long)(k + j) * NF + 32 * t] : 0.f;
+                for (int j = 0; j < 4; ++j) fb[set][u][t][j] = ldz1(wp + (long)(k + j) * NF + 32 * t, w, live && n0 + 32 * t + r < NF);
         }
     };
     auto mma = [&](int set) {
@@ -68,14 +90,12 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvGeom g, co
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].w, fb[set][u][t][3], acc[t], 0, 0, 0);
             }
     };
-    if (cb < ce) load(0, cb);
+    load(0, cb);                                   // (every load is predicated on its own chunk: loads past `ce` fetch nothing new)
     for (int c = cb; c < ce; c += 2 * U) {
-        if (c + U < ce) load(1, c + U);
+        load(1, c + U);
         mma(0);
-        if (c + U < ce) {
-            if (c + 2 * U < ce) load(0, c + 2 * U);
-            mma(1);
-        }
+        load(0, c + 2 * U);
+        if (c + U < ce) mma(1);                    // wave-uniform; no load inside a branch -> exact wait counts
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -95,31 +115,27 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_fwd_kernel(ConvGeom g, co
 }
 
 template <int SRC>
-static hipError_t launch_conv_skinny_fwd(const ConvGeom& g, const float* w, const float* bias, float* out, int NF, int act, hipStream_t st) {
-    const int mt = (g.npix + 31) / 32;
+static hipError_t launch_conv_skinny_fwd(const ConvGeom& g, const float* w, const float* bias, float* out, int NF, int act, hipStream_t st,
+                                         const ConvSkinnyProb* second = nullptr) {
+    const ConvSkinnyProb p0{g, w, bias, out};
+    const ConvSkinnyProb& p1 = second ? *second : p0;
+    const int mt0 = (g.npix + 31) / 32, mt = mt0 + (second ? (second->g.npix + 31) / 32 : 0);
     if (NF % 64 == 0) {
-        if (g.kconv > 256) hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 2, 8>), dim3(mt, NF / 64), dim3(512), 0, st, g, w, bias, out, NF, act);
-        else hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 2, 4>), dim3(mt, NF / 64), dim3(256), 0, st, g, w, bias, out, NF, act);
+        if (g.kconv > 256) hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 2, 8>), dim3(mt, NF / 64), dim3(512), 0, st, p0, p1, mt0, NF, act);
+        else hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 2, 4>), dim3(mt, NF / 64), dim3(256), 0, st, p0, p1, mt0, NF, act);
     } else {
-        if (g.kconv > 256) hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 1, 8>), dim3(mt, (NF + 31) / 32), dim3(512), 0, st, g, w, bias, out, NF, act);
-        else hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 1, 4>), dim3(mt, (NF + 31) / 32), dim3(256), 0, st, g, w, bias, out, NF, act);
+        if (g.kconv > 256) hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 1, 8>), dim3(mt, (NF + 31) / 32), dim3(512), 0, st, p0, p1, mt0, NF, act);
+        else hipLaunchKernelGGL((conv_skinny_fwd_kernel<SRC, 1, 4>), dim3(mt, (NF + 31) / 32), dim3(256), 0, st, p0, p1, mt0, NF, act);
     }
     return hipGetLastError();
-}
-
-// 16 bytes from an address that is only known to be 8-byte aligned (weights inside the flat parameter vector)
-__device__ __forceinline__ float4 sk_ld4(const float* p, bool a16) {
-    if (a16) return *reinterpret_cast<const float4*>(p);
-    const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
-    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // ---- data gradient (gather form, stride-parity classes as DgradGeom): rows = input pixels of class z, k = (tap, filter) -----------------------
 // dX[b, iy, ix, c] = act'(h) * sum_{tap (a, b2), n} dz[b, yy - a, xx - b2, n] W[py + s a, px + s b2, c, n];  NF % 8 == 0: a chunk of 8 k
 // stays inside one tap, so both operands arrive as 16-byte loads along n.  grid (row tiles of 32, channel tiles of 32 TN, classes)
-template <int TN, int NW>
+template <int TN, int NW, bool W16>
 __global__ __launch_bounds__(64 * NW) void conv_skinny_dgrad_kernel(DgradGeom g, const float* __restrict__ dz, const float* __restrict__ w,
-                                                                    EpiDgradConv ef, int w16) {
+                                                                    EpiDgradConv ef) {
     __shared__ float red[NW][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
     const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32 * TN, z = blockIdx.z;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_dgrad_kernel(DgradGeom g,
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    constexpr int U = 4;
+    constexpr int U = TN == 2 ? 2 : 4;
     float4 fa[2][U], fb[2][U][TN];
     auto load = [&](int set, int c) {
 #pragma unroll
@@ -147,13 +163,13 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_dgrad_kernel(DgradGeom g,
             const int a = (int)g.d_taps.div((uint32_t)tap), b2 = tap - a * g.taps;
             const int oy = yy - a, ox = xx - b2;
             const bool oka = live && rowlive && (unsigned)oy < (unsigned)g.OH && (unsigned)ox < (unsigned)g.OW;
-            fa[set][u] = oka ? *reinterpret_cast<const float4*>(dz + (pb + oy * g.OW + ox) * g.NF + n) : f4zero();
+            fa[set][u] = ldz4(dz + (pb + oy * g.OW + ox) * g.NF + n, dz, oka);
             const int ky = py + g.stride * a, kx = px + g.stride * b2;
             const bool okb = live && ky < g.rf && kx < g.rf;
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 const int cc = c0 + 32 * t + r;
-                fb[set][u][t] = (okb && cc < g.C) ? sk_ld4(w + ((long)(ky * g.rf + kx) * g.C + cc) * g.NF + n, w16) : f4zero();
+                fb[set][u][t] = ldz4w<W16>(w + ((long)(ky * g.rf + kx) * g.C + cc) * g.NF + n, w, okb && cc < g.C);
             }
         }
     };
@@ -168,14 +184,12 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_dgrad_kernel(DgradGeom g,
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].w, fb[set][u][t].w, acc[t], 0, 0, 0);
             }
     };
-    if (cb < ce) load(0, cb);
+    load(0, cb);                                   // (every load is predicated on its own chunk: loads past `ce` fetch nothing new)
     for (int c = cb; c < ce; c += 2 * U) {
-        if (c + U < ce) load(1, c + U);
+        load(1, c + U);
         mma(0);
-        if (c + U < ce) {
-            if (c + 2 * U < ce) load(0, c + 2 * U);
-            mma(1);
-        }
+        load(0, c + 2 * U);
+        if (c + U < ce) mma(1);                    // wave-uniform; no load inside a branch -> exact wait counts
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -196,18 +210,21 @@ __global__ __launch_bounds__(64 * NW) void conv_skinny_dgrad_kernel(DgradGeom g,
     }
 }
 
-static hipError_t launch_conv_skinny_dgrad(const DgradGeom& g, const float* dz, const float* w, const EpiDgradConv& ef, hipStream_t st) {
+template <bool W16>
+static hipError_t launch_conv_skinny_dgrad_a(const DgradGeom& g, const float* dz, const float* w, const EpiDgradConv& ef, hipStream_t st) {
     const int Mz = g.B * g.HY * g.WX, mt = (Mz + 31) / 32, zc = g.stride * g.stride;
-    const int w16 = (uintptr_t)w % 16 == 0;
     const bool deep = g.taps * g.taps * g.NF > 256;
     if (g.C % 64 == 0) {
-        if (deep) hipLaunchKernelGGL((conv_skinny_dgrad_kernel<2, 8>), dim3(mt, g.C / 64, zc), dim3(512), 0, st, g, dz, w, ef, w16);
-        else hipLaunchKernelGGL((conv_skinny_dgrad_kernel<2, 4>), dim3(mt, g.C / 64, zc), dim3(256), 0, st, g, dz, w, ef, w16);
+        if (deep) hipLaunchKernelGGL((conv_skinny_dgrad_kernel<2, 8, W16>), dim3(mt, g.C / 64, zc), dim3(512), 0, st, g, dz, w, ef);
+        else hipLaunchKernelGGL((conv_skinny_dgrad_kernel<2, 4, W16>), dim3(mt, g.C / 64, zc), dim3(256), 0, st, g, dz, w, ef);
     } else {
-        if (deep) hipLaunchKernelGGL((conv_skinny_dgrad_kernel<1, 8>), dim3(mt, (g.C + 31) / 32, zc), dim3(512), 0, st, g, dz, w, ef, w16);
-        else hipLaunchKernelGGL((conv_skinny_dgrad_kernel<1, 4>), dim3(mt, (g.C + 31) / 32, zc), dim3(256), 0, st, g, dz, w, ef, w16);
+        if (deep) hipLaunchKernelGGL((conv_skinny_dgrad_kernel<1, 8, W16>), dim3(mt, (g.C + 31) / 32, zc), dim3(512), 0, st, g, dz, w, ef);
+        else hipLaunchKernelGGL((conv_skinny_dgrad_kernel<1, 4, W16>), dim3(mt, (g.C + 31) / 32, zc), dim3(256), 0, st, g, dz, w, ef);
     }
     return hipGetLastError();
+}
+static hipError_t launch_conv_skinny_dgrad(const DgradGeom& g, const float* dz, const float* w, const EpiDgradConv& ef, hipStream_t st) {
+    return (uintptr_t)w % 16 == 0 ? launch_conv_skinny_dgrad_a<true>(g, dz, w, ef, st) : launch_conv_skinny_dgrad_a<false>(g, dz, w, ef, st);
 }
 
 }  // namespace mrl

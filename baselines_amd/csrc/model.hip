@@ -432,7 +432,7 @@ static const OptionDef kOptions[] = {
     {"wgrad_x8", "MRL_WGRAD_X8", 1}, {"c1_wgrad2", "MRL_C1_WGRAD2", 3}, {"wgrad_tr", "MRL_WGRAD_TR", 1},
     {"x6_pg", "MRL_X6_PG", 8}, {"tr_epilogue", "MRL_TR_EPILOGUE", 1}, {"mlp_waves", "MRL_MLP_WAVES", 8},
     {"mlp_slice", "MRL_MLP_SLICE", 1}, {"lstm_e1", "MRL_LSTM_E1", 1}, {"x6_dither", "MRL_X6_DITHER", 3},
-    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1}, {"dqn_latdgrad", "MRL_DQN_LATDGRAD", 1}, {"dqn_wstream", "MRL_DQN_WSTREAM", 1}, {"dqn_heads", "MRL_DQN_HEADS", 1}, {"conv_skinny", "MRL_CONV_SKINNY", 1},
+    {"x6_frag", "MRL_X6_FRAG", 1}, {"conv_x6c", "MRL_CONV_X6C", 1}, {"wgrad_pipe", "MRL_WGRAD_PIPE", 1}, {"x6_ktm", "MRL_X6_KTM", 1}, {"wgrad_xcd", "MRL_WGRAD_XCD", 1}, {"mlp_act", "MRL_MLP_ACT", 1}, {"x6_splitk", "MRL_X6_SPLITK", 1}, {"dqn_overlap", "MRL_DQN_OVERLAP", 1}, {"gae_lane", "MRL_GAE_LANE", 1}, {"conv_splitk", "MRL_CONV_SPLITK", 1}, {"dqn_latdgrad", "MRL_DQN_LATDGRAD", 1}, {"dqn_wstream", "MRL_DQN_WSTREAM", 1}, {"dqn_heads", "MRL_DQN_HEADS", 1}, {"conv_skinny", "MRL_CONV_SKINNY", 1}, {"dqn_pair", "MRL_DQN_PAIR", 1},
 #ifdef MRL_X6_EXPERIMENTS
     // ---- experiment builds only (-DMRL_X6_EXPERIMENTS): measured-and-dropped variants, phase stamps / omissions
     {"imgres_nacc", "MRL_IMGRES_NACC", 0}, {"mlp_dbg", "MRL_MLP_DBG", 0}, {"dgrad_dbg", "MRL_DGRAD_DBG", 0},

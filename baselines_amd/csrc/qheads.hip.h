@@ -24,18 +24,29 @@ struct QHeads {
 
 // ---- forward: hidden pre-activation partials ---------------------------------------------------------------------------------------
 // grid (n tiles of 32 over N0[0] + N0[1], S splits of K, row groups of 32 MT); 8 waves; part[s][b][n], n over both heads
+// Two independent problems in one launch (the DQN step's online and target passes): row groups [0, zg0) of grid.z belong to p0.
+struct QHeadsFwdProb { QHeads hd; const float* lat; int B; float* part; };
 template <int MT>
-__global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeads hd, const float* __restrict__ lat, int B, float* __restrict__ part,
-                                                          int cps /* 8-k chunks per split */) {
+__global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeadsFwdProb p0, QHeadsFwdProb p1, int zg0, int cps /* 8-k chunks per split */) {
     __shared__ float red[8][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
-    const int ntot = hd.N0[0] + (hd.nheads > 1 ? hd.N0[1] : 0);
-    int n0 = blockIdx.x * 32, head = 0;
-    if (n0 >= hd.N0[0]) { head = 1; n0 -= hd.N0[0]; }
-    const int N = hd.N0[head];
-    const float* W = hd.W0[head] + n0 + r;
-    const int m0 = blockIdx.z * 32 * MT;
-    const int kc = hd.K >> 3;
+    // (every field is selected by value: a reference into a by-value kernel argument -- or a run-time index into one of its arrays --
+    // makes the compiler spill the struct to scratch and address it with flat loads)
+    const bool second = (int)blockIdx.z >= zg0;
+    const float* __restrict__ lat = second ? p1.lat : p0.lat;
+    float* __restrict__ part = second ? p1.part : p0.part;
+    const int B = second ? p1.B : p0.B;
+    const int N0a = second ? p1.hd.N0[0] : p0.hd.N0[0], N0s = second ? p1.hd.N0[1] : p0.hd.N0[1];
+    const int nheads = second ? p1.hd.nheads : p0.hd.nheads, K = second ? p1.hd.K : p0.hd.K;
+    const int ntot = N0a + (nheads > 1 ? N0s : 0);
+    int n0 = blockIdx.x * 32;
+    const bool head = n0 >= N0a;
+    if (head) n0 -= N0a;
+    const int N = head ? N0s : N0a;
+    const float* __restrict__ Wbase = head ? (second ? p1.hd.W0[1] : p0.hd.W0[1]) : (second ? p1.hd.W0[0] : p0.hd.W0[0]);
+    const float* W = Wbase + n0 + r;
+    const int m0 = ((int)blockIdx.z - (second ? zg0 : 0)) * 32 * MT;
+    const int kc = K >> 3;
     const int sb = blockIdx.y * cps, se = min(kc, sb + cps);
     const int per = (se - sb + 7) / 8, cb = sb + wave * per, ce = min(se, cb + per);
     const float* ar[MT];
@@ -43,7 +54,7 @@ __global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeads hd, const float
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         alive[t] = m0 + 32 * t + r < B;
-        ar[t] = lat + (long)(m0 + 32 * t + r) * hd.K + 4 * hf;
+        ar[t] = lat + (long)(m0 + 32 * t + r) * K + 4 * hf;
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -60,10 +71,9 @@ __global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeads hd, const float
             const bool live = c + u < ce;
             const long k = 8L * (c + u) + 4 * hf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[set][u][j] = live ? W[(k + j) * N] : 0.f;
+            for (int j = 0; j < 4; ++j) fb[set][u][j] = mrl::ldz1(W + (k + j) * N, Wbase, live);          // branch-free (convskinny.hip.h)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                fa[set][u][t] = (live && alive[t]) ? *reinterpret_cast<const float4*>(ar[t] + 8L * (c + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < MT; ++t) fa[set][u][t] = mrl::ldz4(ar[t] + 8L * (c + u), lat, live && alive[t]);
         }
     };
     auto mma = [&](int set) {
@@ -77,14 +87,12 @@ __global__ __launch_bounds__(512) void q_heads_fwd_kernel(QHeads hd, const float
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u][t].w, fb[set][u][3], acc[t], 0, 0, 0);
             }
     };
-    if (cb < ce) load(0, cb);
+    load(0, cb);                                   // (every load is predicated on its own chunk: loads past `ce` fetch nothing new)
     for (int c = cb; c < ce; c += 2 * U) {
-        if (c + U < ce) load(1, c + U);
+        load(1, c + U);
         mma(0);
-        if (c + U < ce) {
-            if (c + 2 * U < ce) load(0, c + 2 * U);
-            mma(1);
-        }
+        load(0, c + 2 * U);
+        if (c + U < ce) mma(1);                    // wave-uniform; no load inside a branch -> exact wait counts
     }
     const int ncol = blockIdx.x * 32;       // column in the concatenated hidden vector
 #pragma unroll
@@ -123,15 +131,27 @@ __device__ __forceinline__ void q_block_sum8(float (&v)[8], float (*sh)[8] /* [4
 // ---- forward: per sample, hidden activations + output layers + dueling combine ---------------------------------------------------------
 // grid B, 256 threads; h0a / h0s: [B][N0] hidden activations (kept for the backward pass); oa / os: the heads' raw outputs
 constexpr int QH_MAXOUT = 32;
-__global__ __launch_bounds__(256) void q_heads_out_kernel(QHeads hd, const float* __restrict__ part, int S, int B, float* __restrict__ h0a,
-                                                          float* __restrict__ h0s, float* __restrict__ oa, float* __restrict__ os,
-                                                          float* __restrict__ q) {
+struct QHeadsOutProb { QHeads hd; const float* part; int S, B; float *h0a, *h0s, *oa, *os, *q; };
+__global__ __launch_bounds__(256) void q_heads_out_kernel(QHeadsOutProb p0, QHeadsOutProb p1) {
     __shared__ float sh[4][8];
     __shared__ float outs[QH_MAXOUT + 1];
-    const int b = blockIdx.x;
-    const int ntot = hd.N0[0] + (hd.nheads > 1 ? hd.N0[1] : 0);
-    for (int head = 0; head < hd.nheads; ++head) {
-        const int N = hd.N0[head], no = hd.nout[head], col0 = head ? hd.N0[0] : 0;
+    const bool second = (int)blockIdx.x >= p0.B;
+#define QSEL(f) (second ? p1.f : p0.f)
+    const float* __restrict__ part = QSEL(part);
+    const int S = QSEL(S), B = QSEL(B);
+    float* __restrict__ h0a = QSEL(h0a);
+    float* __restrict__ h0s = QSEL(h0s);
+    float* __restrict__ oa = QSEL(oa);
+    float* __restrict__ os = QSEL(os);
+    float* __restrict__ q = QSEL(q);
+    const int b = (int)blockIdx.x - (second ? p0.B : 0);
+    const int nheads = QSEL(hd.nheads), N0a = QSEL(hd.N0[0]), N0s = QSEL(hd.N0[1]);
+    const int ntot = N0a + (nheads > 1 ? N0s : 0);
+    for (int head = 0; head < nheads; ++head) {
+        const int N = head ? N0s : N0a, no = head ? QSEL(hd.nout[1]) : QSEL(hd.nout[0]), col0 = head ? N0a : 0;
+        const float* __restrict__ b0 = head ? QSEL(hd.b0[1]) : QSEL(hd.b0[0]);
+        const float* __restrict__ W1 = head ? QSEL(hd.W1[1]) : QSEL(hd.W1[0]);
+        const float* __restrict__ b1 = head ? QSEL(hd.b1[1]) : QSEL(hd.b1[0]);
         float* hout = head ? h0s : h0a;
         for (int j0 = 0; j0 < no; j0 += 8) {
             float p[8];
@@ -147,9 +167,9 @@ __global__ __launch_bounds__(256) void q_heads_out_kernel(QHeads hd, const float
                     v = (((v + x0) + x1) + x2) + x3;
                 }
                 for (; s < S; ++s) v += pp[(long)s * B * ntot];
-                v = fmaxf(v + hd.b0[head][n], 0.f);
+                v = fmaxf(v + b0[n], 0.f);
                 if (j0 == 0) hout[(long)b * N + n] = v;
-                const float* w1 = hd.W1[head] + (long)n * no + j0;
+                const float* w1 = W1 + (long)n * no + j0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (j0 + j < no) p[j] += v * w1[j];
@@ -160,16 +180,17 @@ __global__ __launch_bounds__(256) void q_heads_out_kernel(QHeads hd, const float
             for (int j = 0; j < 8; ++j)
                 if ((int)threadIdx.x == j) mine = p[j];
             if (threadIdx.x < 8 && j0 + (int)threadIdx.x < no)
-                outs[head ? QH_MAXOUT : j0 + threadIdx.x] = mine + hd.b1[head][j0 + threadIdx.x];
+                outs[head ? QH_MAXOUT : j0 + threadIdx.x] = mine + b1[j0 + threadIdx.x];
         }
     }
     __syncthreads();
-    const int nA = hd.nout[0];
+    const int nA = QSEL(hd.nout[0]);
+#undef QSEL
     if (threadIdx.x < nA) {
         const float a = outs[threadIdx.x];
         oa[(long)b * nA + threadIdx.x] = a;
         float qv = a;
-        if (hd.nheads > 1) {
+        if (nheads > 1) {
             float s = 0.f;
             for (int j = 0; j < nA; ++j) s += outs[j];
             const float mean = s / (float)nA;
@@ -296,8 +317,8 @@ __global__ __launch_bounds__(256) void q_heads_wgrad_kernel(QHeads hd, const flo
         for (int i = 0; i < 16; ++i) {
             const int b = b0 + 2 * i + hf;
             const bool live = b < B;
-            fa[i] = (live && krow) ? lp[(long)b * hd.K] : 0.f;
-            fb[i] = live ? dz[(long)b * N] : 0.f;
+            fa[i] = mrl::ldz1(lp + (long)b * hd.K, lat, live && krow);
+            fb[i] = mrl::ldz1(dz + (long)b * N, dz0a, live);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -271,7 +271,7 @@ __device__ __forceinline__ float4 q_ld4(const float* p, bool a16) {
     const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
     return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
-template <int NW>
+template <int NW, bool W16>
 __global__ __launch_bounds__(64 * NW) void q_lat_dgrad_kernel(QLatDgradArgs a) {
     __shared__ float red[NW][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hf = lane >> 5;
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(64 * NW) void q_lat_dgrad_kernel(QLatDgradArgs a) {
             const bool live = cc < ce;
             const int hd = cc >= c0;
             const long o = 8L * (hd ? cc - c0 : cc);
-            fa[set][u] = (live && brow) ? *reinterpret_cast<const float4*>(dzr[hd] + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            fb[set][u] = (live && krow) ? q_ld4(wr[hd] + o, a.w16[hd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            fa[set][u] = mrl::ldz4(dzr[hd] + o, a.dz[0], live && brow);              // branch-free (convskinny.hip.h)
+            fb[set][u] = mrl::ldz4w<W16>(wr[hd] + o, a.W[0], live && krow);
         }
     };
     auto mma = [&](int set) {
@@ -307,14 +307,12 @@ __global__ __launch_bounds__(64 * NW) void q_lat_dgrad_kernel(QLatDgradArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u].w, fb[set][u].w, acc, 0, 0, 0);
         }
     };
-    if (cb < ce) load(0, cb);
+    load(0, cb);                                   // (every load is predicated on its own chunk: loads past `ce` fetch nothing new)
     for (int c = cb; c < ce; c += 2 * U) {
-        if (c + U < ce) load(1, c + U);
+        load(1, c + U);
         mma(0);
-        if (c + U < ce) {
-            if (c + 2 * U < ce) load(0, c + 2 * U);
-            mma(1);
-        }
+        load(0, c + 2 * U);
+        if (c + U < ce) mma(1);                    // wave-uniform; no load inside a branch -> exact wait counts
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[wave][(i >> 2) * 8 + hf * 4 + (i & 3)][r] = acc[i];      // row = sample, column = latent unit
@@ -449,28 +447,78 @@ static QHeads q_heads_desc(const mrl_qnet* q, const float* params) {
     }
     return hd;
 }
-// latent [B][K] -> hidden activations (ws.av.h[0], ws.sv.h[0]), raw head outputs (h[1]) and q_out
-static int q_heads_forward_fused(const mrl_qnet* q, const float* lat, const float* params, QWs& ws, int B, float* q_out, hipStream_t st) {
+// latent [B][K] -> hidden activations (ws.av.h[0], ws.sv.h[0]), raw head outputs (h[1]) and q_out; with a second problem (other
+// parameters, latent, batch, workspace: the target pass next to the online pass) both go through the same two launches
+struct QPass { const float* params; const void* obs; int B; QWs* ws; float* q_out; };
+static int q_heads_forward_fused(const mrl_qnet* q, const float* lat, const float* params, QWs& ws, int B, float* q_out, hipStream_t st,
+                                 const QPass* second = nullptr) {
     const QHeads hd = q_heads_desc(q, params);
     const int ntot = hd.N0[0] + (hd.nheads > 1 ? hd.N0[1] : 0), ntiles = ntot / 32, kc = hd.K / 8;
-    const int MT = B <= 32 ? 1 : 2, zg = (B + 32 * MT - 1) / (32 * MT);
-    long S = std::max(1, std::min(16, 512 / (ntiles * zg)));
-    S = std::min<long>(S, (long)(ws.part_floats / ((size_t)B * ntot)));
+    const int MT = (B <= 32 || second) ? 1 : 2, zg = (B + 32 * MT - 1) / (32 * MT);
+    const int zg1 = second ? (second->B + 31) / 32 : 0;
+    const int Bmax = second ? std::max(B, second->B) : B;
+    long S = std::max(1, std::min(16, 512 / (ntiles * (zg + zg1))));
+    S = std::min<long>(S, (long)(ws.part_floats / ((size_t)Bmax * ntot)));
+    if (second) S = std::min<long>(S, (long)(second->ws->part_floats / ((size_t)Bmax * ntot)));
     S = std::min<long>(S, std::max(1, kc / 8));
     if (S < 1) return MRL_ENOSPC;
     const int cps = (int)((kc + S - 1) / S);
     S = (kc + cps - 1) / cps;
+    const QHeadsFwdProb f0{hd, lat, B, ws.part};
+    QHeadsFwdProb f1 = f0;
+    QHeadsOutProb o0{hd, ws.part, (int)S, B, ws.av.h[0], q->dueling ? ws.sv.h[0] : nullptr, ws.av.h[1], q->dueling ? ws.sv.h[1] : nullptr, q_out};
+    QHeadsOutProb o1 = o0;
+    if (second) {
+        QWs& w2 = *second->ws;
+        const QHeads hd2 = q_heads_desc(q, second->params);
+        f1 = QHeadsFwdProb{hd2, w2.feat.h.back(), second->B, w2.part};
+        o1 = QHeadsOutProb{hd2, w2.part, (int)S, second->B, w2.av.h[0], q->dueling ? w2.sv.h[0] : nullptr, w2.av.h[1],
+                           q->dueling ? w2.sv.h[1] : nullptr, second->q_out};
+    }
     {
-        ProfScope ps("heads.fwd", 2.0 * B * (double)hd.K * ntot, 0.0, st);
-        if (MT == 1) hipLaunchKernelGGL(q_heads_fwd_kernel<1>, dim3(ntiles, (int)S, zg), dim3(512), 0, st, hd, lat, B, ws.part, cps);
-        else hipLaunchKernelGGL(q_heads_fwd_kernel<2>, dim3(ntiles, (int)S, zg), dim3(512), 0, st, hd, lat, B, ws.part, cps);
+        ProfScope ps("heads.fwd", 2.0 * (B + (second ? second->B : 0)) * (double)hd.K * ntot, 0.0, st);
+        if (MT == 1) hipLaunchKernelGGL(q_heads_fwd_kernel<1>, dim3(ntiles, (int)S, zg + zg1), dim3(512), 0, st, f0, f1, zg, cps);
+        else hipLaunchKernelGGL(q_heads_fwd_kernel<2>, dim3(ntiles, (int)S, zg), dim3(512), 0, st, f0, f1, zg, cps);
         MRL_LAUNCH_CHECK();
     }
-    ProfScope ps("heads.out", 0.0, 4.0 * B * (double)ntot * (S + 2), st);
-    hipLaunchKernelGGL(q_heads_out_kernel, dim3(B), dim3(256), 0, st, hd, ws.part, (int)S, B, ws.av.h[0], q->dueling ? ws.sv.h[0] : nullptr,
-                       ws.av.h[1], q->dueling ? ws.sv.h[1] : nullptr, q_out);
+    ProfScope ps("heads.out", 0.0, 4.0 * (B + (second ? second->B : 0)) * (double)ntot * (S + 2), st);
+    hipLaunchKernelGGL(q_heads_out_kernel, dim3(B + (second ? second->B : 0)), dim3(256), 0, st, o0, o1);
     MRL_LAUNCH_CHECK();
     return 0;
+}
+// The online and the target pass of a learner step as ONE sequence of launches (each kernel takes both problems): possible when every
+// body layer is a conv layer the skinny-tile kernel takes and the heads have the fused form.  false: not this network / these sizes.
+static bool q_forward_pair_ok(const mrl_qnet* q, const QPass& a, const QPass& b) {
+    if (!get_option("dqn_pair", "MRL_DQN_PAIR", 1) || !q_heads_fused_ok(q, a.B) || !q_heads_fused_ok(q, b.B)) return false;
+    const bool u8 = q->qd.ob_dtype == MRL_OB_U8;
+    for (size_t i = 0; i < q->base.pi.L.size(); ++i) {
+        const Layer& l = q->base.pi.L[i];
+        if (l.kind != 0 || l.ln) return false;
+        for (const QPass* p : {&a, &b}) {
+            const void* src = i ? (const void*)p->ws->feat.h[i - 1] : p->obs;
+            if (!conv_skinny_ok(l, p->B * l.OH * l.OW, src, "fwd") || (!(i == 0 && !u8) && wres_fwd_ok(l, i == 0 && u8, src))) return false;
+        }
+    }
+    return true;
+}
+static int q_forward_pair(const mrl_qnet* q, const QPass& a, const QPass& b, hipStream_t st) {
+    const bool u8 = q->qd.ob_dtype == MRL_OB_U8;
+    for (size_t i = 0; i < q->base.pi.L.size(); ++i) {
+        const Layer& l = q->base.pi.L[i];
+        ConvGeom ga, gb;
+        fill_conv(ga, l, i ? (const void*)a.ws->feat.h[i - 1] : a.obs, a.B * l.OH * l.OW, nullptr);
+        fill_conv(gb, l, i ? (const void*)b.ws->feat.h[i - 1] : b.obs, b.B * l.OH * l.OW, nullptr);
+        const ConvSkinnyProb pb{gb, b.params + l.w_off, b.params + l.b_off, b.ws->feat.h[i]};
+        char label[40];
+        if (prof_enabled()) snprintf(label, sizeof label, "%s.fwd", l.name);
+        ProfScope ps(label, 2.0 * (ga.npix + gb.npix) * (double)l.K * l.NF, 0.0, st);
+        const float *W = a.params + l.w_off, *bias = a.params + l.b_off;
+        hipError_t e = i ? launch_conv_skinny_fwd<0>(ga, W, bias, a.ws->feat.h[i], l.NF, l.act, st, &pb)
+                         : u8 ? launch_conv_skinny_fwd<1>(ga, W, bias, a.ws->feat.h[i], l.NF, l.act, st, &pb)
+                              : launch_conv_skinny_fwd<2>(ga, W, bias, a.ws->feat.h[i], l.NF, l.act, st, &pb);
+        if (e != hipSuccess) return (int)e;
+    }
+    return q_heads_forward_fused(q, a.ws->feat.h.back(), a.params, *a.ws, a.B, a.q_out, st, &b);
 }
 // dq [B][nA] -> gradients of all four head tensors (+ biases) in the flat gradient, and (q_lat_dgrad) the latent's gradient
 static int q_heads_backward_fused(const mrl_qnet* q, const float* lat, const float* params, QWs& ws, float* grads, float* dlat, int B,
@@ -630,7 +678,8 @@ static int q_lat_dgrad(const mrl_qnet* q, const float* params, QWs& ws, float* d
     a.h = q->base.pi.L.empty() ? nullptr : ws.feat.h.back();
     a.act = q->lat_act; a.out = dlat; a.B = B; a.K = la.K;
     ProfScope ps("heads0.dgrad", fl, 0.0, st);
-    hipLaunchKernelGGL(q_lat_dgrad_kernel<8>, dim3((a.K + 31) / 32, (B + 31) / 32), dim3(512), 0, st, a);
+    if (a.w16[0] && (!q->dueling || a.w16[1])) hipLaunchKernelGGL((q_lat_dgrad_kernel<8, true>), dim3((a.K + 31) / 32, (B + 31) / 32), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((q_lat_dgrad_kernel<8, false>), dim3((a.K + 31) / 32, (B + 31) / 32), dim3(512), 0, st, a);
     MRL_LAUNCH_CHECK();
     return 0;
 }
@@ -679,7 +728,11 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
         }
     }
     QWs& wtr = roomy ? wt : ws;
-    if (par) {
+    const QPass pass_on{params, obs_t, 2 * B, &ws, ws.q_t}, pass_tg{target_params, obs_tp1, B, &wt, wt.q_tp1};
+    const bool paired = merged && q_forward_pair_ok(q, pass_on, pass_tg);
+    if (paired) {
+        if ((rc = q_forward_pair(q, pass_on, pass_tg, st))) return rc;
+    } else if (par) {
         MRL_HIP_CHECK(hipEventRecord(q->ev_fork, st));
         MRL_HIP_CHECK(hipStreamWaitEvent(q->side, q->ev_fork, 0));
         if ((rc = q_forward(q, target_params, obs_tp1, B, wtr, wtr.q_tp1, q->side))) return rc;
@@ -689,7 +742,9 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
         if ((rc = q_forward(q, target_params, obs_tp1, B, wtr, wtr.q_tp1, st))) return rc;
     }
     const float* q_tp1_on = nullptr;
-    if (merged) {
+    if (paired) {
+        q_tp1_on = ws.q_t + (size_t)B * nA;
+    } else if (merged) {
         if ((rc = q_forward(q, params, obs_t, 2 * B, ws, ws.q_t, st))) return rc;
         q_tp1_on = ws.q_t + (size_t)B * nA;
     } else {
@@ -699,7 +754,7 @@ extern "C" int mrl_qnet_td_grad(const mrl_qnet* q, const float* params, const fl
         }
         if ((rc = q_forward(q, params, obs_t, B, ws, ws.q_t, st))) return rc;
     }
-    if (par) MRL_HIP_CHECK(hipStreamWaitEvent(st, q->ev_join, 0));
+    if (par && !paired) MRL_HIP_CHECK(hipStreamWaitEvent(st, q->ev_join, 0));
     if ((rc = mrl_dqn_td(ws.q_t, wtr.q_tp1, q_tp1_on, act, rew, done, weights, gamma, B, nA, td_out,
                          loss_out, ws.dq, ws.td_scratch, stream)))
         return rc;
