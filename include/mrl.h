@@ -443,6 +443,17 @@ int mrl_tune_set(const char* label, int variant);
  *   "dqn_overlap" [MRL_DQN_OVERLAP, 1]  mrl_qnet_td_grad: the online network's obs_t / obs_tp1 passes as one batch when the caller hands
  *                  them over back to back, the target network's pass on a side stream (needs a workspace of
  *                  mrl_qnet_workspace_bytes(2 B) + mrl_qnet_workspace_bytes(B)); 0 = three passes one after the other.
+ *   "dqn_heads"   [MRL_DQN_HEADS, 1]  the standard dueling heads (one hidden layer per head, no layer norm, hidden width % 32 == 0,
+ *                  batch <= 256) as four fp32-MFMA kernels (csrc/qheads.hip.h) instead of 7 + 13 layer-wise launches; 0 = layer by layer.
+ *   "dqn_latdgrad" [MRL_DQN_LATDGRAD, 1]  both heads' first layers into the latent in one launch (q_lat_dgrad_kernel); 0 = two tiled GEMMs.
+ *   "dqn_wstream" [MRL_DQN_WSTREAM, 1]  mrl_qnet_td_grad: weight gradients (off the dz chain) on side streams next to the data
+ *                  gradients, consecutive layers round-robin over three streams with their own split-K scratch (2 / 3: one / two
+ *                  streams); 0 = everything on the caller's stream.
+ *   "dqn_pair"    [MRL_DQN_PAIR, 1]  mrl_qnet_td_grad with obs_t | obs_tp1 back to back and a conv_only body: the online pass (2 B rows)
+ *                  and the target pass (B rows) go through the SAME launches (every kernel takes two problems); 0 = two passes.
+ *   "conv_skinny" [MRL_CONV_SKINNY, 1]  conv forward / data gradient on the generic path at latency-bound sizes (<= 2 x CUs 128-row tiles):
+ *                  register-direct skinny-tile kernels (csrc/convskinny.hip.h), and row splits of 64 instead of 256 for the tiled weight
+ *                  gradient; 0 = the tiled engine as before.
  *   "conv_splitk" [MRL_CONV_SPLITK, 1]  hidden conv layers on the generic tiled engine at small batches (the Q-network's conv2 / conv3 at
  *                  batch 32-64: a few dozen workgroups walking K alone): K split over the z dimension into partial slabs + the bias /
  *                  activation pass; 0 = one workgroup per output tile walks all of K.

@@ -7,10 +7,19 @@ import sys
 
 
 def short(name):
-    n = name.split('(')[0]
+    n = name
     for pre in ('void ', 'mrl::', '(anonymous namespace)::', 'at::native::'):
         n = n.replace(pre, '')
-    return n[:110]
+    depth, out = 0, []
+    for ch in n:                       # cut at the first '(' outside template brackets: the argument list
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            break
+        out.append(ch)
+    return ''.join(out)[:110]
 
 
 def main(db, anchor, back=3):
