@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void dqn_td_kernel(const float* __restrict__ q
                                                      const float* __restrict__ rew, const float* __restrict__ done,
                                                      const float* __restrict__ w, float gamma, int B, int nA,
                                                      float* __restrict__ td_out, float* __restrict__ dq_out,
-                                                     double* __restrict__ part) {
+                                                     double* __restrict__ part, float* __restrict__ loss_out) {
     __shared__ double sh[4];
     double lsum = 0.0;
     const float invB = 1.f / (float)B;
@@ -367,7 +367,10 @@ __global__ __launch_bounds__(256) void dqn_td_kernel(const float* __restrict__ q
         }
     }
     double t = block_sum_256(lsum, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = t;
+        if (gridDim.x == 1 && loss_out) loss_out[0] = (float)((0.0 + t) / (double)B);      // one block: no second launch (same arithmetic)
+    }
 }
 __global__ void dqn_td_final_kernel(const double* __restrict__ part, int nblk, int B, float* __restrict__ loss_out) {
     if (threadIdx.x == 0) {
@@ -520,9 +523,11 @@ extern "C" int mrl_dqn_td(const float* q_t, const float* q_tp1_target, const flo
     int blocks = std::max(1, std::min((B + 255) / 256, 1024));
     ProfScope ps("dqn_td", 0.0, (double)B * ((q_tp1_online ? 12.0 : 8.0) * nA + 24.0 + (dq_out ? 4.0 * nA : 0.0)), st);
     hipLaunchKernelGGL(dqn_td_kernel, dim3(blocks), dim3(256), 0, st, q_t, q_tp1_target, q_tp1_online, act, rew, done,
-                       weights, gamma, B, nA, td_out, dq_out, (double*)scratch);
+                       weights, gamma, B, nA, td_out, dq_out, (double*)scratch, loss_out);
     MRL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dqn_td_final_kernel, dim3(1), dim3(64), 0, st, (const double*)scratch, blocks, B, loss_out);
-    MRL_LAUNCH_CHECK();
+    if (blocks > 1) {
+        hipLaunchKernelGGL(dqn_td_final_kernel, dim3(1), dim3(64), 0, st, (const double*)scratch, blocks, B, loss_out);
+        MRL_LAUNCH_CHECK();
+    }
     return 0;
 }
