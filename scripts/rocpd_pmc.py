@@ -15,7 +15,7 @@ def main(db, sub=''):
     per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
     for k, cn, v, d in rows:
         if sub in k and any(t in k for t in ('gemm', 'wres', 'imgres', 'dgrad', 'heads', 'mlp_step', 'reduce_slabs', 'adam', 'lstm',
-                                             'c1fwd', 'c1wgrad', 'wgrad_x8', 'wgrad_tr', 'conv_x6c')):
+                                             'c1fwd', 'c1wgrad', 'wgrad_x8', 'wgrad_tr', 'conv_x6c', 'conv_skinny', 'q_lat', 'q_adam')):
             acc[k][cn] += v
             disp[k].add(d)
             per[k][cn][d] += v
