@@ -2871,7 +2871,10 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         } else {
             in.obs = (const char*)obs + (size_t)c0 * ob_bytes; in.srow = nullptr;
         }
-        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st);
+        // (ws.part: split-K of an fc layer whose tiles would not fill the chip -- fc1 at a minibatch of 8192 is 256 tiles of 128 x 128 for
+        // 512 slots, each walking K = 3136 alone: 186 us where 131072 rows take 119 us per 8192; the backward pass's slabs come later on
+        // the same stream)
+        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st, ws.part, ws.part_floats);
         if (rc) return rc;
         if (m->pi.lstm && (rc = lstm_forward(m->pi, in, params, ws.pi, rnn->nseq, Bc / rnn->nseq, rnn->states, rnn->masks,
                                              in.srow, nullptr, true, st)))
