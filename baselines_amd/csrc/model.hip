@@ -2874,7 +2874,11 @@ static int model_grad_range(const mrl_model* m, const float* params, const void*
         // (ws.part: split-K of an fc layer whose tiles would not fill the chip -- fc1 at a minibatch of 8192 is 256 tiles of 128 x 128 for
         // 512 slots, each walking K = 3136 alone: 186 us where 131072 rows take 119 us per 8192; the backward pass's slabs come later on
         // the same stream)
-        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st, ws.part, ws.part_floats);
+        // Only when the whole range is that small: the remainder chunk of a large minibatch keeps the unsplit sums, so that the
+        // result of a large minibatch does not depend on how it is chunked beyond the order of the per-chunk weight-gradient sums
+        // (bench.py's self-check compares two chunkings of one 131072-sample minibatch).
+        const bool small_range = B <= 16384;
+        int rc = net_forward(m, m->pi, in, params, ws.pi, Bc, st, small_range ? ws.part : nullptr, small_range ? ws.part_floats : 0);
         if (rc) return rc;
         if (m->pi.lstm && (rc = lstm_forward(m->pi, in, params, ws.pi, rnn->nseq, Bc / rnn->nseq, rnn->states, rnn->masks,
                                              in.srow, nullptr, true, st)))
